@@ -1,0 +1,289 @@
+"""CPU oracle for the FlowNetS-pyramid flow + bilinear flow-warp hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under `coupe/` may import this file; only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg do, and
+only as the checker / the timed CPU baseline -- never as the product path.
+
+PARITY UNPINNED at the TensorFlow-1.10 / TensorLayer boundary: the reference ships
+no tests, golden vectors, weights or sample data, and TF 1.10 + tensorlayer cannot
+be imported in this image (plain ModuleNotFoundError), so this file
+is a restatement of the graph written from the reference's Python plus the
+TF-r1.10 kernel semantics recorded in SURVEY.md Appendix A.  What pins it instead:
+hand-derivable known-answer tests (tests/test_oracle_kat.py), a second independent
+restatement in plain C (oracle/vstab_oracle.c) that must agree with this one, and
+the fixtures under tests/golden/ that this file generated.
+
+Every function names the reference lines it follows (paths relative to
+/root/reference; "main" = main_flownetS_pyramid_noprevloss_dataloader.py).
+All tensors are NHWC like the reference's; `dtype` is the arithmetic type
+(torch.float64 = arbiter, torch.float32 = "what TF CPU would compute").
+Sample coordinates are always formed in fp32, as the TF kernels do, so the
+fp64 arbiter samples exactly the same source pixels.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+FLOW_KEYS = ("predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3", "predict_flow2")
+
+
+def _t(a, dtype):
+    return torch.as_tensor(np.asarray(a)).to(dtype) if not torch.is_tensor(a) else a.to(dtype)
+
+
+# --------------------------------------------------------------------------- convs
+def pad_conv(x, W_hwio, b, pad: int, stride: int):
+    """PadLayer(pad, "constant") -> Conv2d(k, stride, VALID) + bias (model.py:807-808 etc.).
+    Cross-correlation y[o] = b + sum_k x[s*o + k - p] W[k]."""
+    xn = x.permute(0, 3, 1, 2)
+    w = W_hwio.permute(3, 2, 0, 1)
+    y = F.conv2d(xn, w, b, stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def bn_lrelu(x, beta, mean, var):
+    """BatchNormLayer(act=lrelu(0.1), is_train=False, gamma_init=None) (model.py:809):
+    y = lrelu((x - mu) * rsqrt(var + 1e-5) + beta), no gamma."""
+    y = (x - mean) * torch.rsqrt(var + BN_EPS) + beta
+    return torch.maximum(y, 0.1 * y)      # tl.act.lrelu(x, 0.1) = max(x, 0.1 x), model.py:788
+
+
+def deconv4x4s2(x, W_hwoi, b, out_hw: Tuple[int, int]):
+    """DeConv2dLayer(shape=(4,4,Cout,Cin), output_shape=(B,h,w,Cout), strides 2, SAME) + bias
+    (model.py:850): y[oy,ox,co] = b + sum x[iy,ix,ci] W[ky,kx,co,ci] over oy = 2 iy + ky - 1
+    (SURVEY.md A.2)."""
+    xn = x.permute(0, 3, 1, 2)
+    w = W_hwoi.permute(3, 2, 0, 1)            # [Cin, Cout, kh, kw], no flip
+    y = F.conv_transpose2d(xn, w, b, stride=2, padding=1)
+    oh, ow = out_hw
+    assert (oh + 1) // 2 == x.shape[1] and (ow + 1) // 2 == x.shape[2]
+    return y[:, :, :oh, :ow].permute(0, 2, 3, 1).contiguous()
+
+
+# --------------------------------------------------------------------------- resizes
+def _legacy_axis(n_in: int, n_out: int):
+    """TF-1.10 ResizeBilinear (align_corners=False, no half-pixel centres) source
+    indices and weight for one axis, computed in fp32."""
+    scale = np.float32(n_in) / np.float32(n_out)
+    f = np.arange(n_out, dtype=np.float32) * scale
+    lo = np.floor(f)
+    t = (f - lo).astype(np.float32)
+    lo = lo.astype(np.int64)
+    hi = np.minimum(lo + 1, n_in - 1)
+    return lo, hi, t
+
+
+def resize_bilinear_legacy(x, oh: int, ow: int):
+    """tf.image.resize_images(x, [oh, ow]) / UpSampling2dLayer(size, is_scale=False)
+    with the defaults method=BILINEAR, align_corners=False (model.py:857,866,875,886;
+    main:497,806).  Returns the input unchanged when the size already matches."""
+    B, h, w, C = x.shape
+    if (h, w) == (oh, ow):
+        return x
+    ylo, yhi, ty = _legacy_axis(h, oh)
+    xlo, xhi, tx = _legacy_axis(w, ow)
+    ty = torch.from_numpy(ty).to(x.dtype).view(1, oh, 1, 1)
+    tx = torch.from_numpy(tx).to(x.dtype).view(1, 1, ow, 1)
+    top_rows, bot_rows = x[:, ylo], x[:, yhi]
+    tl_, tr_ = top_rows[:, :, xlo], top_rows[:, :, xhi]
+    bl_, br_ = bot_rows[:, :, xlo], bot_rows[:, :, xhi]
+    top = tl_ + (tr_ - tl_) * tx
+    bot = bl_ + (br_ - bl_) * tx
+    return top + (bot - top) * ty
+
+
+def nearest_align_corners_index(n_in: int, n_out: int) -> np.ndarray:
+    """TF-1.10 ResizeNearestNeighbor(align_corners=True) source index per output index:
+    min(roundf(i * (in-1)/(out-1)), in-1), product in fp32, round half away from zero
+    (used at model.py:883 through the helper model.py:795-802)."""
+    scale = np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)
+    f = np.arange(n_out, dtype=np.float32) * scale
+    r = np.floor(f + np.float32(0.5))          # f >= 0: roundf == floor(f + 0.5)
+    return np.minimum(r.astype(np.int64), n_in - 1)
+
+
+def predict2_fullres(concat2, W_hwio, b, H: int, W: int):
+    """model.py:882-885: PadLayer(concat2, 1) -> nearest(align_corners=True) resize to the
+    input's HxW -> Conv2d 3x3 VALID -> 2 channels.  Materialises the upsampled tensor
+    (fine at oracle sizes)."""
+    p = F.pad(concat2, (0, 0, 1, 1, 1, 1))
+    iy = nearest_align_corners_index(p.shape[1], H)
+    ix = nearest_align_corners_index(p.shape[2], W)
+    up = p[:, iy][:, :, ix]
+    return pad_conv(up, W_hwio, b, pad=0, stride=1)
+
+
+# --------------------------------------------------------------------------- network
+def level_sizes(H: int, W: int):
+    """Spatial size of every encoder stage; generalises the 384x512 literals of
+    model.py:850-886."""
+    spec = ((7, 2, 3), (5, 2, 2), (5, 2, 2), (3, 1, 1), (3, 2, 1), (3, 1, 1), (3, 2, 1), (3, 1, 1),
+            (3, 2, 1), (3, 1, 1))
+    out, h, w = [], H, W
+    for k, s, p in spec:
+        h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        out.append((h, w))
+    return out
+
+
+def flownetS_pyramid(feats, weights: Dict[str, np.ndarray], dtype=torch.float64,
+                     return_internals: bool = False):
+    """The inference graph of model.py:786-893 (is_train=False).  `weights` uses short
+    names ('1/W_conv2d', 'deconv5_bn/beta', ... SURVEY.md A.7)."""
+    x = _t(feats, dtype)
+    Wt = {k: _t(v, dtype) for k, v in weights.items()}
+    B, H, W, _ = x.shape
+    internals = {}
+
+    def enc(name, inp, k, s, p):
+        y = pad_conv(inp, Wt[f"{name}/W_conv2d"], Wt[f"{name}/b_conv2d"], p, s)
+        y = bn_lrelu(y, Wt[f"{name}/beta"], Wt[f"{name}/moving_mean"], Wt[f"{name}/moving_variance"])
+        internals[f"conv{name}"] = y
+        return y
+
+    conv1 = enc("1", x, 7, 2, 3)                       # model.py:807-809
+    conv2 = enc("2", conv1, 5, 2, 2)                   # :810-812
+    conv3 = enc("3", conv2, 5, 2, 2)                   # :813-815
+    conv3_1 = enc("3_1", conv3, 3, 1, 1)               # :818-820
+    conv4 = enc("4", conv3_1, 3, 2, 1)                 # :822-824
+    conv4_1 = enc("4_1", conv4, 3, 1, 1)               # :826-828
+    conv5 = enc("5", conv4_1, 3, 2, 1)                 # :830-832
+    conv5_1 = enc("5_1", conv5, 3, 1, 1)               # :834-836
+    conv6 = enc("6", conv5_1, 3, 2, 1)                 # :838-840
+    conv6_1 = enc("6_1", conv6, 3, 1, 1)               # :842-844
+
+    def predict(name, inp):                            # :847-848 etc. (bias, no BN, no act)
+        return pad_conv(inp, Wt[f"{name}/W_conv2d"], Wt[f"{name}/b_conv2d"], 1, 1)
+
+    def dec(dname, inp, out_hw):                       # :850-851 etc.
+        y = deconv4x4s2(inp, Wt[f"{dname}/W_deconv2d"], Wt[f"{dname}/b_deconv2d"], out_hw)
+        return bn_lrelu(y, Wt[f"{dname}_bn/beta"], Wt[f"{dname}_bn/moving_mean"],
+                        Wt[f"{dname}_bn/moving_variance"])
+
+    def upflow(uname, flow, out_hw):                   # :852 etc.
+        return deconv4x4s2(flow, Wt[f"{uname}/W_deconv2d"], Wt[f"{uname}/b_deconv2d"], out_hw)
+
+    pf6 = predict("predict6", conv6_1)
+    s5 = tuple(conv5_1.shape[1:3])
+    concat5 = torch.cat([conv5_1, dec("deconv5", conv6_1, s5), upflow("upsample6_5", pf6, s5)], 3)
+    up = resize_bilinear_legacy(pf6, *s5)
+    pf5 = (predict("predict5", concat5) + up) + up      # ElementwiseLayer folds left, :857
+
+    s4 = tuple(conv4_1.shape[1:3])
+    concat4 = torch.cat([conv4_1, dec("deconv4", concat5, s4), upflow("upsample5_4", pf5, s4)], 3)
+    up = resize_bilinear_legacy(pf5, *s4)
+    pf4 = (predict("predict4", concat4) + up) + up      # :866
+
+    s3 = tuple(conv3_1.shape[1:3])
+    concat3 = torch.cat([conv3_1, dec("deconv3", concat4, s3), upflow("upsample4_3", pf4, s3)], 3)
+    up = resize_bilinear_legacy(pf4, *s3)
+    pf3 = (predict("predict3", concat3) + up) + up      # :875
+
+    s2 = tuple(conv2.shape[1:3])
+    concat2 = torch.cat([conv2, dec("deconv2", concat3, s2), upflow("upsample3_2", pf3, s2)], 3)
+    pf2 = predict2_fullres(concat2, Wt["predict2/W_conv2d"], Wt["predict2/b_conv2d"], H, W)  # :882-885
+    up = resize_bilinear_legacy(pf3, H - 2, W - 2)      # :886 literal (382, 510)
+    for _ in range(8):                                  # :887, eight sequential adds
+        pf2 = pf2 + up
+
+    out = {"predict_flow6": pf6, "predict_flow5": pf5, "predict_flow4": pf4,
+           "predict_flow3": pf3, "predict_flow2": pf2, "flow": pf2}
+    if return_internals:
+        internals.update(concat5=concat5, concat4=concat4, concat3=concat3, concat2=concat2)
+        return out, internals
+    return out
+
+
+# --------------------------------------------------------------------------- glue
+def flow_to_output_res(pf2, net_h: int, net_w: int, out_h: int, out_w: int):
+    """main:497-498 with the literals generalised (384 -> net_h, 512 -> net_w):
+    outflow = resize_images(pf2 * net_h / pf2.shape[1], [out_h, out_w]);
+    x *= out_w / net_w; y *= out_h / net_h."""
+    dt = pf2.dtype
+    s = torch.tensor(np.float32(net_h) / np.float32(pf2.shape[1]), dtype=dt)
+    f = resize_bilinear_legacy(pf2 * s, out_h, out_w)
+    sx = torch.tensor(np.float32(out_w) / np.float32(net_w), dtype=dt)
+    sy = torch.tensor(np.float32(out_h) / np.float32(net_h), dtype=dt)
+    return torch.stack([f[..., 0] * sx, f[..., 1] * sy], dim=3)
+
+
+# --------------------------------------------------------------------------- warp
+def get_pixel_value(img, x, y):
+    """main:44-68: img[b, y, x, :] for int index maps x, y of shape [B, H, W]."""
+    B = img.shape[0]
+    b = torch.arange(B).view(B, 1, 1).expand_as(x)
+    return img[b, y.long(), x.long()]
+
+
+def tf_warp(img, flow, H: int, W: int, dtype=None):
+    """main:70-130, line by line: sample coordinates = pixel grid + flow (fp32, as the
+    graph's tensors are), corners by truncation toward zero, all four clipped to the
+    image, weights from the CLIPPED corners."""
+    dtype = dtype or img.dtype
+    img = _t(img, dtype)
+    fl = _t(flow, torch.float32)
+    gx = torch.arange(W, dtype=torch.float32).view(1, 1, W)
+    gy = torch.arange(H, dtype=torch.float32).view(1, H, 1)
+    x = gx + fl[..., 0]                                  # main:83,88
+    y = gy + fl[..., 1]
+    x0 = x.to(torch.int32)                               # tf.cast float->int32 truncates, main:92
+    y0 = y.to(torch.int32)
+    x1 = x0 + 1
+    y1 = y0 + 1
+    x0 = x0.clamp(0, W - 1); x1 = x1.clamp(0, W - 1)     # main:98-101
+    y0 = y0.clamp(0, H - 1); y1 = y1.clamp(0, H - 1)
+    Ia = get_pixel_value(img, x0, y0)                    # main:104-107
+    Ib = get_pixel_value(img, x0, y1)
+    Ic = get_pixel_value(img, x1, y0)
+    Id = get_pixel_value(img, x1, y1)
+    xd, yd = x.to(dtype), y.to(dtype)
+    x0f, x1f, y0f, y1f = (t.to(dtype) for t in (x0, x1, y0, y1))
+    wa = ((x1f - xd) * (y1f - yd)).unsqueeze(3)          # main:117-120
+    wb = ((x1f - xd) * (yd - y0f)).unsqueeze(3)
+    wc = ((xd - x0f) * (y1f - yd)).unsqueeze(3)
+    wd = ((xd - x0f) * (yd - y0f)).unsqueeze(3)
+    return wa * Ia + wb * Ib + wc * Ic + wd * Id         # tf.add_n, main:129
+
+
+def warp_discontinuity_mask(flow, H: int, W: int, delta: float = 1e-2):
+    """True where the sample coordinate is farther than `delta` from the lines
+    x in {-1, W-1}, y in {-1, H-1}, the only places tf_warp is discontinuous
+    (across x = 0 the (-1,0) extrapolation branch and the [0,1) branch
+    are the same formula).  Used to compare warped frames computed from flows that
+    differ by rounding."""
+    fl = _t(flow, torch.float32)
+    x = torch.arange(W, dtype=torch.float32).view(1, 1, W) + fl[..., 0]
+    y = torch.arange(H, dtype=torch.float32).view(1, H, 1) + fl[..., 1]
+    ok = torch.ones_like(x, dtype=torch.bool)
+    for v, lim in ((x, W - 1), (y, H - 1)):
+        ok &= (v - lim).abs() > delta
+        ok &= (v + 1).abs() > delta
+    return ok
+
+
+# --------------------------------------------------------------------------- whole path
+def stabilise_originalsize(feats, frame, weights, dtype=torch.float64):
+    """The graph `evaluate_originalSize` builds (main:491-514): network on `feats`
+    [B,Hn,Wn,Cin], flow brought to the output resolution of `frame` [B,oh,ow,3], warp."""
+    flows = flownetS_pyramid(feats, weights, dtype)
+    Hn, Wn = feats.shape[1], feats.shape[2]
+    oh, ow = frame.shape[1], frame.shape[2]
+    outflow = flow_to_output_res(flows["predict_flow2"], Hn, Wn, oh, ow)
+    warped = tf_warp(_t(frame, dtype), outflow.to(torch.float32), oh, ow, dtype)
+    return flows, outflow, warped
+
+
+def stabilise_native(feats, weights, dtype=torch.float64):
+    """The graph `evaluate` builds (main:802-807): warp of the current frame resized to
+    the flow's (H-2)x(W-2) grid by predict_flow2 itself."""
+    flows = flownetS_pyramid(feats, weights, dtype)
+    x = _t(feats, dtype)
+    H, W = x.shape[1], x.shape[2]
+    unstab = resize_bilinear_legacy(x[..., 24:27] if x.shape[3] >= 27 else x[..., -3:], H - 2, W - 2)
+    warped = tf_warp(unstab, flows["predict_flow2"].to(torch.float32), H - 2, W - 2, dtype)
+    return flows, warped

@@ -1,0 +1,122 @@
+"""Known-answer tests that pin the oracle: every expectation here is
+derivable by hand from the op definitions, none comes from running the oracle."""
+import numpy as np
+import torch
+
+from oracle import vstab_oracle as vo
+from oracle import c_oracle as co
+
+F64 = torch.float64
+
+
+def test_identity_flow_zeroes_last_row_and_column():
+    # main:98-120: at x = W-1 both corners clip to W-1 and the weights cancel
+    img = torch.rand(2, 5, 7, 3, dtype=F64) + 1.0
+    out = vo.tf_warp(img, torch.zeros(2, 5, 7, 2), 5, 7)
+    assert torch.equal(out[:, :4, :6], img[:, :4, :6])
+    assert torch.all(out[:, 4] == 0) and torch.all(out[:, :, 6] == 0)
+    assert np.array_equal(co.tf_warp(img.numpy(), np.zeros((2, 5, 7, 2), np.float32)), out.numpy())
+
+
+def test_warp_edge_semantics():
+    # one row image I = [10, 20, 40, 80]; H=2 so that y stays interior on row 0
+    img = torch.tensor([10., 20., 40., 80.], dtype=F64).view(1, 1, 4, 1).repeat(1, 2, 1, 1)
+    def at(xflow):
+        fl = torch.zeros(1, 2, 4, 2); fl[0, 0, 0, 0] = xflow      # pixel (0,0) samples x = xflow
+        return float(vo.tf_warp(img, fl, 2, 4)[0, 0, 0, 0])
+    assert at(0.5) == 15.0                     # plain bilinear
+    assert at(2.25) == 0.75 * 40 + 0.25 * 80
+    assert at(-0.5) == 1.5 * 10 - 0.5 * 20     # trunc(-0.5)=0 -> extrapolation (A.6)
+    assert at(-1.0) == 0.0                     # both corners clip to 0, weights cancel
+    assert at(-7.3) == 0.0
+    assert at(3.0) == 0.0                      # x = W-1 exactly
+    assert at(100.0) == 0.0
+
+
+def test_warp_mask_trick():
+    # main:206: warping ones gives the validity mask
+    fl = torch.zeros(1, 4, 4, 2); fl[..., 0] = 1.0
+    m = vo.tf_warp(torch.ones(1, 4, 4, 1, dtype=F64), fl, 4, 4)[0, :, :, 0]
+    exp = torch.zeros(4, 4, dtype=F64); exp[:3, :2] = 1.0
+    assert torch.equal(m, exp)
+
+
+def test_legacy_bilinear_2x_pattern():
+    # scale = 0.5 exactly: out[2k] = in[k], out[2k+1] = (in[k] + in[min(k+1,n-1)])/2
+    x = torch.tensor([1., 3., 7., 15.], dtype=F64).view(1, 1, 4, 1)
+    y = vo.resize_bilinear_legacy(x, 1, 8)[0, 0, :, 0]
+    assert y.tolist() == [1, 2, 3, 5, 7, 11, 15, 15]
+    x2 = torch.arange(6, dtype=F64).view(1, 2, 3, 1)
+    y2 = vo.resize_bilinear_legacy(x2, 4, 6)[0, :, :, 0]
+    assert y2[0].tolist() == [0, .5, 1, 1.5, 2, 2]
+    assert y2[1].tolist() == [1.5, 2, 2.5, 3, 3.5, 3.5]
+    assert y2[3].tolist() == [3, 3.5, 4, 4.5, 5, 5]
+    assert np.array_equal(co.resize_bilinear(x2.numpy(), 4, 6)[0, :, :, 0], y2.numpy())
+
+
+def test_legacy_bilinear_same_size_is_identity_and_downscale_samples_topleft():
+    x = torch.rand(1, 4, 6, 2, dtype=F64)
+    assert vo.resize_bilinear_legacy(x, 4, 6) is x
+    y = vo.resize_bilinear_legacy(x, 2, 3)            # scale 2: f = 2i, t = 0 -> plain subsample
+    assert torch.equal(y, x[:, ::2, ::2])
+
+
+def test_nearest_align_corners_index():
+    # 98 -> 384 (model.py:883 on the padded concat2): ends map to ends, roundf half away
+    idx = vo.nearest_align_corners_index(98, 384)
+    assert idx[0] == 0 and idx[-1] == 97 and np.all(np.diff(idx) >= 0) and np.diff(idx).max() == 1
+    assert vo.nearest_align_corners_index(3, 5).tolist() == [0, 1, 1, 2, 2]   # .5 -> 1, 1.5 -> 2
+    for n_in, n_out in ((98, 384), (130, 512), (66, 256), (3, 5), (182, 720), (322, 1280)):
+        ref = vo.nearest_align_corners_index(n_in, n_out)
+        assert [co.nearest_index(i, n_in, n_out) for i in range(n_out)] == ref.tolist()
+
+
+def test_deconv_impulse_response():
+    # A.2: o = 2 i + k - 1; a unit impulse at (1,1) paints W[ky,kx] at rows/cols 1..4
+    x = torch.zeros(1, 3, 3, 1, dtype=F64); x[0, 1, 1, 0] = 1.0
+    W = torch.arange(16, dtype=F64).view(4, 4, 1, 1) + 1
+    y = vo.deconv4x4s2(x, W, torch.zeros(1, dtype=F64), (6, 6))[0, :, :, 0]
+    exp = torch.zeros(6, 6, dtype=F64); exp[1:5, 1:5] = W[:, :, 0, 0]
+    assert torch.equal(y, exp)
+    # odd output_shape (ceil(5/2) == 3) is the same thing cropped
+    y5 = vo.deconv4x4s2(x, W, torch.zeros(1, dtype=F64), (5, 5))[0, :, :, 0]
+    assert torch.equal(y5, exp[:5, :5])
+    # impulse at the corner: taps with o = -1 fall off
+    x0 = torch.zeros(1, 3, 3, 1, dtype=F64); x0[0, 0, 0, 0] = 1.0
+    y0 = vo.deconv4x4s2(x0, W, torch.zeros(1, dtype=F64), (6, 6))[0, :, :, 0]
+    assert torch.equal(y0[:3, :3], W[1:, 1:, 0, 0]) and y0[3:].abs().sum() == 0
+
+
+def test_deconv_channel_layout_is_hw_out_in():
+    # W[ky,kx,co,ci] (model.py:850 shape=(4,4,512,1024) maps 1024 -> 512)
+    x = torch.zeros(1, 1, 1, 3, dtype=F64); x[0, 0, 0, 2] = 1.0
+    W = torch.zeros(4, 4, 2, 3, dtype=F64); W[1, 1, 1, 2] = 5.0
+    y = vo.deconv4x4s2(x, W, torch.tensor([0.5, 0.25], dtype=F64), (2, 2))
+    assert y[0, 0, 0].tolist() == [0.5, 5.25]
+
+
+def test_pad_conv_is_cross_correlation_with_zero_pad():
+    x = torch.zeros(1, 4, 4, 1, dtype=F64); x[0, 0, 0, 0] = 1.0
+    W = torch.arange(9, dtype=F64).view(3, 3, 1, 1)
+    y = vo.pad_conv(x, W, torch.zeros(1, dtype=F64), 1, 1)[0, :, :, 0]
+    # output (oy,ox) sees the impulse at tap (ky,kx) = (1-oy, 1-ox)
+    assert y[0, 0] == 4 and y[0, 1] == 3 and y[1, 0] == 1 and y[1, 1] == 0 and y[2:].abs().sum() == 0
+    ys = vo.pad_conv(x, W, torch.zeros(1, dtype=F64), 1, 2)[0, :, :, 0]
+    assert ys.shape == (2, 2) and ys[0, 0] == 4 and ys[0, 1] == 0
+
+
+def test_bn_lrelu_formula():
+    x = torch.tensor([[-2.0, 3.0]], dtype=F64).view(1, 1, 1, 2)
+    y = vo.bn_lrelu(x, torch.tensor([0.5, -1.0], dtype=F64), torch.tensor([1.0, 1.0], dtype=F64),
+                    torch.tensor([4.0 - 1e-5, 1.0 - 1e-5], dtype=F64))
+    assert torch.allclose(y.flatten(), torch.tensor([0.1 * (-1.5 + 0.5), 2.0 - 1.0], dtype=F64), atol=1e-12)
+
+
+def test_flow_glue_constants():
+    # main:497-498 at the reference's native numbers: 384/382 pre-scale, identity post-scale
+    pf2 = torch.ones(1, 382, 510, 2, dtype=F64)
+    f = vo.flow_to_output_res(pf2, 384, 512, 384, 512)
+    assert f.shape == (1, 384, 512, 2)
+    assert torch.allclose(f, torch.full_like(f, float(np.float32(384.0) / np.float32(382.0))), atol=1e-12)
+    f2 = vo.flow_to_output_res(pf2, 384, 512, 768, 1024)
+    assert torch.allclose(f2[..., 0] / f[0, 0, 0, 0], torch.full((1, 768, 1024), 2.0, dtype=F64))
