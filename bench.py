@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stabilised frame-pairs/sec @512x512 (BASELINE.json configs[1]).
+
+One "step" = one pass of the hot path over one batch of synthetic input, per rank:
+  feats [8,512,512,27] -> flownetS_pyramid (5 flows) -> flow to output resolution
+  (main:497-498) -> tf_warp of the [8,512,512,3] frame (main:514).
+Inputs and weights are resident in HBM before the timed region.  With N > 1 ranks every
+rank processes its own batch (weak scaling, samples are independent) and the warped frames
+of each step are all-gathered over RCCL on a side stream, overlapped with the next step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the keys below); a per-layer table goes to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = vector fp32 peak
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(batch, H, W, Cin, weights, seconds_budget=20.0):
+    """The CPU restatement (oracle, torch fp32 on all host cores) timed on a bounded sample
+    of the same workload.  kind = "port": TensorFlow 1.10 cannot exist on this box."""
+    from oracle import vstab_oracle as vo
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(0)
+    nb = min(batch, 2)
+    feats = rng.random((nb, H, W, Cin), dtype=np.float32)
+    frame = rng.random((nb, H, W, 3), dtype=np.float32)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        vo.stabilise_originalsize(feats, frame, weights, torch.float32)       # warm-up
+        warm = time.perf_counter() - t0
+        times = []
+        while len(times) < 5 and (sum(times) + warm) < seconds_budget:
+            t0 = time.perf_counter()
+            vo.stabilise_originalsize(feats, frame, weights, torch.float32)
+            times.append(time.perf_counter() - t0)
+        if not times:
+            times = [warm]
+    med = float(np.median(times))
+    return {"value": nb / med, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} timed passes of a batch of {nb} {H}x{W}x{Cin} samples "
+                      f"(network + flow glue + warp), torch-CPU fp32 restatement of the TF graph"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--cin", type=int, default=27)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of warped frames (N>1)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import coupe.optical_flow_based_deep_video_stabilization_amd as vs
+    from coupe.optical_flow_based_deep_video_stabilization_amd import runtime, netspec
+    from coupe.optical_flow_based_deep_video_stabilization_amd import distributed as vdist
+
+    B, H, W, Cin = args.batch, args.height, args.width, args.cin
+    weights = vs.initialize_global_variables(seed=1, cin=Cin)
+    g = torch.Generator().manual_seed(1000 + rank)
+    feats = torch.rand(B, H, W, Cin, generator=g).cuda()
+    frame = torch.rand(B, H, W, 3, generator=g).cuda()
+    ctx = runtime.get_context()
+
+    gather = None
+    if world > 1 and not args.no_gather:
+        gather = vdist.FrameGatherer((B, H, W, 3), world, torch.device("cuda", local_rank))
+
+    def step():
+        flows, outflow, warped = vs.stabilise_originalsize(feats, frame)
+        if gather is not None:
+            gather.submit(warped)
+        return flows, outflow, warped
+
+    for _ in range(args.warmup):
+        step()
+    if gather is not None:
+        gather.drain()
+    torch.cuda.synchronize()
+    use_events = not args.no_kernel_events
+    ctx.profile(use_events)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if gather is not None:
+        gather.drain()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel family (implicit-GEMM conv on the fp32 MFMA)
+    roofline = None
+    if use_events:
+        ms, flops, nf = ctx.profile_read()
+        ctx.profile(False)
+        tot_ms = sum(ms) / max(nf, 1)
+        tot_fl = sum(flops)
+        if rank == 0:
+            log(f"{'launch':<14}{'ms':>9}{'GFLOP':>10}{'TFLOP/s':>10}{'frac':>8}")
+            for name, m, f in zip(ctx.LAUNCH_SLOTS, ms, flops):
+                m /= max(nf, 1)
+                tf = f / (m * 1e-3) / 1e12 if m > 0 else 0.0
+                log(f"{name:<14}{m:>9.4f}{f / 1e9:>10.2f}{tf:>10.1f}{tf / MFMA_F32_PEAK_TFLOPS:>8.3f}")
+            log(f"{'all conv':<14}{tot_ms:>9.4f}{tot_fl / 1e9:>10.2f}{tot_fl / (tot_ms * 1e-3) / 1e12:>10.1f}"
+                f"{tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS:>8.3f}   step {elapsed / args.steps * 1e3:.3f} ms")
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv_mfma_kernel (15 implicit-GEMM launches per step)",
+                    "avg_launch_ms": round(tot_ms / 15, 5),
+                    "alg_flops_per_step": tot_fl}
+
+    samples = world * B * args.steps
+    value = samples / elapsed
+    res = {
+        "metric": "stabilised frame-pairs/sec @512x512",
+        "value": round(value, 2),
+        "unit": "frame-pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (uniform [0,1) frames, seeded He-normal weights; no checkpoint offline)",
+        "config": {"workload": f"batch={B} {H}x{W}x{Cin} frame stacks per GPU: FlowNetS-pyramid forward "
+                               f"(5 flows) + flow resize/scale + tf_warp at {H}x{W}",
+                   "batch_per_gpu": B, "height": H, "width": W, "cin": Cin,
+                   "gflop_per_sample": round(netspec.gflop_per_sample(H, W, Cin), 2),
+                   "all_gather": bool(gather is not None)},
+        "roofline": roofline,
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(B, H, W, Cin, weights)
+            except Exception as e:   # the baseline must never take the GPU number down with it
+                res["cpu_baseline"] = {"value": None, "unit": "frame-pairs/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

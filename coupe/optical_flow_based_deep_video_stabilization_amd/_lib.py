@@ -1,0 +1,80 @@
+"""ctypes binding of libvstab_hip.so (include/vstab.h).  No CPU fallback: if the HIP
+library cannot be built or loaded every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class VstabTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", c_float_p), ("ndim", C.c_int32), ("shape", C.c_int32 * 4)]
+
+
+class VstabWsEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 24), ("offset_bytes", C.c_int64), ("n", C.c_int32), ("h", C.c_int32),
+                ("w", C.c_int32), ("c", C.c_int32), ("c_stride", C.c_int32)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "vstab_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "vstab_destroy": (None, [C.c_void_p]),
+    "vstab_last_error": (C.c_char_p, [C.c_void_p]),
+    "vstab_version": (C.c_char_p, []),
+    "vstab_load_weights": (C.c_int, [C.c_void_p, C.POINTER(VstabTensor), C.c_int]),
+    "vstab_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "vstab_workspace_layout": (C.c_int, [C.c_int] * 4 + [C.POINTER(VstabWsEntry), C.c_int]),
+    "vstab_flownets_forward": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 +
+                               [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vstab_flow_resize_scale": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] + [C.c_int] * 2 +
+                                [C.c_float] * 3 + [C.c_void_p]),
+    "vstab_resize_bilinear": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]),
+    "vstab_warp_flow": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "vstab_get_pixel_value": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
+    "vstab_level_sizes": (C.c_int, [C.c_int, C.c_int, c_int32_p]),
+    "vstab_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "vstab_profile_reset": (C.c_int, [C.c_void_p]),
+    "vstab_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "vstab_host_layer_plan": (C.c_int, [C.c_int] * 5 + [c_int32_p, C.c_int]),
+    "vstab_host_pack_layer": (C.c_longlong, [C.c_int, C.c_int, c_float_p, C.POINTER(C.c_double), c_float_p,
+                                             C.c_longlong]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (building if needed) libvstab_hip.so.  Raises if that is impossible."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB
+        if os.environ.get("VSTAB_NO_BUILD") != "1":
+            path = _build.build()
+        elif not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing and VSTAB_NO_BUILD=1")
+        L = C.CDLL(path)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class VstabError(RuntimeError):
+    pass
+
+
+def check(code: int, ctx=None):
+    if code == 0:
+        return
+    msg = lib().vstab_last_error(ctx)
+    msg = msg.decode() if msg else "?"
+    if code in (-1, -2):          # VSTAB_E_SHAPE / VSTAB_E_ALIGN
+        raise ValueError(f"vstab error {code}: {msg}")
+    raise VstabError(f"vstab error {code}: {msg}")

@@ -1,0 +1,641 @@
+// C ABI of libvstab_hip.so (include/vstab.h): context, weight packing/upload, the
+// FlowNetS-pyramid forward schedule (model.py:786-893) and the glue/warp entry points.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/vstab.h"
+#include "vstab_internal.h"
+
+using namespace vstab;
+
+// ------------------------------------------------------------------------- errors
+static thread_local std::string g_last_error;
+
+struct vstab_ctx {
+    int device = 0;
+    bool loaded = false;
+    int cin = 0;
+    std::string err;
+    float *dev_weights = nullptr;        // one allocation holding every packed tensor
+    size_t dev_weight_floats = 0;
+    // float offsets into dev_weights
+    size_t enc_w[10], enc_b[10];
+    size_t dec_w[4], dec_b[4];
+    size_t pred_w[4], pred_b[4];         // predict6,5,4,3
+    size_t tab_w, tab_b, pred2_b;        // predict2 tap table (bias of the table = 0)
+    UpflowW up[4];
+    // profiling (vstab_profile_*): event pairs per conv-like launch, one row per forward
+    bool prof = false;
+    std::vector<hipEvent_t> prof_ev;     // [forward][15][2]
+    int prof_forwards = 0;
+    double prof_flops[15] = {0};
+};
+
+static int fail(vstab_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail(ctx, VSTAB_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------- net spec
+namespace {
+
+struct Enc { const char *name; int k, s, p, cout; };
+const Enc ENC[10] = {{"1", 7, 2, 3, 64},    {"2", 5, 2, 2, 128},   {"3", 5, 2, 2, 256},  {"3_1", 3, 1, 1, 256},
+                     {"4", 3, 2, 1, 512},   {"4_1", 3, 1, 1, 512}, {"5", 3, 2, 1, 512},  {"5_1", 3, 1, 1, 512},
+                     {"6", 3, 2, 1, 1024},  {"6_1", 3, 1, 1, 1024}};
+const char *DEC_NAME[4] = {"deconv5", "deconv4", "deconv3", "deconv2"};
+const char *UP_NAME[4] = {"upsample6_5", "upsample5_4", "upsample4_3", "upsample3_2"};
+const char *PRED_NAME[5] = {"predict6", "predict5", "predict4", "predict3", "predict2"};
+const int DEC_COUT[4] = {512, 256, 128, 64};
+const int SKIP_C[4] = {512, 512, 256, 128};                 // conv5_1, conv4_1, conv3_1, conv2
+const int CONCAT_C[4] = {1026, 770, 386, 194};              // concat5..2 (model.py:853,862,871,880)
+const int CONCAT_CS[4] = {1028, 772, 388, 196};             // padded pixel stride (multiple of 4)
+const int DEC_CIN[4] = {1024, 1026, 770, 386};              // channels the deconv consumes
+const int DEC_CS_IN[4] = {1024, 1028, 772, 388};
+const int PRED_CIN[4] = {1024, 1026, 770, 386};             // predict6,5,4,3
+const int PRED_CS[4] = {1024, 1028, 772, 388};
+
+enum Buf { B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV4, B_CONCAT4, B_CONV5, B_CONCAT5, B_CONV6, B_CONV6_1, B_T,
+           B_PARTIAL, N_BUF };
+const char *BUF_NAME[N_BUF] = {"conv1", "concat2", "conv3", "concat3", "conv4", "concat4", "conv5", "concat5",
+                               "conv6", "conv6_1", "pf2_taps", "splitk"};
+
+// where each encoder stage reads and writes: {in buf (-1 = feats), out buf, out stride, used in channels, in stride}
+struct EncIO { int in_buf, out_buf, cs_out, cs_in; };
+const EncIO ENC_IO[10] = {
+    {-1, B_CONV1, 64, 0},         {B_CONV1, B_CONCAT2, 196, 64},   {B_CONCAT2, B_CONV3, 256, 196},
+    {B_CONV3, B_CONCAT3, 388, 256}, {B_CONCAT3, B_CONV4, 512, 388}, {B_CONV4, B_CONCAT4, 772, 512},
+    {B_CONCAT4, B_CONV5, 512, 772}, {B_CONV5, B_CONCAT5, 1028, 512}, {B_CONCAT5, B_CONV6, 1024, 1028},
+    {B_CONV6, B_CONV6_1, 1024, 1024}};
+
+struct Plan {
+    int B, H, W, Cin;
+    int eh[10], ew[10];
+    size_t off[N_BUF];      // byte offsets
+    size_t bytes[N_BUF];
+    int buf_h[N_BUF], buf_w[N_BUF], buf_c[N_BUF], buf_cs[N_BUF];
+    size_t total;
+    // conv-like launches: 10 encoder, 4 deconv, 1 tap table
+    ConvParams cp[15];
+    ConvTile tile[15];
+    bool vec4[15];
+};
+
+bool level_sizes(int H, int W, int *eh, int *ew)
+{
+    int h = H, w = W;
+    for (int i = 0; i < 10; ++i) {
+        h = (h + 2 * ENC[i].p - ENC[i].k) / ENC[i].s + 1;
+        w = (w + 2 * ENC[i].p - ENC[i].k) / ENC[i].s + 1;
+        if (h < 1 || w < 1) return false;
+        eh[i] = h; ew[i] = w;
+    }
+    // deconv output_shape := skip size needs ceil(out/2) == in
+    const int lv[5] = {9, 7, 5, 3, 1};
+    for (int l = 0; l < 4; ++l)
+        if ((eh[lv[l + 1]] + 1) / 2 != eh[lv[l]] || (ew[lv[l + 1]] + 1) / 2 != ew[lv[l]]) return false;
+    return H >= 3 && W >= 3;
+}
+
+void choose_split(ConvParams &p, int BN, int BM = 128)
+{
+    const int KT = p.KH * p.NSEG * (p.SEGP / 32);
+    const long long tiles = (long long)((p.Mmax + BM - 1) / BM) * (p.Npad / BN) * p.nphase;
+    int ks = 1;
+    if (tiles < 400 && (p.N & 3) == 0) {
+        ks = (int)((512 + tiles - 1) / tiles);
+        const int cap = KT / 4 > 1 ? KT / 4 : 1;
+        if (ks > cap) ks = cap;
+        if (ks > 32) ks = 32;
+        const int kts = (KT + ks - 1) / ks;
+        ks = (KT + kts - 1) / kts;
+    }
+    p.ksplit = ks;
+}
+
+KLayout enc_layout(int i, int cin_first)
+{
+    const Enc &e = ENC[i];
+    const int cin = i == 0 ? cin_first : ENC[i - 1].cout;
+    const int cs_in = i == 0 ? cin_first : ENC_IO[i].cs_in;
+    if (cs_in == cin) return klayout_run(e.k, e.k, cs_in);
+    return klayout_tap(e.k, e.k, cin, cs_in);
+}
+
+void set_layout(ConvParams &p, const KLayout &L)
+{
+    p.KH = L.KH; p.NSEG = L.NSEG; p.SEG = L.SEG; p.SEGP = L.SEGP; p.SEG_STRIDE = L.SEG_STRIDE;
+}
+
+bool make_plan(int B, int H, int W, int Cin, Plan &pl)
+{
+    if (B < 1 || Cin < 1 || Cin > 4096) return false;
+    pl.B = B; pl.H = H; pl.W = W; pl.Cin = Cin;
+    if (!level_sizes(H, W, pl.eh, pl.ew)) return false;
+    // every tensor must stay below 2^31 elements (int32 element offsets in the kernels)
+    const long long lim = (1LL << 31) - 1;
+    if ((long long)B * H * W * Cin > lim) return false;
+
+    auto setbuf = [&](int b, int h, int w, int c, int cs) { pl.buf_h[b] = h; pl.buf_w[b] = w; pl.buf_c[b] = c; pl.buf_cs[b] = cs; };
+    setbuf(B_CONV1, pl.eh[0], pl.ew[0], 64, 64);
+    setbuf(B_CONCAT2, pl.eh[1], pl.ew[1], 194, 196);
+    setbuf(B_CONV3, pl.eh[2], pl.ew[2], 256, 256);
+    setbuf(B_CONCAT3, pl.eh[3], pl.ew[3], 386, 388);
+    setbuf(B_CONV4, pl.eh[4], pl.ew[4], 512, 512);
+    setbuf(B_CONCAT4, pl.eh[5], pl.ew[5], 770, 772);
+    setbuf(B_CONV5, pl.eh[6], pl.ew[6], 512, 512);
+    setbuf(B_CONCAT5, pl.eh[7], pl.ew[7], 1026, 1028);
+    setbuf(B_CONV6, pl.eh[8], pl.ew[8], 1024, 1024);
+    setbuf(B_CONV6_1, pl.eh[9], pl.ew[9], 1024, 1024);
+    setbuf(B_T, pl.eh[1], pl.ew[1], 32, 32);
+    setbuf(B_PARTIAL, 0, 0, 0, 0);
+    for (int b = 0; b < N_BUF; ++b) {
+        const long long n = (long long)B * pl.buf_h[b] * pl.buf_w[b] * pl.buf_cs[b];
+        if (n > lim) return false;
+        pl.bytes[b] = (size_t)n * 4;
+    }
+
+    // ---- encoder convs
+    size_t partial_floats = 0;
+    for (int i = 0; i < 10; ++i) {
+        ConvParams &p = pl.cp[i];
+        std::memset(&p, 0, sizeof p);
+        const Enc &e = ENC[i];
+        const int hi = i == 0 ? H : pl.eh[i - 1], wi = i == 0 ? W : pl.ew[i - 1];
+        p.B = B; p.Hi = hi; p.Wi = wi;
+        p.Cs_in = i == 0 ? Cin : ENC_IO[i].cs_in;
+        set_layout(p, enc_layout(i, Cin));
+        p.s_in = e.s; p.s_out = 1;
+        p.Ho = pl.eh[i]; p.Wo = pl.ew[i]; p.Cs_out = ENC_IO[i].cs_out; p.c_off = 0;
+        p.N = e.cout;
+        const int BN = e.cout >= 128 ? 128 : 64;
+        pl.tile[i] = e.cout >= 128 ? TILE_128x128 : TILE_128x64;
+        p.Npad = round_up(e.cout, BN);
+        p.act = 1; p.nphase = 1;
+        p.ph[0].Hg = pl.eh[i]; p.ph[0].Wg = pl.ew[i]; p.ph[0].M = B * pl.eh[i] * pl.ew[i];
+        p.ph[0].off_y = -e.p; p.ph[0].off_x = -e.p; p.ph[0].o_y = 0; p.ph[0].o_x = 0; p.ph[0].w_off = 0;
+        p.Mmax = p.ph[0].M;
+        pl.vec4[i] = (p.Cs_in % 4 == 0) && (p.SEG % 4 == 0);
+        choose_split(p, BN);
+        if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
+    }
+    // ---- decoder transposed convs: 4 phases of a 2x2-tap conv
+    const int dec_in[4] = {B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3};
+    const int dec_out[4] = {B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2};
+    for (int l = 0; l < 4; ++l) {
+        ConvParams &p = pl.cp[10 + l];
+        std::memset(&p, 0, sizeof p);
+        const int ib = dec_in[l], ob = dec_out[l];
+        p.B = B; p.Hi = pl.buf_h[ib]; p.Wi = pl.buf_w[ib]; p.Cs_in = pl.buf_cs[ib];
+        const KLayout L = klayout_deconv(p.Cs_in);
+        set_layout(p, L);
+        p.s_in = 1; p.s_out = 2;
+        p.Ho = pl.buf_h[ob]; p.Wo = pl.buf_w[ob]; p.Cs_out = pl.buf_cs[ob]; p.c_off = SKIP_C[l];
+        p.N = DEC_COUT[l];
+        const int BN = p.N >= 128 ? 128 : 64;
+        pl.tile[10 + l] = p.N >= 128 ? TILE_128x128 : TILE_128x64;
+        p.Npad = round_up(p.N, BN);
+        p.act = 1; p.nphase = 4;
+        const size_t phase_floats = (size_t)L.ktiles() * p.Npad * 32;
+        p.Mmax = 0;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                ConvPhase &ph = p.ph[py * 2 + px];
+                ph.Hg = (p.Ho - py + 1) / 2; ph.Wg = (p.Wo - px + 1) / 2;
+                ph.M = B * ph.Hg * ph.Wg;
+                ph.off_y = py - 1; ph.off_x = px - 1; ph.o_y = py; ph.o_x = px;
+                ph.w_off = (long long)(py * 2 + px) * phase_floats;
+                p.Mmax = std::max(p.Mmax, ph.M);
+            }
+        pl.vec4[10 + l] = true;
+        choose_split(p, BN);
+        if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad);
+    }
+    // ---- predict2 tap table: 1x1 conv concat2 -> 18 (pad 32) columns
+    {
+        ConvParams &p = pl.cp[14];
+        std::memset(&p, 0, sizeof p);
+        p.B = B; p.Hi = pl.buf_h[B_CONCAT2]; p.Wi = pl.buf_w[B_CONCAT2]; p.Cs_in = 196;
+        set_layout(p, klayout_run(1, 1, 196));
+        p.s_in = 1; p.s_out = 1;
+        p.Ho = p.Hi; p.Wo = p.Wi; p.Cs_out = 32; p.c_off = 0;
+        p.N = 32; p.Npad = 32; p.act = 0; p.nphase = 1; p.ksplit = 1;
+        p.ph[0].Hg = p.Hi; p.ph[0].Wg = p.Wi; p.ph[0].M = B * p.Hi * p.Wi; p.Mmax = p.ph[0].M;
+        pl.tile[14] = TILE_128x32; pl.vec4[14] = true;
+    }
+    pl.bytes[B_PARTIAL] = partial_floats * 4;
+    size_t off = 0;
+    for (int b = 0; b < N_BUF; ++b) {
+        pl.off[b] = off;
+        off += (pl.bytes[b] + 255) / 256 * 256;
+    }
+    pl.total = off;
+    return true;
+}
+
+const vstab_tensor *find(const vstab_tensor *t, int n, const std::string &name)
+{
+    for (int i = 0; i < n; ++i)
+        if (t[i].name && name == t[i].name) return &t[i];
+    return nullptr;
+}
+
+bool shape_is(const vstab_tensor *t, std::initializer_list<int> s)
+{
+    if (!t || t->ndim != (int)s.size()) return false;
+    int i = 0;
+    for (int v : s)
+        if (t->shape[i++] != v) return false;
+    return t->data != nullptr;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------- context
+extern "C" const char *vstab_version(void) { return "vstab-hip 0.1 (gfx950)"; }
+
+extern "C" const char *vstab_last_error(const vstab_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int vstab_create(vstab_ctx **out, int device)
+{
+    if (!out) return fail(nullptr, VSTAB_E_STATE, "vstab_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(nullptr, VSTAB_E_HIP, "vstab_create: device %d of %d", device, n);
+    HIP_TRY(nullptr, hipSetDevice(device));
+    HIP_TRY(nullptr, conv_set_attributes());
+    vstab_ctx *c = new (std::nothrow) vstab_ctx();
+    if (!c) return fail(nullptr, VSTAB_E_NOMEM, "vstab_create: out of host memory");
+    c->device = device;
+    *out = c;
+    return VSTAB_OK;
+}
+
+extern "C" void vstab_destroy(vstab_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->dev_weights) (void)hipFree(ctx->dev_weights);
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+extern "C" int vstab_level_sizes(int H, int W, int32_t *hw20)
+{
+    int eh[10], ew[10];
+    if (!hw20 || !level_sizes(H, W, eh, ew)) return fail(nullptr, VSTAB_E_SHAPE, "unsupported input size %dx%d", H, W);
+    for (int i = 0; i < 10; ++i) { hw20[2 * i] = eh[i]; hw20[2 * i + 1] = ew[i]; }
+    return VSTAB_OK;
+}
+
+extern "C" size_t vstab_workspace_bytes(int B, int H, int W, int Cin)
+{
+    Plan pl;
+    if (!make_plan(B, H, W, Cin, pl)) { fail(nullptr, VSTAB_E_SHAPE, "unsupported problem %dx%dx%dx%d", B, H, W, Cin); return 0; }
+    return pl.total;
+}
+
+extern "C" int vstab_workspace_layout(int B, int H, int W, int Cin, vstab_ws_entry *entries, int max_entries)
+{
+    Plan pl;
+    if (!entries || !make_plan(B, H, W, Cin, pl)) return fail(nullptr, VSTAB_E_SHAPE, "unsupported problem %dx%dx%dx%d", B, H, W, Cin);
+    int n = 0;
+    for (int b = 0; b < N_BUF && n < max_entries; ++b) {
+        vstab_ws_entry &e = entries[n++];
+        std::memset(&e, 0, sizeof e);
+        std::snprintf(e.name, sizeof e.name, "%s", BUF_NAME[b]);
+        e.offset_bytes = (int64_t)pl.off[b];
+        e.n = B; e.h = pl.buf_h[b]; e.w = pl.buf_w[b]; e.c = pl.buf_c[b]; e.c_stride = pl.buf_cs[b];
+        if (b == B_PARTIAL) { e.n = 1; e.h = 1; e.w = (int32_t)std::min<size_t>(pl.bytes[b] / 4, 0x7fffffff); e.c = 1; e.c_stride = 1; }
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------------- host-only helpers
+static const int LAYER_IN[15] = {-1, B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV4, B_CONCAT4, B_CONV5, B_CONCAT5, B_CONV6,
+                                 B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2};
+static const int LAYER_OUT[15] = {B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV4, B_CONCAT4, B_CONV5, B_CONCAT5, B_CONV6,
+                                  B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2, B_T};
+
+extern "C" int vstab_host_layer_plan(int B, int H, int W, int Cin, int layer, int32_t *out, int cap)
+{
+    Plan pl;
+    if (!out || layer < 0 || layer > 14 || !make_plan(B, H, W, Cin, pl))
+        return fail(nullptr, VSTAB_E_SHAPE, "layer_plan: bad arguments");
+    const ConvParams &p = pl.cp[layer];
+    const int need = 26 + 7 * p.nphase;
+    if (cap < need) return fail(nullptr, VSTAB_E_NOMEM, "layer_plan: need %d ints", need);
+    const int v[26] = {p.B, p.Hi, p.Wi, p.Cs_in, p.KH, p.NSEG, p.SEG, p.SEGP, p.SEG_STRIDE, p.s_in, p.s_out, p.Ho, p.Wo,
+                       p.Cs_out, p.c_off, p.N, p.Npad, p.act, p.nphase, p.ksplit, p.Mmax, (int)pl.tile[layer],
+                       (int)pl.vec4[layer], LAYER_IN[layer], LAYER_OUT[layer], 0};
+    for (int i = 0; i < 26; ++i) out[i] = v[i];
+    for (int k = 0; k < p.nphase; ++k) {
+        const ConvPhase &ph = p.ph[k];
+        const int q[7] = {ph.Hg, ph.Wg, ph.M, ph.off_y, ph.off_x, ph.o_y, ph.o_x};
+        for (int i = 0; i < 7; ++i) out[26 + 7 * k + i] = q[i];
+    }
+    return need;
+}
+
+extern "C" long long vstab_host_pack_layer(int Cin, int layer, const float *W, const double *scale, float *wpk,
+                                           long long cap)
+{
+    if (!W || !wpk || layer < 0 || layer > 14 || Cin < 1) return fail(nullptr, VSTAB_E_SHAPE, "pack_layer: bad arguments");
+    std::vector<double> ones;
+    if (layer < 10) {
+        const Enc &e = ENC[layer];
+        const int ci = layer == 0 ? Cin : ENC[layer - 1].cout, cs_in = layer == 0 ? Cin : ENC_IO[layer].cs_in;
+        const int npad = round_up(e.cout, e.cout >= 128 ? 128 : 64);
+        const KLayout L = enc_layout(layer, Cin);
+        const long long n = (long long)L.ktiles() * npad * 32;
+        if (cap < n) return fail(nullptr, VSTAB_E_NOMEM, "pack_layer: need %lld floats", n);
+        if (!scale) { ones.assign(npad, 1.0); scale = ones.data(); }
+        pack_conv(W, scale, e.k, e.k, ci, cs_in, e.cout, npad, L, wpk);
+        return n;
+    }
+    if (layer < 14) {
+        const int l = layer - 10, co = DEC_COUT[l], npad = round_up(co, co >= 128 ? 128 : 64);
+        const long long n = 4LL * klayout_deconv(DEC_CS_IN[l]).ktiles() * npad * 32;
+        if (cap < n) return fail(nullptr, VSTAB_E_NOMEM, "pack_layer: need %lld floats", n);
+        if (!scale) { ones.assign(npad, 1.0); scale = ones.data(); }
+        pack_deconv(W, scale, DEC_CIN[l], DEC_CS_IN[l], co, npad, wpk);
+        return n;
+    }
+    const long long n = (long long)klayout_run(1, 1, 196).ktiles() * 32 * 32;
+    if (cap < n) return fail(nullptr, VSTAB_E_NOMEM, "pack_layer: need %lld floats", n);
+    pack_predict2_table(W, 194, 196, 32, wpk);
+    return n;
+}
+
+// ------------------------------------------------------------------------- weights
+extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int count)
+{
+    if (!ctx) return fail(nullptr, VSTAB_E_STATE, "vstab_load_weights: ctx is NULL");
+    if (!t || count <= 0) return fail(ctx, VSTAB_E_WEIGHTS, "vstab_load_weights: no tensors");
+    const vstab_tensor *w1 = find(t, count, "1/W_conv2d");
+    if (!w1 || w1->ndim != 4) return fail(ctx, VSTAB_E_WEIGHTS, "missing variable 1/W_conv2d");
+    const int cin = w1->shape[2];
+    if (cin < 1 || cin > 4096) return fail(ctx, VSTAB_E_WEIGHTS, "1/W_conv2d: bad Cin %d", cin);
+
+    std::vector<float> host;
+    auto reserve = [&](size_t n) { size_t o = (host.size() + 63) / 64 * 64; host.resize(o + n, 0.f); return o; };
+    std::vector<double> scale;
+    auto need = [&](const std::string &name, std::initializer_list<int> s) -> const vstab_tensor * {
+        const vstab_tensor *x = find(t, count, name);
+        return shape_is(x, s) ? x : nullptr;
+    };
+#define NEED(var, name, ...)                                                                   \
+    const vstab_tensor *var = need(name, {__VA_ARGS__});                                        \
+    if (!var) return fail(ctx, VSTAB_E_WEIGHTS, "missing or mis-shaped variable %s", std::string(name).c_str());
+
+    // encoder
+    for (int i = 0; i < 10; ++i) {
+        const Enc &e = ENC[i];
+        const int ci = i == 0 ? cin : ENC[i - 1].cout;
+        const int cs_in = i == 0 ? cin : ENC_IO[i].cs_in;
+        const std::string n = e.name;
+        NEED(W, n + "/W_conv2d", e.k, e.k, ci, e.cout)
+        NEED(b, n + "/b_conv2d", e.cout)
+        NEED(beta, n + "/beta", e.cout)
+        NEED(mean, n + "/moving_mean", e.cout)
+        NEED(var, n + "/moving_variance", e.cout)
+        const int BN = e.cout >= 128 ? 128 : 64, npad = round_up(e.cout, BN);
+        const KLayout L = enc_layout(i, cin);
+        scale.assign(npad, 1.0);
+        ctx->enc_b[i] = reserve(npad);
+        fold_bn(b->data, beta->data, mean->data, var->data, e.cout, npad, scale.data(), host.data() + ctx->enc_b[i]);
+        ctx->enc_w[i] = reserve((size_t)L.ktiles() * npad * 32);
+        pack_conv(W->data, scale.data(), e.k, e.k, ci, cs_in, e.cout, npad, L, host.data() + ctx->enc_w[i]);
+    }
+    // decoder
+    for (int l = 0; l < 4; ++l) {
+        const std::string n = DEC_NAME[l];
+        const int co = DEC_COUT[l], ci = DEC_CIN[l], cs = DEC_CS_IN[l];
+        NEED(W, n + "/W_deconv2d", 4, 4, co, ci)
+        NEED(b, n + "/b_deconv2d", co)
+        NEED(beta, n + "_bn/beta", co)
+        NEED(mean, n + "_bn/moving_mean", co)
+        NEED(var, n + "_bn/moving_variance", co)
+        const int BN = co >= 128 ? 128 : 64, npad = round_up(co, BN);
+        scale.assign(npad, 1.0);
+        ctx->dec_b[l] = reserve(npad);
+        fold_bn(b->data, beta->data, mean->data, var->data, co, npad, scale.data(), host.data() + ctx->dec_b[l]);
+        ctx->dec_w[l] = reserve(4 * (size_t)klayout_deconv(cs).ktiles() * npad * 32);
+        pack_deconv(W->data, scale.data(), ci, cs, co, npad, host.data() + ctx->dec_w[l]);
+
+        const std::string u = UP_NAME[l];
+        NEED(uw, u + "/W_deconv2d", 4, 4, 2, 2)
+        NEED(ub, u + "/b_deconv2d", 2)
+        std::memcpy(ctx->up[l].w, uw->data, sizeof(float) * 64);
+        ctx->up[l].b[0] = ub->data[0]; ctx->up[l].b[1] = ub->data[1];
+    }
+    // predict heads
+    for (int l = 0; l < 4; ++l) {
+        const std::string n = PRED_NAME[l];
+        NEED(W, n + "/W_conv2d", 3, 3, PRED_CIN[l], 2)
+        NEED(b, n + "/b_conv2d", 2)
+        ctx->pred_w[l] = reserve((size_t)18 * PRED_CS[l]);
+        pack_predict(W->data, PRED_CIN[l], PRED_CS[l], host.data() + ctx->pred_w[l]);
+        ctx->pred_b[l] = reserve(4);
+        host[ctx->pred_b[l]] = b->data[0]; host[ctx->pred_b[l] + 1] = b->data[1];
+    }
+    {
+        NEED(W, "predict2/W_conv2d", 3, 3, 194, 2)
+        NEED(b, "predict2/b_conv2d", 2)
+        const KLayout L = klayout_run(1, 1, 196);
+        ctx->tab_w = reserve((size_t)L.ktiles() * 32 * 32);
+        pack_predict2_table(W->data, 194, 196, 32, host.data() + ctx->tab_w);
+        ctx->tab_b = reserve(32);
+        ctx->pred2_b = reserve(4);
+        host[ctx->pred2_b] = b->data[0]; host[ctx->pred2_b + 1] = b->data[1];
+    }
+#undef NEED
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->dev_weights) { (void)hipFree(ctx->dev_weights); ctx->dev_weights = nullptr; }
+    ctx->loaded = false;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->dev_weights), host.size() * sizeof(float));
+    if (e != hipSuccess) return fail(ctx, VSTAB_E_NOMEM, "hipMalloc(%zu bytes of packed weights): %s", host.size() * 4, hipGetErrorString(e));
+    HIP_TRY(ctx, hipMemcpy(ctx->dev_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->dev_weight_floats = host.size();
+    ctx->cin = cin;
+    ctx->loaded = true;
+    return VSTAB_OK;
+}
+
+// ------------------------------------------------------------------------- forward
+extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6,
+                                      float *pf5, float *pf4, float *pf3, float *pf2, void *workspace,
+                                      size_t workspace_bytes, void *stream_)
+{
+    if (!ctx) return fail(nullptr, VSTAB_E_STATE, "forward: ctx is NULL");
+    if (!ctx->loaded) return fail(ctx, VSTAB_E_STATE, "forward: vstab_load_weights has not been called");
+    if (Cin != ctx->cin) return fail(ctx, VSTAB_E_SHAPE, "forward: feats has %d channels, weights expect %d", Cin, ctx->cin);
+    if (!feats || !pf6 || !pf5 || !pf4 || !pf3 || !pf2 || !workspace) return fail(ctx, VSTAB_E_STATE, "forward: NULL buffer");
+    Plan pl;
+    if (!make_plan(B, H, W, Cin, pl)) return fail(ctx, VSTAB_E_SHAPE, "forward: unsupported problem %dx%dx%dx%d", B, H, W, Cin);
+    if (workspace_bytes < pl.total) return fail(ctx, VSTAB_E_NOMEM, "forward: workspace %zu < %zu bytes", workspace_bytes, pl.total);
+    if (((uintptr_t)workspace & 255) != 0) return fail(ctx, VSTAB_E_ALIGN, "forward: workspace must be 256-byte aligned");
+    if (((uintptr_t)feats & 15) || ((uintptr_t)pf6 & 7) || ((uintptr_t)pf5 & 7) || ((uintptr_t)pf4 & 7) ||
+        ((uintptr_t)pf3 & 7) || ((uintptr_t)pf2 & 7))
+        return fail(ctx, VSTAB_E_ALIGN, "forward: feats must be 16-byte and flows 8-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    char *ws = (char *)workspace;
+    auto buf = [&](int b) { return (float *)(ws + pl.off[b]); };
+    const float *dw = ctx->dev_weights;
+
+    // optional per-launch events
+    hipEvent_t *ev = nullptr;
+    if (ctx->prof) {
+        const size_t need = (size_t)(ctx->prof_forwards + 1) * 30;
+        while (ctx->prof_ev.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->prof_ev.push_back(e);
+        }
+        ev = ctx->prof_ev.data() + (size_t)ctx->prof_forwards * 30;
+        for (int i = 0; i < 15; ++i) {
+            const ConvParams &p = pl.cp[i];
+            double mac = 0;
+            if (i < 10) mac = (double)p.ph[0].M * ENC[i].k * ENC[i].k * (i == 0 ? Cin : ENC[i - 1].cout) * p.N;
+            else if (i < 14) mac = (double)B * p.Ho * p.Wo * 4.0 * DEC_CIN[i - 10] * p.N;
+            else mac = (double)p.ph[0].M * 194.0 * 18.0;
+            ctx->prof_flops[i] = 2.0 * mac;
+        }
+    }
+#define EV_START(slot) do { if (ev) HIP_TRY(ctx, hipEventRecord(ev[2 * (slot)], stream)); } while (0)
+#define EV_STOP(slot) do { if (ev) HIP_TRY(ctx, hipEventRecord(ev[2 * (slot) + 1], stream)); } while (0)
+
+    // encoder (model.py:807-844)
+    for (int i = 0; i < 10; ++i) {
+        ConvParams p = pl.cp[i];
+        p.in = ENC_IO[i].in_buf < 0 ? feats : buf(ENC_IO[i].in_buf);
+        p.out = buf(ENC_IO[i].out_buf);
+        p.wpk = dw + ctx->enc_w[i];
+        p.bias = dw + ctx->enc_b[i];
+        p.partial = buf(B_PARTIAL);
+        EV_START(i);
+        HIP_TRY(ctx, launch_conv(p, pl.tile[i], pl.vec4[i], stream));
+        EV_STOP(i);
+    }
+    // decoder (model.py:847-880)
+    float *pfs[5] = {pf6, pf5, pf4, pf3, pf2};
+    const int cat_buf[4] = {B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2};
+    const int lvl_enc[5] = {9, 7, 5, 3, 1};              // encoder stage giving each level's size
+    HIP_TRY(ctx, launch_predict_flow(buf(B_CONV6_1), B, pl.eh[9], pl.ew[9], 1024, dw + ctx->pred_w[0], dw + ctx->pred_b[0],
+                                     nullptr, 0, 0, pf6, stream));
+    for (int l = 0; l < 4; ++l) {
+        ConvParams p = pl.cp[10 + l];
+        const int ib = l == 0 ? B_CONV6_1 : cat_buf[l - 1];
+        p.in = buf(ib);
+        p.out = buf(cat_buf[l]);
+        p.wpk = dw + ctx->dec_w[l];
+        p.bias = dw + ctx->dec_b[l];
+        p.partial = buf(B_PARTIAL);
+        EV_START(10 + l);
+        HIP_TRY(ctx, launch_conv(p, pl.tile[10 + l], true, stream));
+        EV_STOP(10 + l);
+        const int ph = pl.eh[lvl_enc[l]], pw = pl.ew[lvl_enc[l]];          // coarser level
+        const int h = pl.eh[lvl_enc[l + 1]], w = pl.ew[lvl_enc[l + 1]];    // this level
+        HIP_TRY(ctx, launch_upflow(pfs[l], B, ph, pw, ctx->up[l], buf(cat_buf[l]), h, w, CONCAT_CS[l], CONCAT_C[l] - 2, stream));
+        if (l < 3)
+            HIP_TRY(ctx, launch_predict_flow(buf(cat_buf[l]), B, h, w, CONCAT_CS[l], dw + ctx->pred_w[l + 1],
+                                             dw + ctx->pred_b[l + 1], pfs[l], ph, pw, pfs[l + 1], stream));
+    }
+    // full-resolution head (model.py:882-887)
+    {
+        ConvParams p = pl.cp[14];
+        p.in = buf(B_CONCAT2); p.out = buf(B_T);
+        p.wpk = dw + ctx->tab_w; p.bias = dw + ctx->tab_b; p.partial = nullptr;
+        EV_START(14);
+        HIP_TRY(ctx, launch_conv(p, pl.tile[14], true, stream));
+        EV_STOP(14);
+        HIP_TRY(ctx, launch_pf2(buf(B_T), B, pl.eh[1], pl.ew[1], dw + ctx->pred2_b, pf3, pl.eh[3], pl.ew[3], pf2, H, W, stream));
+    }
+#undef EV_START
+#undef EV_STOP
+    if (ev) ctx->prof_forwards++;
+    return VSTAB_OK;
+}
+
+// ------------------------------------------------------------------------- profiling
+extern "C" int vstab_profile_enable(vstab_ctx *ctx, int enable)
+{
+    if (!ctx) return fail(nullptr, VSTAB_E_STATE, "profile_enable: ctx is NULL");
+    ctx->prof = enable != 0;
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_profile_reset(vstab_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, VSTAB_E_STATE, "profile_reset: ctx is NULL");
+    ctx->prof_forwards = 0;
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_profile_read(vstab_ctx *ctx, double *ms_sum15, double *flops15, int *n_forwards)
+{
+    if (!ctx || !ms_sum15 || !flops15 || !n_forwards) return fail(ctx, VSTAB_E_STATE, "profile_read: NULL argument");
+    for (int i = 0; i < 15; ++i) { ms_sum15[i] = 0; flops15[i] = ctx->prof_flops[i]; }
+    for (int f = 0; f < ctx->prof_forwards; ++f)
+        for (int i = 0; i < 15; ++i) {
+            float ms = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[(size_t)f * 30 + 2 * i], ctx->prof_ev[(size_t)f * 30 + 2 * i + 1]));
+            ms_sum15[i] += ms;
+        }
+    *n_forwards = ctx->prof_forwards;
+    return VSTAB_OK;
+}
+
+// ------------------------------------------------------------------------- glue + warp
+extern "C" int vstab_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow, float pre,
+                                       float sx, float sy, void *stream)
+{
+    if (!flow || !out) return fail(nullptr, VSTAB_E_STATE, "flow_resize_scale: NULL buffer");
+    if (B < 1 || h < 1 || w < 1 || oh < 1 || ow < 1) return fail(nullptr, VSTAB_E_SHAPE, "flow_resize_scale: bad shape");
+    if (((uintptr_t)flow & 7) || ((uintptr_t)out & 7)) return fail(nullptr, VSTAB_E_ALIGN, "flow_resize_scale: 8-byte alignment");
+    HIP_TRY(nullptr, launch_flow_resize_scale(flow, B, h, w, out, oh, ow, pre, sx, sy, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_resize_bilinear(const float *x, int B, int h, int w, int C, float *out, int oh, int ow, void *stream)
+{
+    if (!x || !out) return fail(nullptr, VSTAB_E_STATE, "resize_bilinear: NULL buffer");
+    if (B < 1 || h < 1 || w < 1 || C < 1 || oh < 1 || ow < 1) return fail(nullptr, VSTAB_E_SHAPE, "resize_bilinear: bad shape");
+    HIP_TRY(nullptr, launch_resize_bilinear(x, B, h, w, C, out, oh, ow, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W, int C, void *stream)
+{
+    if (!img || !flow || !out) return fail(nullptr, VSTAB_E_STATE, "warp_flow: NULL buffer");
+    if (B < 1 || H < 1 || W < 1 || C < 1) return fail(nullptr, VSTAB_E_SHAPE, "warp_flow: bad shape");
+    if ((uintptr_t)flow & 7) return fail(nullptr, VSTAB_E_ALIGN, "warp_flow: flow must be 8-byte aligned");
+    HIP_TRY(nullptr, launch_warp_flow(img, flow, out, B, H, W, C, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_get_pixel_value(const float *img, const int32_t *x, const int32_t *y, float *out, int B, int H,
+                                     int W, int C, int Hi, int Wi, void *stream)
+{
+    if (!img || !x || !y || !out) return fail(nullptr, VSTAB_E_STATE, "get_pixel_value: NULL buffer");
+    if (B < 1 || H < 1 || W < 1 || C < 1 || Hi < 1 || Wi < 1) return fail(nullptr, VSTAB_E_SHAPE, "get_pixel_value: bad shape");
+    HIP_TRY(nullptr, launch_get_pixel_value(img, x, y, out, B, H, W, C, Hi, Wi, (hipStream_t)stream));
+    return VSTAB_OK;
+}

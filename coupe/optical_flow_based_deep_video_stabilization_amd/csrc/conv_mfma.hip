@@ -1,0 +1,333 @@
+// Implicit-GEMM convolution / transposed convolution on the gfx950 fp32 matrix cores.
+//
+// Replaces, for inference, the TensorLayer stacks of model.py:807-844 (PadLayer + Conv2d
+// VALID + BatchNormLayer + lrelu) and model.py:850-851 etc. (DeConv2dLayer 4x4 s2 SAME +
+// BatchNormLayer + lrelu): BatchNorm is folded into W/b by the packer, the activation is
+// fused into the epilogue, and outputs go straight into their channel slice of the concat
+// buffers (model.py:853,862,871,880 need no copy).
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is a k-ordered chain of fp32 FMAs (exact fp32, no
+// reduced-precision path exists on gfx950), so results match an fp32 CPU convolution up
+// to summation order.
+//
+// Structure (one workgroup = 4 waves, one wave per SIMD; 2-3 workgroups per CU):
+//   * GEMM rows = output pixels, cols = output channels, K = (row tap, segment, 32-float
+//     chunk of the segment): a segment is a contiguous piece of the NHWC input row --
+//     either the whole KW*Cs run ("run mode", x and c are adjacent in NHWC) or, when only
+//     the first channels of a wider concat pixel are consumed, one tap's channels
+//     ("tap mode", NSEG = KW, stride Cs);
+//   * A tile (BM x 32) gathered from the input with 16-byte loads (dword loads for the
+//     27-channel network input), B tile (BN x 32) is a linear 16-byte copy of the
+//     pre-tiled, pre-swizzled packed weights;
+//   * both staged through registers into double-buffered LDS (loads for tile t+1 are in
+//     flight during the MFMAs of tile t, written to LDS before the single barrier per tile);
+//   * LDS rows are 128 B with the 16-byte chunk index XORed by ((row>>1)&7): the
+//     ds_read_b128 operand reads of a wave are bank-conflict free;
+//   * K order inside a tile is permuted so that ONE ds_read_b128 feeds four MFMA k-steps:
+//     lane (i, h) holds k = 8q + 4h + j for step (q, j) -- A and B use the same map;
+//   * split-K (grid.z) with fp32 slabs + a combine kernel for the small late layers.
+#include "vstab_internal.h"
+
+namespace vstab {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
+{
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
+    static_assert(MB >= 1 && NB >= 1, "wave tile");
+    constexpr int A_ROWS_V = BM / 32;   // float4 loads per thread per tile (VEC)
+    constexpr int A_ELEMS_S = BM / 8;   // dword loads per thread per tile (!VEC)
+    constexpr int B_PASS = BN / 32;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sA = reinterpret_cast<float *>(smem);
+    float *sB = sA + 2 * BM * 32;
+    int4 *rinfo = reinterpret_cast<int4 *>(sB + 2 * BN * 32);
+    int *ooff = reinterpret_cast<int *>(rinfo + BM);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int z = blockIdx.z;
+    const int phase = z / p.ksplit, split = z - phase * p.ksplit;
+    const ConvPhase ph = p.ph[phase];
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= ph.M) return;                       // uniform for the whole workgroup
+    const int n0 = blockIdx.y * BN;
+
+    // ---- per-row gather table: {input element offset, iy0, q_lo, q_hi} and output offset
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        int4 ri = make_int4(0, -(1 << 28), 0, 0);
+        int oo = -1;
+        if (m < ph.M) {
+            const int hw = ph.Hg * ph.Wg;
+            const int n = m / hw, rem = m - n * hw;
+            const int j = rem / ph.Wg, i = rem - j * ph.Wg;
+            const int iy0 = j * p.s_in + ph.off_y, ix0 = i * p.s_in + ph.off_x;
+            ri.x = ((n * p.Hi + iy0) * p.Wi + ix0) * p.Cs_in;
+            ri.y = iy0;
+            ri.z = -ix0 * p.Cs_in;
+            ri.w = (p.Wi - ix0) * p.Cs_in;
+            oo = ((n * p.Ho + j * p.s_out + ph.o_y) * p.Wo + i * p.s_out + ph.o_x) * p.Cs_out + p.c_off;
+        }
+        rinfo[r] = ri;
+        ooff[r] = oo;
+    }
+    __syncthreads();
+
+    const int kps = p.SEGP >> 5;                  // K-tiles per segment
+    const int KT = p.KH * p.NSEG * kps;
+    const int kts = (KT + p.ksplit - 1) / p.ksplit;
+    const int kt0 = split * kts;
+    const int kt1 = min(KT, kt0 + kts);
+
+    // ---- staging registers
+    f32x4 ra[VEC ? A_ROWS_V : 1];
+    float ras[VEC ? 1 : A_ELEMS_S];
+    f32x4 rb[B_PASS];
+    int4 R[VEC ? A_ROWS_V : 1];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int j = 0; j < A_ROWS_V; ++j) R[j] = rinfo[(tid >> 3) + 32 * j];
+    }
+    const long long row_pitch = (long long)p.Wi * p.Cs_in;
+    const float *wbase = p.wpk + ph.w_off + (long long)n0 * 32 + tid * 4;
+
+    // K-tile cursor (row tap, segment, chunk) of the NEXT tile to load
+    int c_ky, c_sg, c_kc;
+    {
+        const int per_row = p.NSEG * kps;
+        c_ky = kt0 / per_row;
+        const int r = kt0 - c_ky * per_row;
+        c_sg = r / kps;
+        c_kc = r - c_sg * kps;
+    }
+
+    auto load_tile = [&](int kt) {
+        const int ky = c_ky;
+        const int qseg = c_kc * 32;                       // float offset inside the segment
+        const int qabs0 = c_sg * p.SEG_STRIDE + qseg;     // float offset from the run start
+        if (++c_kc == kps) { c_kc = 0; if (++c_sg == p.NSEG) { c_sg = 0; ++c_ky; } }
+        if constexpr (VEC) {
+            const int qs = qseg + (tid & 7) * 4;
+            const int qa = qabs0 + (tid & 7) * 4;
+            const long long rowoff = (long long)ky * row_pitch + qa;
+            const bool segok = qs < p.SEG;
+#pragma unroll
+            for (int j = 0; j < A_ROWS_V; ++j) {
+                const bool ok = segok && (unsigned)(R[j].y + ky) < (unsigned)p.Hi && qa >= R[j].z && qa < R[j].w;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *reinterpret_cast<const f32x4 *>(p.in + ((long long)R[j].x + rowoff));
+                ra[j] = v;
+            }
+        } else {
+            const int qs = qseg + (tid & 31);
+            const int qa = qabs0 + (tid & 31);
+            const long long rowoff = (long long)ky * row_pitch + qa;
+            const bool segok = qs < p.SEG;
+#pragma unroll
+            for (int j = 0; j < A_ELEMS_S; ++j) {
+                const int4 ri = rinfo[(tid >> 5) + 8 * j];
+                const bool ok = segok && (unsigned)(ri.y + ky) < (unsigned)p.Hi && qa >= ri.z && qa < ri.w;
+                float v = 0.f;
+                if (ok) v = p.in[(long long)ri.x + rowoff];
+                ras[j] = v;
+            }
+        }
+        const float *ws = wbase + (long long)kt * p.Npad * 32;
+#pragma unroll
+        for (int jb = 0; jb < B_PASS; ++jb) rb[jb] = *reinterpret_cast<const f32x4 *>(ws + jb * 1024);
+    };
+
+    auto store_tile = [&](int buf) {
+        float *dA = sA + buf * (BM * 32);
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < A_ROWS_V; ++j) {
+                const int row = (tid >> 3) + 32 * j;
+                const int chunk = (tid & 7) ^ ((row >> 1) & 7);
+                *reinterpret_cast<f32x4 *>(dA + row * 32 + chunk * 4) = ra[j];
+            }
+        } else {
+            const int k = tid & 31;
+#pragma unroll
+            for (int j = 0; j < A_ELEMS_S; ++j) {
+                const int row = (tid >> 5) + 8 * j;
+                dA[row * 32 + ((((k >> 2) ^ ((row >> 1) & 7)) << 2) | (k & 3))] = ras[j];
+            }
+        }
+        float *dB = sB + buf * (BN * 32) + tid * 4;
+#pragma unroll
+        for (int jb = 0; jb < B_PASS; ++jb) *reinterpret_cast<f32x4 *>(dB + jb * 1024) = rb[jb];
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int sw = (li >> 1) & 7;
+    const int a_row0 = (wm * MB * 32 + li) * 32;
+    const int b_row0 = (wn * NB * 32 + li) * 32;
+
+    auto compute = [&](int buf) {
+        const float *cA = sA + buf * (BM * 32) + a_row0;
+        const float *cB = sB + buf * (BN * 32) + b_row0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int chunk = ((2 * q + lh) ^ sw) * 4;
+            f32x4 a[MB], b[NB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const f32x4 *>(cA + mb * 1024 + chunk);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const f32x4 *>(cB + nb * 1024 + chunk);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][jj], b[nb][jj], acc[mb][nb], 0, 0, 0);
+        }
+    };
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const bool more = (kt + 1 < kt1);
+            if (more) load_tile(kt + 1);
+            compute(buf);
+            if (more) store_tile(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (p.ksplit == 1) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = n0 + (wn * NB + nb) * 32 + li;
+            const bool cok = col < p.N;
+            const float bv = cok ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int oo = ooff[row];
+                    if (cok && oo >= 0) {
+                        float v = acc[mb][nb][r] + bv;
+                        if (p.act) v = fmaxf(v, 0.1f * v);
+                        p.out[(long long)oo + col] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        float *pz = p.partial + ((long long)z * p.Mmax + m0) * p.Npad;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = n0 + (wn * NB + nb) * 32 + li;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m0 + row < ph.M) pz[(long long)row * p.Npad + col] = acc[mb][nb][r];
+                }
+            }
+        }
+    }
+}
+
+// Sum the split-K slabs, add bias, activate, scatter to the output tensor.
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const ConvParams p)
+{
+    const int n4 = p.N >> 2;
+    const long long per_phase = (long long)p.Mmax * n4;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= per_phase * p.nphase) return;
+    const int phase = (int)(idx / per_phase);
+    const long long rem = idx - phase * per_phase;
+    const int m = (int)(rem / n4), c4 = (int)(rem - (long long)m * n4);
+    const ConvPhase ph = p.ph[phase];
+    if (m >= ph.M) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.ksplit; ++k) {
+        const float *src = p.partial + (((long long)(phase * p.ksplit + k) * p.Mmax + m) * p.Npad + c4 * 4);
+        s += *reinterpret_cast<const f32x4 *>(src);
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + c4 * 4);
+    s += bv;
+    if (p.act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e], 0.1f * s[e]);
+    }
+    const int hw = ph.Hg * ph.Wg;
+    const int n = m / hw, r2 = m - n * hw;
+    const int j = r2 / ph.Wg, i = r2 - j * ph.Wg;
+    const long long oo = ((long long)(n * p.Ho + j * p.s_out + ph.o_y) * p.Wo + i * p.s_out + ph.o_x) * p.Cs_out + p.c_off;
+    *reinterpret_cast<f32x4 *>(p.out + oo + c4 * 4) = s;
+}
+
+template <int BM, int BN>
+static constexpr size_t conv_lds_bytes() { return (size_t)(2 * BM * 32 + 2 * BN * 32) * 4 + (size_t)BM * 20; }
+
+hipError_t conv_set_attributes()
+{
+    hipError_t e;
+#define VSTAB_SET(K, BM, BN)                                                                           \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)conv_lds_bytes<BM, BN>());                                            \
+    if (e != hipSuccess) return e;
+    VSTAB_SET((conv_mfma_kernel<128, 128, 2, 2, true>), 128, 128)
+    VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, true>), 128, 64)
+    VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, false>), 128, 64)
+    VSTAB_SET((conv_mfma_kernel<128, 32, 4, 1, true>), 128, 32)
+#undef VSTAB_SET
+    return hipSuccess;
+}
+
+hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream)
+{
+    const int BM = 128;
+    const int BN = tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32);
+    if (p.Npad % BN != 0 || p.SEGP % 32 != 0 || p.SEGP < p.SEG || p.NSEG < 1 || p.ksplit < 1 || p.nphase < 1 || p.nphase > 4)
+        return hipErrorInvalidValue;
+    if (vec4 && ((p.Cs_in & 3) || (p.SEG & 3) || (p.SEG_STRIDE & 3))) return hipErrorInvalidValue;
+    if (p.ksplit > 1 && ((p.N & 3) || (p.Cs_out & 3) || (p.c_off & 3) || p.partial == nullptr))
+        return hipErrorInvalidValue;
+    dim3 grid((p.Mmax + BM - 1) / BM, p.Npad / BN, p.nphase * p.ksplit), block(256);
+    if (tile == TILE_128x128 && vec4)
+        conv_mfma_kernel<128, 128, 2, 2, true><<<grid, block, conv_lds_bytes<128, 128>(), stream>>>(p);
+    else if (tile == TILE_128x64 && vec4)
+        conv_mfma_kernel<128, 64, 2, 2, true><<<grid, block, conv_lds_bytes<128, 64>(), stream>>>(p);
+    else if (tile == TILE_128x64 && !vec4)
+        conv_mfma_kernel<128, 64, 2, 2, false><<<grid, block, conv_lds_bytes<128, 64>(), stream>>>(p);
+    else if (tile == TILE_128x32 && vec4)
+        conv_mfma_kernel<128, 32, 4, 1, true><<<grid, block, conv_lds_bytes<128, 32>(), stream>>>(p);
+    else
+        return hipErrorInvalidValue;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (p.ksplit > 1) {
+        const long long total = (long long)p.Mmax * (p.N >> 2) * p.nphase;
+        splitk_combine_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(p);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+}  // namespace vstab

@@ -1,0 +1,347 @@
+// VALU kernels of the flow pyramid and the warp: everything on the hot path that is not
+// a wide-output convolution.  All are HBM/latency-bound gathers and lerps (~1 FLOP/byte).
+// Built with -ffp-contract=off so that the lerp / weight arithmetic is the same sequence
+// of fp32 roundings the reference's TF graph performs; dot products use explicit fmaf.
+#include "vstab_internal.h"
+
+namespace vstab {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- legacy TF bilinear (ResizeBilinear, align_corners=False, no half-pixel centres):
+// f = i * (in/out) in fp32, lo = floor(f), hi = min(lo+1, in-1), t = f - lo
+struct Lerp { int lo, hi; float t; };
+__device__ __forceinline__ Lerp legacy_coord(int o, float scale, int n_in)
+{
+    const float f = (float)o * scale;
+    const float fl = floorf(f);
+    Lerp L;
+    L.lo = min((int)fl, n_in - 1);
+    L.hi = min(L.lo + 1, n_in - 1);
+    L.t = f - fl;
+    return L;
+}
+__device__ __forceinline__ float lerp2(float tl, float tr, float bl, float br, float tx, float ty)
+{
+    const float top = tl + (tr - tl) * tx;
+    const float bot = bl + (br - bl) * tx;
+    return top + (bot - top) * ty;
+}
+
+__device__ __forceinline__ f32x2 sample_flow_legacy(const float *f, int n, int h, int w, int oy, int ox,
+                                                    float sy, float sx)
+{
+    const Lerp Y = legacy_coord(oy, sy, h), X = legacy_coord(ox, sx, w);
+    const f32x2 *b = reinterpret_cast<const f32x2 *>(f) + (long long)n * h * w;
+    const f32x2 tl = b[Y.lo * w + X.lo], tr = b[Y.lo * w + X.hi];
+    const f32x2 bl = b[Y.hi * w + X.lo], br = b[Y.hi * w + X.hi];
+    f32x2 r;
+    r.x = lerp2(tl.x, tr.x, bl.x, br.x, X.t, Y.t);
+    r.y = lerp2(tl.y, tr.y, bl.y, br.y, X.t, Y.t);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------
+// predict_flowN: 3x3 pad-1 conv to 2 channels.  One wave per output pixel: lanes stride
+// over the channels with 16-byte loads, two running dot products, butterfly reduction
+// with wavefront shuffles; lane 0 adds bias and the doubled upsampled coarser flow
+// (ElementwiseLayer left fold, model.py:857: (conv + u) + u).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void predict_flow_kernel(const float *__restrict__ in, int B, int h, int w, int Cs,
+                                                           const float *__restrict__ wp, const float *__restrict__ bias2,
+                                                           const float *__restrict__ prev, int ph, int pw,
+                                                           float sy, float sx, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long total = (long long)B * h * w;
+    if (pix >= total) return;                      // wave-uniform
+    const int n = (int)(pix / (h * w));
+    const int rem = (int)(pix - (long long)n * h * w);
+    const int y = rem / w, x = rem - y * w;
+    const int c4n = Cs >> 2;
+    float a0 = 0.f, a1 = 0.f;
+    for (int ty = 0; ty < 3; ++ty) {
+        const int iy = y + ty - 1;
+        if (iy < 0 || iy >= h) continue;
+        for (int tx = 0; tx < 3; ++tx) {
+            const int ix = x + tx - 1;
+            if (ix < 0 || ix >= w) continue;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(in + ((long long)(n * h + iy) * w + ix) * Cs);
+            const f32x4 *w0 = reinterpret_cast<const f32x4 *>(wp + (long long)((ty * 3 + tx) * 2) * Cs);
+            const f32x4 *w1 = w0 + c4n;
+            for (int c = lane; c < c4n; c += 64) {
+                const f32x4 v = src[c], p = w0[c], q = w1[c];
+                a0 = fmaf(v.x, p.x, a0); a0 = fmaf(v.y, p.y, a0); a0 = fmaf(v.z, p.z, a0); a0 = fmaf(v.w, p.w, a0);
+                a1 = fmaf(v.x, q.x, a1); a1 = fmaf(v.y, q.y, a1); a1 = fmaf(v.z, q.z, a1); a1 = fmaf(v.w, q.w, a1);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a0 += __shfl_xor(a0, off, 64);
+        a1 += __shfl_xor(a1, off, 64);
+    }
+    if (lane == 0) {
+        float v0 = a0 + bias2[0], v1 = a1 + bias2[1];
+        if (prev) {
+            const f32x2 u = sample_flow_legacy(prev, n, ph, pw, y, x, sy, sx);
+            v0 = (v0 + u.x) + u.x;
+            v1 = (v1 + u.y) + u.y;
+        }
+        f32x2 o; o.x = v0; o.y = v1;
+        reinterpret_cast<f32x2 *>(out)[pix] = o;
+    }
+}
+
+hipError_t launch_predict_flow(const float *in, int B, int h, int w, int Cs, const float *wp, const float *bias2,
+                               const float *prev, int ph, int pw, float *out, hipStream_t stream)
+{
+    if (Cs & 3) return hipErrorInvalidValue;
+    const long long total = (long long)B * h * w;
+    const float sy = prev ? (float)ph / (float)h : 0.f, sx = prev ? (float)pw / (float)w : 0.f;
+    // when the coarser level already has this size TF returns it unchanged; scale 1 does that
+    predict_flow_kernel<<<dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream>>>(in, B, h, w, Cs, wp, bias2, prev,
+                                                                                   ph, pw, sy, sx, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// upsample_flowN: 2->2 channel 4x4 stride-2 SAME transposed conv + bias (model.py:852).
+// o = 2*i + k - 1  =>  for output o the taps are k = (o+1)&1 and k+2, i = (o+1-k)/2.
+// Writes (u, v, 0, 0) so the two pad channels of the concat pixel are zero every call.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upflow_kernel(const float *__restrict__ flow, int B, int h, int w, UpflowW W,
+                                                     float *__restrict__ concat, int oh, int ow, int Cs, int c_off)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * oh * ow;
+    if (idx >= total) return;
+    const int n = (int)(idx / (oh * ow));
+    const int rem = (int)(idx - (long long)n * oh * ow);
+    const int oy = rem / ow, ox = rem - oy * ow;
+    float u = W.b[0], v = W.b[1];
+    const f32x2 *fb = reinterpret_cast<const f32x2 *>(flow) + (long long)n * h * w;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int ky = ((oy + 1) & 1) + 2 * a;
+        const int iy = (oy + 1 - ky) >> 1;
+        if (iy < 0 || iy >= h) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int kx = ((ox + 1) & 1) + 2 * b;
+            const int ix = (ox + 1 - kx) >> 1;
+            if (ix < 0 || ix >= w) continue;
+            const f32x2 f = fb[iy * w + ix];
+            const float *wk = W.w + (ky * 4 + kx) * 4;     // [co][ci]
+            u = fmaf(f.x, wk[0], u); u = fmaf(f.y, wk[1], u);
+            v = fmaf(f.x, wk[2], v); v = fmaf(f.y, wk[3], v);
+        }
+    }
+    f32x4 o = {u, v, 0.f, 0.f};
+    *reinterpret_cast<f32x4 *>(concat + idx * Cs + c_off) = o;
+}
+
+hipError_t launch_upflow(const float *flow, int B, int h, int w, const UpflowW &W, float *concat, int oh, int ow, int Cs,
+                         int c_off, hipStream_t stream)
+{
+    if ((Cs & 3) || (c_off & 3) || c_off + 4 > Cs) return hipErrorInvalidValue;
+    const long long total = (long long)B * oh * ow;
+    upflow_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(flow, B, h, w, W, concat, oh, ow, Cs, c_off);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// predict_flow2 at full resolution (model.py:882-887).  The reference pads concat2 by one
+// pixel, nearest-upsamples it (align_corners=True) to the input's HxW and runs a 3x3 VALID
+// conv.  Every tap of that conv reads some source pixel s = (ny(y+dy), nx(x+dx)), so
+//   pf2_raw[y,x,o] = b[o] + sum_{dy,dx} T[s][dy*3+dx][o],  T[s][tap][o] = sum_c P[s][c] W[tap][c][o]
+// T is a 1x1 conv to 18 channels computed once per source pixel by the MFMA kernel; this
+// kernel does the 9 gathers, then pf2 = pf2_raw + 8 sequential adds of up(pf3).
+// Index map: src = min((int)roundf(i * (in-1)/(out-1)), in-1) on the padded grid.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int nearest_ac(int i, float scale, int n_in)
+{
+    return min((int)roundf((float)i * scale), n_in - 1);
+}
+
+__global__ __launch_bounds__(256) void pf2_kernel(const float *__restrict__ T, int B, int h2, int w2,
+                                                  const float *__restrict__ bias2, const float *__restrict__ pf3,
+                                                  int h3, int w3, float *__restrict__ pf2, int H, int W,
+                                                  float nsy, float nsx, float usy, float usx)
+{
+    const int oh = H - 2, ow = W - 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * oh * ow;
+    if (idx >= total) return;
+    const int n = (int)(idx / (oh * ow));
+    const int rem = (int)(idx - (long long)n * oh * ow);
+    const int y = rem / ow, x = rem - y * ow;
+    int sy[3], sx[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        sy[d] = nearest_ac(y + d, nsy, h2 + 2) - 1;     // index into the unpadded concat2
+        sx[d] = nearest_ac(x + d, nsx, w2 + 2) - 1;
+    }
+    float a0 = bias2[0], a1 = bias2[1];
+    const float *Tn = T + (long long)n * h2 * w2 * 32;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        if (sy[dy] < 0 || sy[dy] >= h2) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            if (sx[dx] < 0 || sx[dx] >= w2) continue;
+            const f32x2 t = *reinterpret_cast<const f32x2 *>(Tn + ((long long)sy[dy] * w2 + sx[dx]) * 32 + (dy * 3 + dx) * 2);
+            a0 += t.x;
+            a1 += t.y;
+        }
+    }
+    const f32x2 u = sample_flow_legacy(pf3, n, h3, w3, y, x, usy, usx);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { a0 += u.x; a1 += u.y; }
+    f32x2 o; o.x = a0; o.y = a1;
+    reinterpret_cast<f32x2 *>(pf2)[idx] = o;
+}
+
+hipError_t launch_pf2(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3,
+                      float *pf2, int H, int W, hipStream_t stream)
+{
+    const long long total = (long long)B * (H - 2) * (W - 2);
+    const float nsy = H > 1 ? (float)(h2 + 2 - 1) / (float)(H - 1) : 0.f;
+    const float nsx = W > 1 ? (float)(w2 + 2 - 1) / (float)(W - 1) : 0.f;
+    const float usy = (float)h3 / (float)(H - 2), usx = (float)w3 / (float)(W - 2);
+    pf2_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(T, B, h2, w2, bias2, pf3, h3, w3, pf2, H, W,
+                                                                             nsy, nsx, usy, usx);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// main:497-498: out = resize_images(flow * pre, [oh, ow]); x *= sx; y *= sy.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_resize_scale_kernel(const float *__restrict__ flow, int B, int h, int w,
+                                                                float *__restrict__ out, int oh, int ow, float pre,
+                                                                float sx, float sy, float ry, float rx)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * oh * ow;
+    if (idx >= total) return;
+    const int n = (int)(idx / (oh * ow));
+    const int rem = (int)(idx - (long long)n * oh * ow);
+    const int oy = rem / ow, ox = rem - oy * ow;
+    const Lerp Y = legacy_coord(oy, ry, h), X = legacy_coord(ox, rx, w);
+    const f32x2 *b = reinterpret_cast<const f32x2 *>(flow) + (long long)n * h * w;
+    f32x2 tl = b[Y.lo * w + X.lo], tr = b[Y.lo * w + X.hi], bl = b[Y.hi * w + X.lo], br = b[Y.hi * w + X.hi];
+    f32x2 o;
+    o.x = lerp2(tl.x * pre, tr.x * pre, bl.x * pre, br.x * pre, X.t, Y.t) * sx;
+    o.y = lerp2(tl.y * pre, tr.y * pre, bl.y * pre, br.y * pre, X.t, Y.t) * sy;
+    reinterpret_cast<f32x2 *>(out)[idx] = o;
+}
+
+hipError_t launch_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow, float pre, float sx,
+                                    float sy, hipStream_t stream)
+{
+    const long long total = (long long)B * oh * ow;
+    // same size: TF returns the tensor unchanged; scale 1.0 gives lo = i, t = 0 -> identical values
+    const float ry = (float)h / (float)oh, rx = (float)w / (float)ow;
+    flow_resize_scale_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(flow, B, h, w, out, oh, ow,
+                                                                                           pre, sx, sy, ry, rx);
+    return hipGetLastError();
+}
+
+// generic NHWC legacy-bilinear resize (main:806; one thread per output element)
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float *__restrict__ x, int B, int h, int w, int C,
+                                                              float *__restrict__ out, int oh, int ow, float ry, float rx)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * oh * ow * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long pix = idx / C;
+    const int n = (int)(pix / (oh * ow));
+    const int rem = (int)(pix - (long long)n * oh * ow);
+    const int oy = rem / ow, ox = rem - oy * ow;
+    const Lerp Y = legacy_coord(oy, ry, h), X = legacy_coord(ox, rx, w);
+    const float *b = x + (long long)n * h * w * C + c;
+    const float tl = b[((long long)Y.lo * w + X.lo) * C], tr = b[((long long)Y.lo * w + X.hi) * C];
+    const float bl = b[((long long)Y.hi * w + X.lo) * C], br = b[((long long)Y.hi * w + X.hi) * C];
+    out[idx] = lerp2(tl, tr, bl, br, X.t, Y.t);
+}
+
+hipError_t launch_resize_bilinear(const float *x, int B, int h, int w, int C, float *out, int oh, int ow, hipStream_t stream)
+{
+    const long long total = (long long)B * oh * ow * C;
+    if (h == oh && w == ow)
+        return hipMemcpyAsync(out, x, sizeof(float) * total, hipMemcpyDeviceToDevice, stream);
+    resize_bilinear_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(
+        x, B, h, w, C, out, oh, ow, (float)h / (float)oh, (float)w / (float)ow);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// tf_warp (main:70-130): dense backward warp.  One thread per output pixel: one 8-byte
+// flow read, four corner gathers, C stores.  Corners by float->int truncation toward
+// zero, all four clipped into the image, weights from the CLIPPED corners (A.6).
+// The saturating v_cvt_i32_f32 keeps NaN/inf flows inside the image (no fault).
+// ---------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void warp_flow_kernel(const float *__restrict__ img, const float *__restrict__ flow,
+                                                        float *__restrict__ out, int B, int H, int W, int Cdyn)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * H * W;
+    if (idx >= total) return;
+    const int n = (int)(idx / (H * W));
+    const int rem = (int)(idx - (long long)n * H * W);
+    const int yy = rem / W, xx = rem - yy * W;
+    const f32x2 f = reinterpret_cast<const f32x2 *>(flow)[idx];
+    const float x = (float)xx + f.x, y = (float)yy + f.y;
+    int x0 = (int)x, y0 = (int)y;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
+    y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
+    const float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
+    const float wa = (x1f - x) * (y1f - y), wb = (x1f - x) * (y - y0f);
+    const float wc = (x - x0f) * (y1f - y), wd = (x - x0f) * (y - y0f);
+    const int Cc = C > 0 ? C : Cdyn;
+    const float *base = img + (long long)n * H * W * Cc;
+    const float *Ia = base + ((long long)y0 * W + x0) * Cc, *Ib = base + ((long long)y1 * W + x0) * Cc;
+    const float *Ic = base + ((long long)y0 * W + x1) * Cc, *Id = base + ((long long)y1 * W + x1) * Cc;
+    float *o = out + idx * Cc;
+    for (int c = 0; c < Cc; ++c) o[c] = ((wa * Ia[c] + wb * Ib[c]) + wc * Ic[c]) + wd * Id[c];   // tf.add_n order
+}
+
+hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W, int C, hipStream_t stream)
+{
+    const long long total = (long long)B * H * W;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (C == 3) warp_flow_kernel<3><<<grid, block, 0, stream>>>(img, flow, out, B, H, W, C);
+    else if (C == 1) warp_flow_kernel<1><<<grid, block, 0, stream>>>(img, flow, out, B, H, W, C);
+    else warp_flow_kernel<0><<<grid, block, 0, stream>>>(img, flow, out, B, H, W, C);
+    return hipGetLastError();
+}
+
+// get_pixel_value (main:44-68): out[b,h,w,:] = img[b, y[b,h,w], x[b,h,w], :]
+__global__ __launch_bounds__(256) void get_pixel_value_kernel(const float *__restrict__ img, const int32_t *__restrict__ x,
+                                                              const int32_t *__restrict__ y, float *__restrict__ out,
+                                                              int B, int H, int W, int C, int Hi, int Wi)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * H * W;
+    if (idx >= total) return;
+    const int n = (int)(idx / (H * W));
+    const int xi = min(max(x[idx], 0), Wi - 1), yi = min(max(y[idx], 0), Hi - 1);
+    const float *s = img + (((long long)n * Hi + yi) * Wi + xi) * C;
+    float *o = out + idx * C;
+    for (int c = 0; c < C; ++c) o[c] = s[c];
+}
+
+hipError_t launch_get_pixel_value(const float *img, const int32_t *x, const int32_t *y, float *out, int B, int H, int W,
+                                  int C, int Hi, int Wi, hipStream_t stream)
+{
+    const long long total = (long long)B * H * W;
+    get_pixel_value_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, x, y, out, B, H, W, C, Hi, Wi);
+    return hipGetLastError();
+}
+
+}  // namespace vstab

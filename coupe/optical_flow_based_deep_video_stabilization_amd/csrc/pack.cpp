@@ -1,0 +1,104 @@
+// Host-side weight packing: reference layouts -> the K-tiled, swizzled operand layout the
+// implicit-GEMM kernel streams.  Pure CPU code (unit-tested without a GPU).
+//
+// Packed layout: [KT][Npad][32] floats.  K-tile kt = ((t*NSEG + s)*SEGP/32 + kc) holds, for
+// output column n, the 32 weights multiplying input floats q = kc*32 .. +31 of segment s of
+// row tap t; inside the 32-float row the 16-byte chunks are XOR-swizzled by ((n>>1)&7)
+// (swz32) so that the kernel's global->LDS copy of a B tile is linear.
+#include <cmath>
+#include <cstring>
+
+#include "vstab_internal.h"
+
+namespace vstab {
+
+KLayout klayout_run(int kh, int kw, int cs_in)
+{
+    KLayout L{kh, 1, kw * cs_in, round_up(kw * cs_in, 32), 0};
+    return L;
+}
+KLayout klayout_tap(int kh, int kw, int cin, int cs_in)
+{
+    KLayout L{kh, kw, cin, round_up(cin, 32), cs_in};
+    return L;
+}
+KLayout klayout_deconv(int cs_in) { return klayout_run(2, 2, cs_in); }
+
+void fold_bn(const float *b, const float *beta, const float *mean, const float *var, int cout, int npad,
+             double *scale, float *bias_out)
+{
+    for (int n = 0; n < npad; ++n) {
+        double s = 1.0, bb = 0.0;
+        if (n < cout) {
+            bb = b ? (double)b[n] : 0.0;
+            if (beta) {
+                s = 1.0 / std::sqrt((double)var[n] + 1e-5);
+                bb = (bb - (double)mean[n]) * s + (double)beta[n];
+            }
+        }
+        scale[n] = s;
+        bias_out[n] = (float)bb;
+    }
+}
+
+// generic fill: wfn(t, kx, ci, n) -> weight, kx/ci derived from the absolute run offset
+template <class F>
+static void pack_generic(const KLayout &L, int cs_in, int cin, int kw, int cout, int npad, F wfn, float *wpk)
+{
+    const int kps = L.SEGP / 32;
+    std::memset(wpk, 0, sizeof(float) * (size_t)L.ktiles() * npad * 32);
+    for (int t = 0; t < L.KH; ++t)
+        for (int s = 0; s < L.NSEG; ++s)
+            for (int q = 0; q < L.SEG; ++q) {
+                const int qa = s * L.SEG_STRIDE + q;
+                const int kx = qa / cs_in, ci = qa % cs_in;
+                if (kx >= kw || ci >= cin) continue;
+                const size_t kt = (size_t)(t * L.NSEG + s) * kps + q / 32;
+                float *row = wpk + kt * npad * 32;
+                for (int n = 0; n < cout; ++n) row[(size_t)n * 32 + swz32(n, q & 31)] = wfn(t, kx, ci, n);
+            }
+}
+
+void pack_conv(const float *W, const double *scale, int kh, int kw, int cin, int cs_in, int cout, int npad,
+               const KLayout &L, float *wpk)
+{
+    (void)kh;
+    pack_generic(L, cs_in, cin, kw, cout, npad,
+                 [&](int t, int kx, int ci, int n) {
+                     return (float)((double)W[(((size_t)t * kw + kx) * cin + ci) * cout + n] * scale[n]);
+                 },
+                 wpk);
+}
+
+void pack_deconv(const float *W, const double *scale, int cin, int cs_in, int cout, int npad, float *wpk)
+{
+    const KLayout L = klayout_deconv(cs_in);
+    const size_t phase_floats = (size_t)L.ktiles() * npad * 32;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            // input row iy = j + py - 1 + t  <->  ky = 3 - py - 2t   (oy = 2*iy + ky - 1 = 2j + py)
+            pack_generic(L, cs_in, cin, 2, cout, npad,
+                         [&](int t, int bx, int ci, int n) {
+                             const int ky = 3 - py - 2 * t, kx = 3 - px - 2 * bx;
+                             return (float)((double)W[(((size_t)ky * 4 + kx) * cout + n) * cin + ci] * scale[n]);
+                         },
+                         wpk + (size_t)(py * 2 + px) * phase_floats);
+        }
+}
+
+void pack_predict(const float *W, int cin, int cs_in, float *wp)
+{
+    std::memset(wp, 0, sizeof(float) * 18 * (size_t)cs_in);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int o = 0; o < 2; ++o) wp[((size_t)tap * 2 + o) * cs_in + ci] = W[((size_t)tap * cin + ci) * 2 + o];
+}
+
+void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wpk)
+{
+    const KLayout L = klayout_run(1, 1, cs_in);
+    pack_generic(L, cs_in, cin, 1, 18, npad,
+                 [&](int, int, int ci, int n) { return W[((size_t)(n >> 1) * cin + ci) * 2 + (n & 1)]; }, wpk);
+}
+
+}  // namespace vstab

@@ -1,0 +1,127 @@
+// Internal declarations shared by the HIP kernels, the host packer and the C ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vstab {
+
+// ---------------------------------------------------------------------------------
+// Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// GEMM view: rows m = output pixels of one "phase" grid (n, j, i), columns = output
+// channels, K = KH row-taps x NSEG segments x SEG floats.  A segment is a contiguous
+// piece of the NHWC input row starting SEG_STRIDE*s floats after the run start: either
+// the whole KW*Cs run (run mode, NSEG = 1; x and c are adjacent in NHWC) or the first
+// Cin channels of tap s of a wider pixel (tap mode, NSEG = KW, SEG_STRIDE = Cs).
+//   input row   iy  = j*s_in + off_y + t          (t = row tap 0..KH-1)
+//   run start   ix0 = i*s_in + off_x              (float offset q in the run -> element
+//                                                  ((n*Hi+iy)*Wi+ix0)*Cs_in + q)
+//   output      (j*s_out + o_y, i*s_out + o_x), channel c_off + col, pixel stride Cs_out
+// A plain conv is one phase (s_in = stride, off = -pad, s_out = 1); a 4x4 stride-2
+// transposed conv is four phases of a 2x2-tap conv (s_in = 1, s_out = 2).
+// Out-of-image taps and the padded tail of the run read as zero.
+// ---------------------------------------------------------------------------------
+struct ConvPhase {
+    int Hg, Wg, M;          // phase grid and its number of GEMM rows (B*Hg*Wg)
+    int off_y, off_x;       // input offsets
+    int o_y, o_x;           // output offsets
+    int pad_;
+    long long w_off;        // float offset of this phase's packed weights inside wpk
+};
+
+struct ConvParams {
+    const float *in;
+    const float *wpk;       // packed weights [KT][Npad][32], 16B chunks XOR-swizzled
+    const float *bias;      // [Npad] (BatchNorm already folded in)
+    float *out;
+    float *partial;         // split-K slabs [(phase*ksplit+split)][Mmax][Npad]
+    int B, Hi, Wi, Cs_in;
+    int KH;                 // row taps
+    int NSEG, SEG, SEGP;    // segments per row tap, floats per segment, SEG rounded up to 32
+    int SEG_STRIDE;         // floats between segment starts (run mode: NSEG = 1)
+    int s_in, s_out;
+    int Ho, Wo, Cs_out, c_off;
+    int N, Npad;
+    int act;                // 1 = leaky relu 0.1
+    int nphase, ksplit, Mmax;
+    ConvPhase ph[4];
+};
+
+enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2 };
+
+// Launch the implicit-GEMM kernel (and the split-K combine when p.ksplit > 1).
+hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream);
+hipError_t conv_set_attributes();   // raises the dynamic-LDS limit once per process
+
+// ---------------------------------------------------------------------------------
+// Small VALU kernels of the flow pyramid and the warp.
+// ---------------------------------------------------------------------------------
+// predict_flowN = 3x3 pad-1 conv to 2 channels (+bias) [+ (.. + u) + u with
+// u = legacy-bilinear upsample of the coarser flow]; model.py:848,856-857,865-866,874-875
+hipError_t launch_predict_flow(const float *in, int B, int h, int w, int Cs, const float *wp,
+                               const float *bias2, const float *prev, int ph, int pw, float *out,
+                               hipStream_t stream);
+
+// upsample_flowN = 4x4 s2 SAME transposed conv 2->2 + bias, written as (u, v, 0, 0) into
+// the last four floats of the concat pixel; model.py:852,861,870,879
+struct UpflowW { float w[64]; float b[2]; };   // w[ky][kx][co][ci]
+hipError_t launch_upflow(const float *flow, int B, int h, int w, const UpflowW &W, float *concat,
+                         int oh, int ow, int Cs, int c_off, hipStream_t stream);
+
+// predict_flow2 (model.py:882-887) from the per-source-pixel tap table T[B,h2,w2,32]
+// (T[.., tap*2 + o] = sum_c concat2[.., c] * W[tap][c][o]) and pf3.
+hipError_t launch_pf2(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3,
+                      int h3, int w3, float *pf2, int H, int W, hipStream_t stream);
+
+hipError_t launch_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh,
+                                    int ow, float pre, float sx, float sy, hipStream_t stream);
+hipError_t launch_resize_bilinear(const float *x, int B, int h, int w, int C, float *out, int oh,
+                                  int ow, hipStream_t stream);
+hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W,
+                            int C, hipStream_t stream);
+hipError_t launch_get_pixel_value(const float *img, const int32_t *x, const int32_t *y, float *out,
+                                  int B, int H, int W, int C, int Hi, int Wi, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------
+// Host-side weight packing (pack.cpp): pure CPU code.
+// ---------------------------------------------------------------------------------
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// Physical position of logical float k (0..31) of row n inside a 32-float LDS/packed row:
+// 16-byte chunks are XOR-swizzled with ((n>>1)&7) so that ds_read_b128 of 16 different
+// rows is bank-conflict free.
+inline int swz32(int n, int k) { return ((((k >> 2) ^ ((n >> 1) & 7)) << 2) | (k & 3)); }
+
+// K layout of one conv GEMM (mirrors the fields of ConvParams)
+struct KLayout {
+    int KH, NSEG, SEG, SEGP, SEG_STRIDE;
+    int ktiles() const { return KH * NSEG * (SEGP / 32); }
+};
+KLayout klayout_run(int kh, int kw, int cs_in);            // whole KW*Cs run per row tap
+KLayout klayout_tap(int kh, int kw, int cin, int cs_in);   // first cin channels of each tap
+
+// BatchNorm fold (inference, no gamma): scale[n] = rsqrt(var+eps), bias' = (b-mean)*scale+beta.
+// beta == nullptr means "no BatchNorm".  Outputs have npad entries (zero padded).
+void fold_bn(const float *b, const float *beta, const float *mean, const float *var, int cout,
+             int npad, double *scale, float *bias_out);
+
+// Conv weights W[kh][kw][Cin][Cout] -> packed [KT][Npad][32] for the given K layout.
+// cs_in = channel stride of the input buffer (>= cin; extra channels get zero weights).
+void pack_conv(const float *W, const double *scale, int kh, int kw, int cin, int cs_in, int cout,
+               int npad, const KLayout &L, float *wpk);
+
+// Transposed-conv weights W[4][4][Cout][Cin] -> 4 phase matrices (phase = py*2+px), each a
+// 2-row-tap conv in run mode (run = 2*cs_in); phase p starts at p*phase_floats.
+void pack_deconv(const float *W, const double *scale, int cin, int cs_in, int cout, int npad,
+                 float *wpk);
+KLayout klayout_deconv(int cs_in);
+
+// predict conv W[3][3][Cin][2] -> [9][2][cs_in]
+void pack_predict(const float *W, int cin, int cs_in, float *wp);
+
+// predict2 W[3][3][Cin][2] -> 1x1 conv (run mode over cs_in) with 18 (pad npad) output
+// columns, col = tap*2 + o
+void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wpk);
+
+}  // namespace vstab

@@ -1,0 +1,81 @@
+"""Multi-GPU layer: one process per GPU, samples sharded by contiguous blocks, and ONE
+collective -- an all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) that reassembles
+the stabilised sequence.  The reference has no distributed code at all (single tf.Session,
+main:489); samples are independent at inference (BatchNorm uses moving statistics), so there is
+no other exchange step on this path."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition of range(n_items): the first n_items % world ranks get one extra."""
+    if world < 1 or not (0 <= rank < world) or n_items < 0:
+        raise ValueError("bad shard arguments")
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def shard_sizes(n_items: int, world: int) -> List[int]:
+    return [shard_range(n_items, r, world)[1] - shard_range(n_items, r, world)[0] for r in range(world)]
+
+
+def gather_sequence(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """All-gather the per-rank shards (leading dim = this rank's shard_range size) back into the
+    full [n_total, ...] sequence on every rank, in the original order."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = shard_sizes(n_total, world)
+    if local.shape[0] != sizes[rank]:
+        raise ValueError(f"rank {rank}: shard has {local.shape[0]} items, expected {sizes[rank]}")
+    mx = max(sizes) if sizes else 0
+    if mx == 0:
+        return local.new_empty((0,) + tuple(local.shape[1:]))
+    padded = local
+    if local.shape[0] < mx:
+        pad = local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))
+        padded = torch.cat([local, pad])
+    out = local.new_empty((world, mx) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out.view((world * mx,) + tuple(local.shape[1:])), padded.contiguous(), group=group)
+    return torch.cat([out[r, :sizes[r]] for r in range(world)])
+
+
+class FrameGatherer:
+    """Overlapped reassembly for a stream of equally sized per-rank batches: submit() starts an
+    asynchronous all-gather of this step's frames into one of `depth` rotating buffers and
+    returns at once; the collective runs beside the next step's kernels.  result(k) / drain()
+    wait.  Buffers: [world, *shape]; rank r's frames land at index r (block partition)."""
+
+    def __init__(self, shape, world: int, device, dtype=torch.float32, depth: int = 2, group=None):
+        self.world, self.depth, self.group = world, depth, group
+        self.bufs = [torch.empty((world,) + tuple(shape), dtype=dtype, device=device) for _ in range(depth)]
+        self.pending: List[Optional[tuple]] = [None] * depth
+        self.count = 0
+
+    def submit(self, frames: torch.Tensor) -> int:
+        slot = self.count % self.depth
+        self._wait(slot)
+        buf = self.bufs[slot]
+        work = dist.all_gather_into_tensor(buf.view((-1,) + tuple(buf.shape[2:])), frames.contiguous(),
+                                           group=self.group, async_op=True)
+        self.pending[slot] = (work, frames)          # keep `frames` alive until the collective is done
+        self.count += 1
+        return slot
+
+    def _wait(self, slot: int):
+        if self.pending[slot] is not None:
+            self.pending[slot][0].wait()
+            self.pending[slot] = None
+
+    def result(self, slot: int) -> torch.Tensor:
+        self._wait(slot)
+        b = self.bufs[slot]
+        return b.view((-1,) + tuple(b.shape[2:]))
+
+    def drain(self):
+        for s in range(self.depth):
+            self._wait(s)

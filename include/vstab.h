@@ -1,0 +1,156 @@
+/*
+ * vstab.h -- C ABI of libvstab_hip.so: FlowNetS-pyramid optical-flow inference and
+ * bilinear flow warp for MI355X (gfx950), hand-written HIP kernels.
+ *
+ * The reference (posgraph/coupe.optical_flow_based_deep_video_stabilization) is pure
+ * Python on TensorFlow 1.10 + TensorLayer and has no FFI of its own: its boundary for
+ * this path is the pair of Python graph-builder calls
+ *     flownetS_pyramid(feats, batch_size, is_train, reuse, scope)      model.py:786-893
+ *     tf_warp(img, flow, H, W) / get_pixel_value(img, x, y)            main:70-130 / 44-68
+ * ("main" = main_flownetS_pyramid_noprevloss_dataloader.py) plus the glue lines
+ * main:497-498 and main:806 and the checkpoint restore main:520.  Each entry point below
+ * cites the reference lines it replaces; INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - all tensors fp32, NHWC, contiguous, DEVICE pointers unless a parameter says "host";
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream); no hidden host<->device copies, no allocation after vstab_load_weights;
+ *   - the caller owns every I/O buffer and the workspace; the context owns only the
+ *     packed weights;
+ *   - every function returns 0 or a negative VSTAB_E_* code and never throws;
+ *     vstab_last_error() gives the message for the last failure on that context
+ *     (or the last context-less failure when ctx == NULL);
+ *   - one context per device; calls on one context must not overlap in time unless
+ *     they use distinct workspaces and only read the context.
+ */
+#ifndef VSTAB_H
+#define VSTAB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSTAB_OK          0
+#define VSTAB_E_SHAPE    -1   /* bad dimensions / unsupported size                      */
+#define VSTAB_E_ALIGN    -2   /* pointer not 16-byte aligned where required             */
+#define VSTAB_E_HIP      -3   /* a HIP runtime call or kernel launch failed             */
+#define VSTAB_E_NOMEM    -4   /* workspace too small / allocation failed                */
+#define VSTAB_E_WEIGHTS  -5   /* missing or mis-shaped variable in vstab_load_weights   */
+#define VSTAB_E_STATE    -6   /* call order (e.g. forward before load_weights)          */
+
+#if defined(__GNUC__)
+#define VSTAB_API __attribute__((visibility("default")))
+#else
+#define VSTAB_API
+#endif
+
+typedef struct vstab_ctx vstab_ctx;
+
+/* One named variable of the checkpoint, in the reference's own layout:
+ * conv W [kh][kw][Cin][Cout], deconv W [kh][kw][Cout][Cin], vectors [C].
+ * `name` is the short variable name ("1/W_conv2d", "deconv5_bn/beta",
+ * "upsample6_5/W_deconv2d", ... = the tensorlayer key without the
+ * "main_net/flownetS/" prefix and ":0" suffix).  `data` is a HOST pointer. */
+typedef struct vstab_tensor {
+    const char  *name;
+    const float *data;
+    int32_t      ndim;
+    int32_t      shape[4];
+} vstab_tensor;
+
+/* A tensor living in the forward workspace (for tests / debugging). */
+typedef struct vstab_ws_entry {
+    char    name[24];
+    int64_t offset_bytes;
+    int32_t n, h, w, c;      /* logical NHWC shape                           */
+    int32_t c_stride;        /* floats between consecutive pixels (>= c)     */
+} vstab_ws_entry;
+
+/* ---- context ------------------------------------------------------------------- */
+VSTAB_API int  vstab_create(vstab_ctx **out, int device);
+VSTAB_API void vstab_destroy(vstab_ctx *ctx);
+VSTAB_API const char *vstab_last_error(const vstab_ctx *ctx);
+VSTAB_API const char *vstab_version(void);
+
+/* Replaces tl.files.load_and_assign_npz_dict (main:520) + the variable creation inside
+ * flownetS_pyramid: validates every variable of the graph, folds inference BatchNorm
+ * (no gamma, eps 1e-5; model.py:809) into W and b, packs the weights into the MFMA
+ * operand layout and uploads them.  Synchronous.  Input channels = shape[2] of
+ * "1/W_conv2d" (27 in the reference). */
+VSTAB_API int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *tensors, int count);
+
+/* Bytes of workspace vstab_flownets_forward needs for this problem (0 on bad shape). */
+VSTAB_API size_t vstab_workspace_bytes(int B, int H, int W, int Cin);
+
+/* Names/offsets of the intermediate tensors inside the workspace.  Returns the number
+ * of entries written (<= max_entries) or a negative error. */
+VSTAB_API int vstab_workspace_layout(int B, int H, int W, int Cin, vstab_ws_entry *entries, int max_entries);
+
+/* ---- the network: flownetS_pyramid(feats, batch_size, is_train=False) model.py:786-893
+ * feats [B,H,W,Cin] -> predict_flow6..3 at the pyramid levels and predict_flow2
+ * [B,H-2,W-2,2] (the 'flow' key is the same tensor).  The 384x512 literals of the
+ * reference are generalised by SURVEY.md 8a-note-1.  `workspace` must be 256-byte
+ * aligned and at least vstab_workspace_bytes() long. */
+VSTAB_API int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin,
+                           float *pf6, float *pf5, float *pf4, float *pf3, float *pf2,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- measurement support.  With profiling enabled every conv-like launch of
+ * vstab_flownets_forward (15 per forward: encoder stages 1..6_1, deconv5..2, predict2 tap
+ * table; a split-K launch includes its combine kernel) is bracketed by hipEvents recorded on
+ * the forward's stream.  vstab_profile_read must be called after that stream has been
+ * synchronised: it returns, summed over the forwards recorded since the last reset, the
+ * elapsed milliseconds per launch slot, and the ALGORITHMIC flops of one forward per slot
+ * (2*MAC of the layer as SURVEY.md 8d counts it; deconvs at 4 taps/output). */
+VSTAB_API int vstab_profile_enable(vstab_ctx *ctx, int enable);
+VSTAB_API int vstab_profile_reset(vstab_ctx *ctx);
+VSTAB_API int vstab_profile_read(vstab_ctx *ctx, double *ms_sum15, double *flops15, int *n_forwards);
+
+/* ---- glue: main:497-498.  out[B,oh,ow,2] = resize_images(flow * pre, [oh,ow]) with the
+ * x channel then multiplied by sx and the y channel by sy (legacy TF bilinear,
+ * align_corners=False; identity resample when the size already matches). */
+VSTAB_API int vstab_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow,
+                            float pre, float sx, float sy, void *stream);
+
+/* ---- glue: main:806 / model.py:857 UpSampling2dLayer defaults.  Legacy TF bilinear
+ * resize of an NHWC tensor. */
+VSTAB_API int vstab_resize_bilinear(const float *x, int B, int h, int w, int C, float *out, int oh, int ow,
+                          void *stream);
+
+/* ---- tf_warp(img, flow, H, W) main:70-130.  img [B,H,W,C], flow [B,H,W,2] (x, y),
+ * out [B,H,W,C]; truncating corners, clipped indices, weights from the clipped corners. */
+VSTAB_API int vstab_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W, int C,
+                    void *stream);
+
+/* ---- get_pixel_value(img, x, y) main:44-68.  x, y int32 [B,H,W] -> out[b,h,w,:] =
+ * img[b, y, x, :].  Indices are clamped into the image instead of faulting. */
+VSTAB_API int vstab_get_pixel_value(const float *img, const int32_t *x, const int32_t *y, float *out, int B,
+                          int H, int W, int C, int Hi, int Wi, void *stream);
+
+/* ---- host-only helpers (no GPU needed; used by the CPU tests) --------------------- */
+/* Level sizes of the encoder for an HxW input: hw[2*i], hw[2*i+1] = (h, w) of stage i
+ * (10 stages).  Returns 0 or VSTAB_E_SHAPE. */
+VSTAB_API int vstab_level_sizes(int H, int W, int32_t *hw20);
+
+/* Host-side view of one conv-like launch of the forward schedule (layer 0-9 = encoder
+ * stages 1..6_1, 10-13 = deconv5..2, 14 = predict2 tap table): writes 26 + 7*nphase ints
+ *   B Hi Wi Cs_in KH NSEG SEG SEGP SEG_STRIDE s_in s_out Ho Wo Cs_out c_off N Npad act
+ *   nphase ksplit Mmax tile vec4 in_buf out_buf reserved, then per phase
+ *   Hg Wg M off_y off_x o_y o_x
+ * (buffers index vstab_workspace_layout entries, -1 = feats).  Returns ints written. */
+VSTAB_API int vstab_host_layer_plan(int B, int H, int W, int Cin, int layer, int32_t *out, int cap);
+
+/* Host-side weight packing exactly as vstab_load_weights does it for `layer` of a
+ * Cin-channel network: W is the reference-layout tensor, scale (may be NULL = ones) the
+ * folded BatchNorm scale per output channel.  Writes the packed floats ([phase][KT][Npad][32])
+ * to `wpk` (capacity `cap` floats) and returns the number of floats, or a negative error. */
+VSTAB_API long long vstab_host_pack_layer(int Cin, int layer, const float *W, const double *scale,
+                                          float *wpk, long long cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSTAB_H */

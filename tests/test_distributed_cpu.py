@@ -1,0 +1,71 @@
+"""N>1 path on the CPU: world_size-2 (and 3, ragged) gloo processes run the sharding +
+all-gather reassembly of distributed.py and must reproduce the unsharded sequence exactly."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from coupe.optical_flow_based_deep_video_stabilization_amd import distributed as vd
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(n_total * 6, dtype=torch.float32).view(n_total, 2, 3)     # "frames"
+        lo, hi = vd.shard_range(n_total, rank, world)
+        local = full[lo:hi] * 2.0 + 1.0                                               # stand-in per-sample work
+        seq = vd.gather_sequence(local, n_total)
+        ok1 = torch.equal(seq, full * 2.0 + 1.0)
+        # streaming gatherer: 3 steps, depth 2, equal batches
+        g = vd.FrameGatherer((2, 2, 3), world, "cpu")
+        outs = []
+        for step in range(3):
+            slot = g.submit(torch.full((2, 2, 3), float(rank * 10 + step)))
+            outs.append((slot, step))
+            if step >= 1:                                                            # read the previous step's result
+                pslot, pstep = outs[step - 1]
+                r = g.result(pslot).view(world, 2, 2, 3)
+                ok1 = ok1 and all(float(r[k].mean()) == k * 10 + pstep for k in range(world))
+        g.drain()
+        r = g.result(outs[-1][0]).view(world, 2, 2, 3)
+        ok1 = ok1 and all(float(r[k].mean()) == k * 10 + 2 for k in range(world))
+        q.put((rank, bool(ok1)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 8), (2, 5), (3, 7)])
+def test_shard_and_gather_matches_unsharded(world, n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def test_shard_range_partition():
+    for n in (0, 1, 7, 8, 1000):
+        for w in (1, 2, 3, 8):
+            spans = [vd.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert vd.shard_sizes(1000, 8) == [125] * 8
+    with pytest.raises(ValueError):
+        vd.shard_range(4, 2, 2)

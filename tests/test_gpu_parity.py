@@ -1,0 +1,188 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden vectors.  Tolerance for flows: 1e-3 max-abs (BASELINE.json north_star), fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import coupe.optical_flow_based_deep_video_stabilization_amd as vs
+from coupe.optical_flow_based_deep_video_stabilization_amd import netspec, runtime, weights as wts
+from oracle import vstab_oracle as vo
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FLOW_TOL = 1e-3
+
+
+def dev(a):
+    return torch.as_tensor(np.asarray(a)).to("cuda")
+
+
+def maxabs(a, b):
+    return float((a.double().cpu() - torch.as_tensor(np.asarray(b)).double()).abs().max())
+
+
+# ------------------------------------------------------------------------- warp + glue
+def test_warp_golden_bit_exact():
+    z = np.load(os.path.join(GOLD, "warp_37x53.npz"))
+    out = vs.tf_warp(dev(z["img"]), dev(z["flow"]), 37, 53)
+    torch.cuda.synchronize()
+    # same fp32 op sequence as the oracle, contraction disabled -> identical bits
+    assert np.array_equal(out.cpu().numpy(), z["warped"])
+
+
+@pytest.mark.parametrize("B,H,W,C", [(1, 5, 7, 3), (3, 64, 96, 3), (2, 33, 41, 1), (1, 30, 30, 4), (1, 1, 1, 3)])
+def test_warp_random_vs_oracle(B, H, W, C):
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    img = torch.rand(B, H, W, C, generator=g)
+    flow = (torch.rand(B, H, W, 2, generator=g) - 0.5) * 2 * max(H, W)
+    flow[0, 0, 0] = torch.tensor([0.0, 0.0])
+    out = vs.tf_warp(img.cuda(), flow.cuda(), H, W)
+    ref = vo.tf_warp(img, flow, H, W, torch.float32)
+    assert maxabs(out, ref) <= 1e-6
+    # identity flow zeroes the last row and column
+    ident = vs.tf_warp(img.cuda(), torch.zeros(B, H, W, 2, device="cuda"), H, W).cpu()
+    assert torch.equal(ident[:, :H - 1, :W - 1], img[:, :H - 1, :W - 1])
+    assert ident[:, H - 1].abs().sum() == 0 and ident[:, :, W - 1].abs().sum() == 0
+
+
+def test_warp_nonfinite_flow_does_not_fault():
+    img = torch.rand(1, 8, 8, 3).cuda()
+    flow = torch.zeros(1, 8, 8, 2)
+    flow[0, 0, 0] = torch.tensor([float("nan"), float("inf")])
+    flow[0, 1, 1] = torch.tensor([-float("inf"), 3e38])
+    out = vs.tf_warp(img, flow.cuda(), 8, 8)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 8, 8, 3)
+
+
+def test_get_pixel_value():
+    img = torch.rand(2, 9, 11, 3)
+    x = torch.randint(0, 11, (2, 4, 5), dtype=torch.int32)
+    y = torch.randint(0, 9, (2, 4, 5), dtype=torch.int32)
+    out = vs.get_pixel_value(img.cuda(), x.cuda(), y.cuda())
+    assert torch.equal(out.cpu(), vo.get_pixel_value(img, x, y))
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(6, 8, 12, 16), (24, 32, 48, 64), (48, 64, 382, 510), (17, 30, 34, 60), (12, 12, 12, 12), (40, 40, 20, 13)])
+def test_resize_images_vs_oracle(h, w, oh, ow):
+    x = torch.rand(2, h, w, 3)
+    out = vs.resize_images(x.cuda(), (oh, ow))
+    ref = vo.resize_bilinear_legacy(x, oh, ow)
+    assert maxabs(out, ref) <= 1e-6
+
+
+@pytest.mark.parametrize("hn,wn,oh,ow", [(384, 512, 384, 512), (64, 64, 64, 64), (70, 90, 96, 120), (64, 96, 32, 48)])
+def test_flow_glue_vs_oracle(hn, wn, oh, ow):
+    pf2 = torch.randn(2, hn - 2, wn - 2, 2) * 5
+    out = vs.flow_to_output_res(pf2.cuda(), hn, wn, oh, ow)
+    ref = vo.flow_to_output_res(pf2, hn, wn, oh, ow)
+    assert maxabs(out, ref) <= 2e-5
+
+
+# ------------------------------------------------------------------------- network
+def run_net(feats, w):
+    runtime.reset()
+    vs.assign_weights(w)
+    out = vs.flownetS_pyramid(dev(feats), feats.shape[0], is_train=False)
+    torch.cuda.synchronize()
+    return out
+
+
+def check_internals(feats, w, ref_int):
+    B, H, W, Cin = feats.shape
+    ints = runtime.get_context().internals(B, H, W, Cin)
+    names = {"conv1": "conv1", "concat2": "concat2", "conv3": "conv3", "concat3": "concat3", "conv4": "conv4",
+             "concat4": "concat4", "conv5": "conv5", "concat5": "concat5", "conv6": "conv6", "conv6_1": "conv6_1"}
+    report = {}
+    for mine, theirs in names.items():
+        r = ref_int[theirs]
+        err = maxabs(ints[mine], r)
+        report[mine] = (err, float(r.abs().max()))
+    return report
+
+
+@pytest.mark.parametrize("B,H,W,cin,seed", [(2, 64, 64, 27, 3), (1, 88, 104, 27, 4), (1, 70, 90, 6, 5), (3, 48, 64, 28, 6)])
+def test_network_every_layer_vs_oracle(B, H, W, cin, seed):
+    w = wts.synthetic_weights(seed=seed, cin=cin, random_bn=True, flow_gain=2.0)
+    feats = np.random.default_rng(seed).random((B, H, W, cin), dtype=np.float32)
+    ref, ref_int = vo.flownetS_pyramid(feats, w, torch.float64, return_internals=True)
+    out = run_net(feats, w)
+    report = check_internals(feats, w, ref_int)
+    bad = {k: v for k, v in report.items() if v[0] > 2e-4 * max(1.0, v[1])}
+    assert not bad, f"layer errors (max-abs err, max-abs ref): {report}"
+    errs = {k: maxabs(out[k], ref[k]) for k in vo.FLOW_KEYS}
+    assert all(e <= FLOW_TOL for e in errs.values()), errs
+    assert out["flow"] is out["predict_flow2"]
+    assert float(ref["predict_flow2"].abs().max()) > 0.5
+
+
+@pytest.mark.parametrize("name", ["net_48x64_c27", "net_70x90_c6"])
+def test_network_golden_end_to_end(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    B, H, W, Cin, oh, ow, seed, rbn = [int(v) for v in z["meta"]]
+    w = wts.synthetic_weights(seed=seed, cin=Cin, random_bn=bool(rbn), flow_gain=float(z["flow_gain"]))
+    runtime.reset()
+    vs.assign_weights(w)
+    flows, outflow, warped = vs.stabilise_originalsize(dev(z["feats"]), dev(z["frame"]))
+    torch.cuda.synchronize()
+    for k in vo.FLOW_KEYS:
+        assert maxabs(flows[k], z[k]) <= FLOW_TOL, k
+    assert maxabs(outflow, z["outflow"]) <= FLOW_TOL
+    # warped frame: compare away from tf_warp's discontinuity lines
+    ok = vo.warp_discontinuity_mask(torch.from_numpy(z["outflow"]), oh, ow, delta=5e-3)
+    diff = (warped.cpu() - torch.from_numpy(z["warped"])).abs().amax(dim=3)
+    assert float(diff[ok].max()) <= 2e-3
+    assert ok.float().mean() > 0.9
+
+
+def test_cfg0_256x256_single_pair_vs_fp64_oracle():
+    # BASELINE.json configs[0]: one 256x256 synthetic sample through network + glue + warp
+    w = wts.synthetic_weights(seed=1, cin=27, random_bn=False)
+    g = np.random.default_rng(0)
+    feats = g.random((1, 256, 256, 27), dtype=np.float32)
+    ref = vo.flownetS_pyramid(feats, w, torch.float64)
+    out = run_net(feats, w)
+    errs = {k: maxabs(out[k], ref[k]) for k in vo.FLOW_KEYS}
+    assert all(e <= FLOW_TOL for e in errs.values()), errs
+
+
+def test_native_path_matches_oracle():
+    w = wts.synthetic_weights(seed=9, cin=27, random_bn=True, flow_gain=2.0)
+    feats = np.random.default_rng(9).random((1, 64, 80, 27), dtype=np.float32)
+    runtime.reset()
+    vs.assign_weights(w)
+    flows, warped = vs.stabilise_native(dev(feats))
+    rflows, rwarped = vo.stabilise_native(feats, w, torch.float64)
+    assert maxabs(flows["predict_flow2"], rflows["predict_flow2"]) <= FLOW_TOL
+    ok = vo.warp_discontinuity_mask(rflows["predict_flow2"].float(), 62, 78, delta=5e-3)
+    diff = (warped.cpu().double() - rwarped).abs().amax(dim=3)
+    assert float(diff[ok].max()) <= 2e-3
+
+
+def test_batch_independence_and_determinism():
+    # samples are independent (no cross-sample op at inference): sharding by sample is exact
+    w = wts.synthetic_weights(seed=2, cin=27, random_bn=True)
+    feats = np.random.default_rng(2).random((4, 64, 64, 27), dtype=np.float32)
+    runtime.reset()
+    vs.assign_weights(w)
+    full = vs.flownetS_pyramid(dev(feats), 4)["predict_flow2"].clone()
+    again = vs.flownetS_pyramid(dev(feats), 4)["predict_flow2"].clone()
+    assert torch.equal(full, again)
+    halves = torch.cat([vs.flownetS_pyramid(dev(feats[:2]), 2)["predict_flow2"].clone(),
+                        vs.flownetS_pyramid(dev(feats[2:]), 2)["predict_flow2"].clone()])
+    assert maxabs(full, halves.cpu()) <= 1e-5      # split-K factors may differ with batch -> not bitwise
+
+
+def test_errors_through_the_abi():
+    runtime.reset()
+    with pytest.raises(RuntimeError, match="weights"):
+        vs.flownetS_pyramid(torch.zeros(1, 64, 64, 27, device="cuda"), 1)
+    vs.initialize_global_variables(seed=1, cin=27)
+    with pytest.raises(ValueError):
+        vs.flownetS_pyramid(torch.zeros(1, 64, 64, 6, device="cuda"), 1)      # channel mismatch
+    with pytest.raises(ValueError):
+        vs.flownetS_pyramid(torch.zeros(1, 2, 2, 27, device="cuda"), 1)       # too small
+    with pytest.raises(ValueError):
+        vs.tf_warp(torch.zeros(1, 4, 4, 3, device="cuda"), torch.zeros(1, 4, 5, 2, device="cuda"), 4, 4)
