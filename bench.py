@@ -32,15 +32,30 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_cpu_share():
+    """Cores this process may really use: cgroup quota if one is set, else the affinity mask,
+    capped at 16 (a 1-GPU box's CPU share; more threads than that only oversubscribe)."""
+    if os.environ.get("VSTAB_CPU_THREADS"):
+        return max(1, int(os.environ["VSTAB_CPU_THREADS"]))
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(batch, H, W, Cin, weights, seconds_budget=20.0):
     """The CPU restatement (oracle, torch fp32 on all host cores) timed on a bounded sample
     of the same workload.  kind = "port": TensorFlow 1.10 cannot exist on this box."""
     from oracle import vstab_oracle as vo
-    threads = os.cpu_count() or 1
-    try:
-        threads = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    threads = host_cpu_share()
     torch.set_num_threads(threads)
     rng = np.random.default_rng(0)
     nb = min(batch, 2)

@@ -296,7 +296,11 @@ __global__ __launch_bounds__(256) void warp_flow_kernel(const float *__restrict_
     const int yy = rem / W, xx = rem - yy * W;
     const f32x2 f = reinterpret_cast<const f32x2 *>(flow)[idx];
     const float x = (float)xx + f.x, y = (float)yy + f.y;
-    int x0 = (int)x, y0 = (int)y;
+    // Clamp BEFORE the conversion: float->int of an out-of-range value and x0 + 1 at INT_MAX are
+    // undefined in C++ (the optimiser folds the clips below around them and a NaN/inf flow then
+    // indexes out of bounds).  Inside [-2, W] nothing changes; outside, both corners still end
+    // up clipped to the same border pixel exactly as in the reference.
+    int x0 = (int)fminf(fmaxf(x, -2.f), (float)W), y0 = (int)fminf(fmaxf(y, -2.f), (float)H);
     int x1 = x0 + 1, y1 = y0 + 1;
     x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
     y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
