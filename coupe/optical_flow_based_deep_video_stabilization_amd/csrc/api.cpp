@@ -519,8 +519,8 @@ extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B,
             ctx->prof_flops[i] = 2.0 * mac;
         }
     }
-#define EV_START(slot) do { if (ev) HIP_TRY(ctx, hipEventRecord(ev[2 * (slot)], stream)); } while (0)
-#define EV_STOP(slot) do { if (ev) HIP_TRY(ctx, hipEventRecord(ev[2 * (slot) + 1], stream)); } while (0)
+#define EV_A(slot) (ev ? ev[2 * (slot)] : nullptr)
+#define EV_B(slot) (ev ? ev[2 * (slot) + 1] : nullptr)
 
     // encoder (model.py:807-844)
     for (int i = 0; i < 10; ++i) {
@@ -530,9 +530,7 @@ extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B,
         p.wpk = dw + ctx->enc_w[i];
         p.bias = dw + ctx->enc_b[i];
         p.partial = buf(B_PARTIAL);
-        EV_START(i);
-        HIP_TRY(ctx, launch_conv(p, pl.tile[i], pl.vec4[i], stream));
-        EV_STOP(i);
+        HIP_TRY(ctx, launch_conv(p, pl.tile[i], pl.vec4[i], stream, EV_A(i), EV_B(i)));
     }
     // decoder (model.py:847-880)
     float *pfs[5] = {pf6, pf5, pf4, pf3, pf2};
@@ -548,9 +546,7 @@ extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B,
         p.wpk = dw + ctx->dec_w[l];
         p.bias = dw + ctx->dec_b[l];
         p.partial = buf(B_PARTIAL);
-        EV_START(10 + l);
-        HIP_TRY(ctx, launch_conv(p, pl.tile[10 + l], true, stream));
-        EV_STOP(10 + l);
+        HIP_TRY(ctx, launch_conv(p, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l)));
         const int ph = pl.eh[lvl_enc[l]], pw = pl.ew[lvl_enc[l]];          // coarser level
         const int h = pl.eh[lvl_enc[l + 1]], w = pl.ew[lvl_enc[l + 1]];    // this level
         HIP_TRY(ctx, launch_upflow(pfs[l], B, ph, pw, ctx->up[l], buf(cat_buf[l]), h, w, CONCAT_CS[l], CONCAT_C[l] - 2, stream));
@@ -563,13 +559,11 @@ extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B,
         ConvParams p = pl.cp[14];
         p.in = buf(B_CONCAT2); p.out = buf(B_T);
         p.wpk = dw + ctx->tab_w; p.bias = dw + ctx->tab_b; p.partial = nullptr;
-        EV_START(14);
-        HIP_TRY(ctx, launch_conv(p, pl.tile[14], true, stream));
-        EV_STOP(14);
+        HIP_TRY(ctx, launch_conv(p, pl.tile[14], true, stream, EV_A(14), EV_B(14)));
         HIP_TRY(ctx, launch_pf2(buf(B_T), B, pl.eh[1], pl.ew[1], dw + ctx->pred2_b, pf3, pl.eh[3], pl.ew[3], pf2, H, W, stream));
     }
-#undef EV_START
-#undef EV_STOP
+#undef EV_A
+#undef EV_B
     if (ev) ctx->prof_forwards++;
     return VSTAB_OK;
 }

@@ -300,7 +300,7 @@ hipError_t conv_set_attributes()
     return hipSuccess;
 }
 
-hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream)
+hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const int BM = 128;
     const int BN = tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32);
@@ -310,6 +310,7 @@ hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_
     if (p.ksplit > 1 && ((p.N & 3) || (p.Cs_out & 3) || (p.c_off & 3) || p.partial == nullptr))
         return hipErrorInvalidValue;
     dim3 grid((p.Mmax + BM - 1) / BM, p.Npad / BN, p.nphase * p.ksplit), block(256);
+    if (ev_start) (void)hipEventRecord(ev_start, stream);
     if (tile == TILE_128x128 && vec4)
         conv_mfma_kernel<128, 128, 2, 2, true><<<grid, block, conv_lds_bytes<128, 128>(), stream>>>(p);
     else if (tile == TILE_128x64 && vec4)
@@ -321,6 +322,7 @@ hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_
     else
         return hipErrorInvalidValue;
     hipError_t e = hipGetLastError();
+    if (ev_stop) (void)hipEventRecord(ev_stop, stream);   // brackets the GEMM kernel only, not the combine
     if (e != hipSuccess) return e;
     if (p.ksplit > 1) {
         const long long total = (long long)p.Mmax * (p.N >> 2) * p.nphase;

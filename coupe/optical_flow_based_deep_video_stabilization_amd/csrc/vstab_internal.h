@@ -51,7 +51,9 @@ struct ConvParams {
 enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2 };
 
 // Launch the implicit-GEMM kernel (and the split-K combine when p.ksplit > 1).
-hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream);
+// ev_start/ev_stop (optional) are recorded immediately around the GEMM kernel itself.
+hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream,
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t conv_set_attributes();   // raises the dynamic-LDS limit once per process
 
 // ---------------------------------------------------------------------------------

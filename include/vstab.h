@@ -100,8 +100,8 @@ VSTAB_API int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B, 
 
 /* ---- measurement support.  With profiling enabled every conv-like launch of
  * vstab_flownets_forward (15 per forward: encoder stages 1..6_1, deconv5..2, predict2 tap
- * table; a split-K launch includes its combine kernel) is bracketed by hipEvents recorded on
- * the forward's stream.  vstab_profile_read must be called after that stream has been
+ * table; the GEMM kernel itself, not the split-K combine that may follow it) is bracketed by
+ * hipEvents recorded on the forward's stream.  vstab_profile_read must be called after that stream has been
  * synchronised: it returns, summed over the forwards recorded since the last reset, the
  * elapsed milliseconds per launch slot, and the ALGORITHMIC flops of one forward per slot
  * (2*MAC of the layer as SURVEY.md 8d counts it; deconvs at 4 taps/output). */
