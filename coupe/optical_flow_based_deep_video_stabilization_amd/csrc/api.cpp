@@ -24,6 +24,7 @@ struct vstab_ctx {
     size_t dev_weight_floats = 0;
     // float offsets into dev_weights
     size_t enc_w[10], enc_b[10];
+    size_t enc0_rw = 0;                  // layer-1 weights in the row-window layout (conv_rowwin.hip)
     size_t dec_w[4], dec_b[4];
     size_t pred_w[4], pred_b[4];         // predict6,5,4,3
     size_t tab_w, tab_b, pred2_b;        // predict2 tap table (bias of the table = 0)
@@ -281,6 +282,7 @@ extern "C" int vstab_create(vstab_ctx **out, int device)
     if (device < 0 || device >= n) return fail(nullptr, VSTAB_E_HIP, "vstab_create: device %d of %d", device, n);
     HIP_TRY(nullptr, hipSetDevice(device));
     HIP_TRY(nullptr, conv_set_attributes());
+    HIP_TRY(nullptr, rowwin_set_attributes());
     vstab_ctx *c = new (std::nothrow) vstab_ctx();
     if (!c) return fail(nullptr, VSTAB_E_NOMEM, "vstab_create: out of host memory");
     c->device = device;
@@ -422,6 +424,11 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
         fold_bn(b->data, beta->data, mean->data, var->data, e.cout, npad, scale.data(), host.data() + ctx->enc_b[i]);
         ctx->enc_w[i] = reserve((size_t)L.ktiles() * npad * 32);
         pack_conv(W->data, scale.data(), e.k, e.k, ci, cs_in, e.cout, npad, L, host.data() + ctx->enc_w[i]);
+        if (i == 0) {
+            const int lead = rowwin_lead(-e.p, cin), segp = rowwin_segp(-e.p, e.k, cin);
+            ctx->enc0_rw = reserve((size_t)e.k * (segp / 32) * npad * 32);
+            pack_conv_rowwin(W->data, scale.data(), e.k, e.k, cin, e.cout, npad, lead, segp, host.data() + ctx->enc0_rw);
+        }
     }
     // decoder
     for (int l = 0; l < 4; ++l) {
@@ -525,6 +532,23 @@ extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B,
     // encoder (model.py:807-844)
     for (int i = 0; i < 10; ++i) {
         ConvParams p = pl.cp[i];
+        if (i == 0) {           // first layer: row-window kernel when its alignment conditions hold
+            RowWinParams r{};
+            r.in = feats; r.out = buf(B_CONV1); r.wpk = dw + ctx->enc0_rw; r.bias = dw + ctx->enc_b[0];
+            const long long in_bytes = (long long)B * H * W * Cin * 4;
+            r.in_bytes = (unsigned)std::min<long long>(in_bytes, 0xFFFFFFFFLL);
+            r.B = B; r.Hi = H; r.Wi = W; r.Cs_in = Cin; r.KH = ENC[0].k;
+            r.SEGP = rowwin_segp(-ENC[0].p, ENC[0].k, Cin);
+            r.s_in = ENC[0].s; r.off_y = -ENC[0].p;
+            r.e_off = -ENC[0].p * Cin - rowwin_lead(-ENC[0].p, Cin);
+            r.w_a = ((r.e_off % 4) + 4) % 4;
+            r.WLEN = round_up(r.s_in * Cin * 127 + r.w_a + r.SEGP, 4);
+            r.Ho = p.Ho; r.Wo = p.Wo; r.Cs_out = p.Cs_out; r.c_off = 0; r.N = p.N; r.Npad = p.Npad; r.act = 1;
+            if (in_bytes < 0x80000000LL && rowwin_applicable(r)) {
+                HIP_TRY(ctx, launch_conv_rowwin(r, stream, EV_A(0), EV_B(0)));
+                continue;
+            }
+        }
         p.in = ENC_IO[i].in_buf < 0 ? feats : buf(ENC_IO[i].in_buf);
         p.out = buf(ENC_IO[i].out_buf);
         p.wpk = dw + ctx->enc_w[i];

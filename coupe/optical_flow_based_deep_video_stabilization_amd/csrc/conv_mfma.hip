@@ -26,6 +26,8 @@
 //   * K order inside a tile is permuted so that ONE ds_read_b128 feeds four MFMA k-steps:
 //     lane (i, h) holds k = 8q + 4h + j for step (q, j) -- A and B use the same map;
 //   * split-K (grid.z) with fp32 slabs + a combine kernel for the small late layers.
+#include <cstdlib>
+
 #include "vstab_internal.h"
 
 namespace vstab {
@@ -206,10 +208,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
         int buf = 0;
         for (int kt = kt0; kt < kt1; ++kt) {
             const bool more = (kt + 1 < kt1);
+#ifndef VSTAB_ABL          // tuning-harness ablations (tools/conv_bench); never defined in the product build
             if (more) load_tile(kt + 1);
             compute(buf);
             if (more) store_tile(buf ^ 1);
             __syncthreads();
+#else
+            if (more && !(VSTAB_ABL & 1)) load_tile(kt + 1);
+            if (!(VSTAB_ABL & 8)) compute(buf);
+            if (more && !(VSTAB_ABL & 2)) store_tile(buf ^ 1);
+            if (!(VSTAB_ABL & 4)) __syncthreads();
+#endif
             buf ^= 1;
         }
     }
@@ -283,7 +292,14 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const ConvParams p)
 }
 
 template <int BM, int BN>
-static constexpr size_t conv_lds_bytes() { return (size_t)(2 * BM * 32 + 2 * BN * 32) * 4 + (size_t)BM * 20; }
+static size_t conv_lds_bytes()
+{
+    size_t n = (size_t)(2 * BM * 32 + 2 * BN * 32) * 4 + (size_t)BM * 20;
+#ifdef VSTAB_ABL
+    if (const char *e = getenv("VSTAB_LDS_PAD")) n += (size_t)atoi(e);     // occupancy experiments
+#endif
+    return n;
+}
 
 hipError_t conv_set_attributes()
 {

@@ -1,0 +1,193 @@
+// "Row-window" implicit-GEMM convolution for the network's first layer (model.py:807-809:
+// PadLayer(3) + Conv2d 7x7 s2 VALID + BatchNorm + lrelu on the 27-channel frame stack).
+//
+// Why a second conv kernel: with C_in = 27 a pixel is 108 bytes, so the generic kernel has to
+// gather its im2col tile with predicated dword loads (16 per thread per 32-wide K-tile) and
+// runs at ~50 % of the fp32 MFMA rate.  But in NHWC the K run of one output pixel and one
+// filter row -- KW*C_in = 189 consecutive floats -- is contiguous, and neighbouring output
+// pixels start s*C_in = 54 floats apart.  So for 128 consecutive output pixels of one output
+// row, ALL operands of one filter row live in ONE contiguous window of 54*127+192 floats of
+// the input row.  The workgroup copies that window to LDS with aligned 16-byte loads (7 per
+// thread per filter row instead of 96 dword gathers) and the MFMA A operands are read
+// straight out of it (lane i reads at 54*i + k): the im2col matrix is never materialised,
+// not even in LDS.
+//   * A reads are ds_read_b64 (two k-steps each); the run is extended by one leading dummy
+//     float (zero weight) so that 54*i + k is 8-byte aligned; 32 lanes hit 32 distinct even
+//     banks -> conflict free.
+//   * B (weights, 64 x 1344, packed per K-tile) is read by every wave straight from
+//     global/L1 into registers (4 x 16 B per lane per K-tile, prefetched one tile ahead):
+//     no LDS staging, hence no barrier per K-tile -- only one per filter row (7 per block).
+//   * window double-buffered: the loads of filter row ky+1 are in flight during the 192
+//     MFMAs of row ky.
+// Zero padding: window floats left of / right of the image row and whole rows above/below
+// the image are loaded as zeros via the buffer descriptor's range check (no branches).
+// Requires (s*C_in) even, (W*C_in) % 4 == 0, 16-byte aligned input; otherwise the generic
+// scalar-gather kernel runs instead.
+#include "vstab_internal.h"
+
+namespace vstab {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NWIN4>   // float4 loads per thread per window
+__global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *win = reinterpret_cast<float *>(smem);           // [2][WLEN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                // 2x2 waves, wave tile 64 (pixels) x 32 (channels)
+    const int li = lane & 31, lh = lane >> 5;
+    const int ox0 = blockIdx.x * 128, oy = blockIdx.y, n = blockIdx.z;
+    const int pix_step = p.s_in * p.Cs_in;
+    const int row_floats = p.Wi * p.Cs_in;
+    const int g0 = pix_step * ox0 + p.e_off - p.w_a;       // window start, floats from the row start (multiple of 4)
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, p.in_bytes, 0x00020000);
+    const unsigned OOB = 0xC0000000u;
+
+    f32x4 wv[NWIN4];
+    auto load_window = [&](int ky) {
+        const int iy = oy * p.s_in + p.off_y + ky;
+        const bool yok = (unsigned)iy < (unsigned)p.Hi;
+        const int rowbase = ((n * p.Hi + iy) * p.Wi) * p.Cs_in;      // element offset (< 2^29, checked on the host)
+#pragma unroll
+        for (int j = 0; j < NWIN4; ++j) {
+            const int c4 = tid + 256 * j;
+            const int g = g0 + 4 * c4;
+            const bool ok = yok && g >= 0 && g < row_floats && 4 * c4 < p.WLEN;
+            const unsigned off = ok ? (unsigned)(rowbase + g) * 4u : OOB;
+            wv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
+        }
+    };
+    auto store_window = [&](int buf) {
+        float *d = win + buf * p.WLEN;
+#pragma unroll
+        for (int j = 0; j < NWIN4; ++j) {
+            const int c4 = tid + 256 * j;
+            if (4 * c4 < p.WLEN) *reinterpret_cast<f32x4 *>(d + 4 * c4) = wv[j];
+        }
+    };
+
+    // B fragments: packed [kt][Npad][32]; lane (i,h) of n-block wn owns floats (2q+h)*4 .. +3 of row wn*32+i
+    const float *bbase = p.wpk + (long long)(wn * 32 + li) * 32 + lh * 4;
+    const int ktile_stride = p.Npad * 32;
+    f32x4 b0[4], b1[4];
+    const int KT = p.KH * (p.SEGP >> 5);
+    auto load_b = [&](f32x4 (&dst)[4], int kt) {
+        const float *s = bbase + (long long)(kt < KT ? kt : KT - 1) * ktile_stride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const f32x4 *>(s + q * 8);
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    const int kpr = p.SEGP >> 5;                       // K-tiles per filter row
+    // A operand address inside the window: pix_step*m + w_a + 32*kc + 4*r + 2*h
+    const int a_off0 = pix_step * (wm * 64 + li) + p.w_a + 2 * lh;
+    const int a_off1 = a_off0 + pix_step * 32;
+
+    // one K-tile: 16 ds_read_b64 + 32 MFMAs; the B fragments are already in registers
+    auto compute = [&](const float *w, int kc, const f32x4 (&b)[4]) {
+        const float *wa0 = w + a_off0 + 32 * kc, *wa1 = w + a_off1 + 32 * kc;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const f32x2 a0 = *reinterpret_cast<const f32x2 *>(wa0 + 4 * r);
+            const f32x2 a1 = *reinterpret_cast<const f32x2 *>(wa1 + 4 * r);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int s = 2 * r + j;
+                const float bv = b[s >> 2][s & 3];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bv, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bv, acc[1], 0, 0, 0);
+            }
+        }
+    };
+
+    load_window(0);
+    store_window(0);
+    load_b(b0, 0);
+    __syncthreads();
+    int buf = 0, kt = 0;
+    for (int ky = 0; ky < p.KH; ++ky) {
+        const bool more = ky + 1 < p.KH;
+        if (more) load_window(ky + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float *w = win + buf * p.WLEN;
+        int kc = 0;
+        // two K-tiles per trip with two named fragment sets: the loads of tile t+1 are issued before
+        // the MFMAs of tile t and first used 32 MFMAs later (no register copies, no early wait)
+        // (sched_barrier pins the loads here: hipcc otherwise sinks them to their first use and
+        // waits for the L2 round trip four times per K-tile)
+        for (; kc + 1 < kpr; kc += 2, kt += 2) {
+            load_b(b1, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(w, kc, b0);
+            load_b(b0, kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(w, kc + 1, b1);
+        }
+        if (kc < kpr) {                                  // odd number of K-tiles per filter row
+            load_b(b1, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(w, kc, b0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b0[q] = b1[q];
+            ++kt;
+        }
+        if (more) {
+            store_window(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // epilogue: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = wn * 32 + li;
+    if (col < p.N) {
+        const float bv = p.bias[col];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ox < p.Wo) {
+                    float v = acc[mb][r] + bv;
+                    if (p.act) v = fmaxf(v, 0.1f * v);
+                    p.out[((long long)(n * p.Ho + oy) * p.Wo + ox) * p.Cs_out + p.c_off + col] = v;
+                }
+            }
+    }
+}
+
+bool rowwin_applicable(const RowWinParams &p)
+{
+    const int pix_step = p.s_in * p.Cs_in;
+    return (pix_step % 2 == 0) && ((p.Wi * p.Cs_in) % 4 == 0) && (((uintptr_t)p.in & 15) == 0) && p.N <= 64 &&
+           p.Npad == 64 && p.WLEN <= 7 * 1024 && (p.WLEN % 4) == 0 && p.in_bytes < 0x80000000u;
+}
+
+hipError_t rowwin_set_attributes()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rowwin_kernel<7>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * 1024 * 4);
+}
+
+hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    if (!rowwin_applicable(p)) return hipErrorInvalidValue;
+    dim3 grid((p.Wo + 127) / 128, p.Ho, p.B), block(256);
+    if (ev_start) (void)hipEventRecord(ev_start, stream);
+    conv_rowwin_kernel<7><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(p);
+    hipError_t e = hipGetLastError();
+    if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+    return e;
+}
+
+}  // namespace vstab

@@ -70,6 +70,30 @@ void pack_conv(const float *W, const double *scale, int kh, int kw, int cin, int
                  wpk);
 }
 
+// rowwin layout: physical position of logical k (0..31) inside a 32-float row so that lane half h's
+// float4 number q, element e feeds MFMA step 4q+e with k = 8q + 4(e>>1) + 2h + (e&1)  (conv_rowwin.hip)
+static inline int perm_rowwin(int k)
+{
+    const int q = k >> 3, rem = k & 7, h = (rem >> 1) & 1, e = ((rem >> 2) << 1) | (rem & 1);
+    return (2 * q + h) * 4 + e;
+}
+
+void pack_conv_rowwin(const float *W, const double *scale, int kh, int kw, int cin, int cout, int npad, int lead,
+                      int segp, float *wpk)
+{
+    const int kpr = segp / 32;
+    std::memset(wpk, 0, sizeof(float) * (size_t)kh * kpr * npad * 32);
+    for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < kw; ++kx)
+            for (int ci = 0; ci < cin; ++ci) {
+                const int k = lead + kx * cin + ci;
+                float *row = wpk + ((size_t)ky * kpr + k / 32) * npad * 32;
+                for (int n = 0; n < cout; ++n)
+                    row[(size_t)n * 32 + perm_rowwin(k & 31)] =
+                        (float)((double)W[(((size_t)ky * kw + kx) * cin + ci) * cout + n] * scale[n]);
+            }
+}
+
 void pack_deconv(const float *W, const double *scale, int cin, int cs_in, int cout, int npad, float *wpk)
 {
     const KLayout L = klayout_deconv(cs_in);

@@ -6,6 +6,8 @@
 
 namespace vstab {
 
+inline int round_up_c(int a, int b) { return (a + b - 1) / b * b; }
+
 // ---------------------------------------------------------------------------------
 // Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
 //
@@ -55,6 +57,36 @@ enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2 };
 hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t conv_set_attributes();   // raises the dynamic-LDS limit once per process
+
+// ---------------------------------------------------------------------------------
+// Row-window convolution (conv_rowwin.hip): first layer, one output-row segment of 128
+// pixels per workgroup, operands read from a contiguous LDS copy of the input row window.
+// ---------------------------------------------------------------------------------
+struct RowWinParams {
+    const float *in;
+    const float *wpk;       // packed [KH*SEGP/32][Npad][32], rowwin k-permutation, no swizzle
+    const float *bias;
+    float *out;
+    unsigned in_bytes;      // size of the input tensor (buffer descriptor range)
+    int B, Hi, Wi, Cs_in;
+    int KH, SEGP;           // filter rows; extended run (lead dummies + KW*Cs) padded to 32
+    int s_in, off_y;
+    int e_off;              // extended run start = ox*s_in*Cs + e_off (floats from the row start), even
+    int w_a;                // window lead (0 or 2): window start = s_in*Cs*ox0 + e_off - w_a, multiple of 4
+    int WLEN;               // window length in floats (multiple of 4)
+    int Ho, Wo, Cs_out, c_off;
+    int N, Npad, act;
+};
+bool rowwin_applicable(const RowWinParams &p);
+hipError_t rowwin_set_attributes();
+hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                              hipEvent_t ev_stop = nullptr);
+// lead dummy floats d (0/1) making off_x*Cs - d even, and the padded extended run length
+inline int rowwin_lead(int off_x, int cs) { return ((off_x * cs) % 2 != 0) ? 1 : 0; }
+inline int rowwin_segp(int off_x, int kw, int cs) { return round_up_c(rowwin_lead(off_x, cs) + kw * cs, 32); }
+// Conv weights W[kh][kw][Cin][Cout] -> rowwin packed layout
+void pack_conv_rowwin(const float *W, const double *scale, int kh, int kw, int cin, int cout, int npad,
+                      int lead, int segp, float *wpk);
 
 // ---------------------------------------------------------------------------------
 // Small VALU kernels of the flow pyramid and the warp.

@@ -1,0 +1,11 @@
+#!/bin/bash
+# builds tools/conv_bench (tuning harness) next to the library objects
+set -e
+cd "$(dirname "$0")/.."
+P=coupe/optical_flow_based_deep_video_stabilization_amd
+python $P/build.py >/dev/null
+for abl in 0 1 2 3 7 8; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DVSTAB_ABL=$abl tools/conv_bench.hip $P/csrc/conv_mfma.hip $P/csrc/pack.cpp $P/csrc/api.cpp $P/csrc/flow_ops.hip -o tools/conv_bench_abl$abl 2>/dev/null &
+done
+wait
+echo built tools/conv_bench_abl*
