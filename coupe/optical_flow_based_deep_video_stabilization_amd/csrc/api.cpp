@@ -144,13 +144,22 @@ void set_layout(ConvParams &p, const KLayout &L)
     p.KH = L.KH; p.NSEG = L.NSEG; p.SEG = L.SEG; p.SEGP = L.SEGP; p.SEG_STRIDE = L.SEG_STRIDE;
 }
 
+// buffer-descriptor ranges (bytes); called once Npad and the layout are final
+void set_ranges(ConvParams &p)
+{
+    p.in_bytes = (unsigned)std::min<long long>((long long)p.B * p.Hi * p.Wi * p.Cs_in * 4, 0xFFFFFFFFLL);
+    p.w_bytes = (unsigned)std::min<long long>((long long)p.KH * p.NSEG * (p.SEGP / 32) * p.Npad * 128, 0xFFFFFFFFLL);
+}
+
 bool make_plan(int B, int H, int W, int Cin, Plan &pl)
 {
     if (B < 1 || Cin < 1 || Cin > 4096) return false;
     pl.B = B; pl.H = H; pl.W = W; pl.Cin = Cin;
     if (!level_sizes(H, W, pl.eh, pl.ew)) return false;
-    // every tensor must stay below 2^31 elements (int32 element offsets in the kernels)
-    const long long lim = (1LL << 31) - 1;
+    // every tensor must stay below 2^31 BYTES: the kernels address through buffer descriptors with
+    // 32-bit byte offsets and use 0xC0000000 as the "reads as zero" offset (larger batches are
+    // processed in chunks by vstab_flownets_forward)
+    const long long lim = (1LL << 29) - 1;
     if ((long long)B * H * W * Cin > lim) return false;
 
     auto setbuf = [&](int b, int h, int w, int c, int cs) { pl.buf_h[b] = h; pl.buf_w[b] = w; pl.buf_c[b] = c; pl.buf_cs[b] = cs; };
@@ -193,6 +202,7 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         p.ph[0].off_y = -e.p; p.ph[0].off_x = -e.p; p.ph[0].o_y = 0; p.ph[0].o_x = 0; p.ph[0].w_off = 0;
         p.Mmax = p.ph[0].M;
         pl.vec4[i] = (p.Cs_in % 4 == 0) && (p.SEG % 4 == 0);
+        set_ranges(p);
         choose_split(p, BN);
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
     }
@@ -225,6 +235,7 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
                 p.Mmax = std::max(p.Mmax, ph.M);
             }
         pl.vec4[10 + l] = true;
+        set_ranges(p);
         choose_split(p, BN);
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad);
     }
@@ -239,6 +250,7 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         p.N = 32; p.Npad = 32; p.act = 0; p.nphase = 1; p.ksplit = 1;
         p.ph[0].Hg = p.Hi; p.ph[0].Wg = p.Wi; p.ph[0].M = B * p.Hi * p.Wi; p.Mmax = p.ph[0].M;
         pl.tile[14] = TILE_128x32; pl.vec4[14] = true;
+        set_ranges(p);
     }
     pl.bytes[B_PARTIAL] = partial_floats * 4;
     size_t off = 0;
@@ -306,17 +318,23 @@ extern "C" int vstab_level_sizes(int H, int W, int32_t *hw20)
     return VSTAB_OK;
 }
 
+static int max_chunk(int B, int H, int W, int Cin);
+
 extern "C" size_t vstab_workspace_bytes(int B, int H, int W, int Cin)
 {
     Plan pl;
-    if (!make_plan(B, H, W, Cin, pl)) { fail(nullptr, VSTAB_E_SHAPE, "unsupported problem %dx%dx%dx%d", B, H, W, Cin); return 0; }
+    const int chunk = B >= 1 ? max_chunk(B, H, W, Cin) : 0;
+    if (chunk < 1 || !make_plan(chunk, H, W, Cin, pl)) { fail(nullptr, VSTAB_E_SHAPE, "unsupported problem %dx%dx%dx%d", B, H, W, Cin); return 0; }
     return pl.total;
 }
 
 extern "C" int vstab_workspace_layout(int B, int H, int W, int Cin, vstab_ws_entry *entries, int max_entries)
 {
     Plan pl;
-    if (!entries || !make_plan(B, H, W, Cin, pl)) return fail(nullptr, VSTAB_E_SHAPE, "unsupported problem %dx%dx%dx%d", B, H, W, Cin);
+    const int chunk = B >= 1 ? max_chunk(B, H, W, Cin) : 0;     // the workspace holds one chunk of the batch
+    if (!entries || chunk < 1 || !make_plan(chunk, H, W, Cin, pl))
+        return fail(nullptr, VSTAB_E_SHAPE, "unsupported problem %dx%dx%dx%d", B, H, W, Cin);
+    B = chunk;
     int n = 0;
     for (int b = 0; b < N_BUF && n < max_entries; ++b) {
         vstab_ws_entry &e = entries[n++];
@@ -487,6 +505,22 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
 }
 
 // ------------------------------------------------------------------------- forward
+// Largest batch whose every tensor stays below 2 GiB (0 if even one sample does not fit).
+static int max_chunk(int B, int H, int W, int Cin)
+{
+    Plan pl;
+    int lo = 0, hi = B;                     // invariant: lo fits (or 0), hi+1.. do not
+    if (make_plan(B, H, W, Cin, pl)) return B;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (make_plan(mid, H, W, Cin, pl)) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5,
+                         float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_);
+
 extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6,
                                       float *pf5, float *pf4, float *pf3, float *pf2, void *workspace,
                                       size_t workspace_bytes, void *stream_)
@@ -495,6 +529,25 @@ extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B,
     if (!ctx->loaded) return fail(ctx, VSTAB_E_STATE, "forward: vstab_load_weights has not been called");
     if (Cin != ctx->cin) return fail(ctx, VSTAB_E_SHAPE, "forward: feats has %d channels, weights expect %d", Cin, ctx->cin);
     if (!feats || !pf6 || !pf5 || !pf4 || !pf3 || !pf2 || !workspace) return fail(ctx, VSTAB_E_STATE, "forward: NULL buffer");
+    int eh[10], ew[10];
+    if (B < 1 || !level_sizes(H, W, eh, ew)) return fail(ctx, VSTAB_E_SHAPE, "forward: unsupported problem %dx%dx%dx%d", B, H, W, Cin);
+    const int chunk = max_chunk(B, H, W, Cin);
+    if (chunk < 1) return fail(ctx, VSTAB_E_SHAPE, "forward: one %dx%dx%d sample exceeds the 2 GiB tensor limit", H, W, Cin);
+    // samples are independent: process the batch in chunks that keep every tensor below 2 GiB
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int bc = std::min(chunk, B - b0);
+        const int rc = forward_chunk(ctx, feats + (size_t)b0 * H * W * Cin, bc, H, W, Cin,
+                                     pf6 + (size_t)b0 * eh[9] * ew[9] * 2, pf5 + (size_t)b0 * eh[7] * ew[7] * 2,
+                                     pf4 + (size_t)b0 * eh[5] * ew[5] * 2, pf3 + (size_t)b0 * eh[3] * ew[3] * 2,
+                                     pf2 + (size_t)b0 * (H - 2) * (W - 2) * 2, workspace, workspace_bytes, stream_);
+        if (rc != VSTAB_OK) return rc;
+    }
+    return VSTAB_OK;
+}
+
+static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5,
+                         float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_)
+{
     Plan pl;
     if (!make_plan(B, H, W, Cin, pl)) return fail(ctx, VSTAB_E_SHAPE, "forward: unsupported problem %dx%dx%dx%d", B, H, W, Cin);
     if (workspace_bytes < pl.total) return fail(ctx, VSTAB_E_NOMEM, "forward: workspace %zu < %zu bytes", workspace_bytes, pl.total);
@@ -523,7 +576,7 @@ extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B,
             if (i < 10) mac = (double)p.ph[0].M * ENC[i].k * ENC[i].k * (i == 0 ? Cin : ENC[i - 1].cout) * p.N;
             else if (i < 14) mac = (double)B * p.Ho * p.Wo * 4.0 * DEC_CIN[i - 10] * p.N;
             else mac = (double)p.ph[0].M * 194.0 * 18.0;
-            ctx->prof_flops[i] = 2.0 * mac;
+            ctx->prof_flops[i] += 2.0 * mac;
         }
     }
 #define EV_A(slot) (ev ? ev[2 * (slot)] : nullptr)
@@ -604,6 +657,7 @@ extern "C" int vstab_profile_reset(vstab_ctx *ctx)
 {
     if (!ctx) return fail(nullptr, VSTAB_E_STATE, "profile_reset: ctx is NULL");
     ctx->prof_forwards = 0;
+    for (double &f : ctx->prof_flops) f = 0;
     return VSTAB_OK;
 }
 

@@ -96,8 +96,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
         for (int j = 0; j < A_ROWS_V; ++j) R[j] = rinfo[(tid >> 3) + 32 * j];
     }
-    const long long row_pitch = (long long)p.Wi * p.Cs_in;
-    const float *wbase = p.wpk + ph.w_off + (long long)n0 * 32 + tid * 4;
+    // Operands are fetched with raw buffer loads: an out-of-image tap, the padded tail of a segment
+    // or a tile past the end of this split simply gets an offset beyond the descriptor's range and
+    // the hardware returns zeros -- the loop body has no branches and the compiler can interleave
+    // the address arithmetic and the loads with the MFMAs.
+    const int row_pitch = p.Wi * p.Cs_in;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwt =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wpk + ph.w_off), 0, p.w_bytes, 0x00020000);
+    const unsigned OOB = 0xC0000000u;                 // every tensor is < 2^31 bytes (checked on the host)
+    const unsigned wvoff0 = (unsigned)(n0 * 32 + tid * 4) * 4u;
 
     // K-tile cursor (row tap, segment, chunk) of the NEXT tile to load
     int c_ky, c_sg, c_kc;
@@ -113,36 +121,43 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
         const int ky = c_ky;
         const int qseg = c_kc * 32;                       // float offset inside the segment
         const int qabs0 = c_sg * p.SEG_STRIDE + qseg;     // float offset from the run start
-        if (++c_kc == kps) { c_kc = 0; if (++c_sg == p.NSEG) { c_sg = 0; ++c_ky; } }
+        {   // advance the cursor without branches (keeps the loop body one scheduling region)
+            const int kc1 = c_kc + 1;
+            const bool wrap_kc = kc1 == kps;
+            const int sg1 = c_sg + (wrap_kc ? 1 : 0);
+            const bool wrap_sg = sg1 == p.NSEG;
+            c_kc = wrap_kc ? 0 : kc1;
+            c_sg = wrap_sg ? 0 : sg1;
+            c_ky += wrap_sg ? 1 : 0;
+        }
         if constexpr (VEC) {
             const int qs = qseg + (tid & 7) * 4;
             const int qa = qabs0 + (tid & 7) * 4;
-            const long long rowoff = (long long)ky * row_pitch + qa;
+            const int rowoff = ky * row_pitch + qa;
             const bool segok = qs < p.SEG;
 #pragma unroll
             for (int j = 0; j < A_ROWS_V; ++j) {
-                const bool ok = segok && (unsigned)(R[j].y + ky) < (unsigned)p.Hi && qa >= R[j].z && qa < R[j].w;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) v = *reinterpret_cast<const f32x4 *>(p.in + ((long long)R[j].x + rowoff));
-                ra[j] = v;
+                const bool ok = segok & ((unsigned)(R[j].y + ky) < (unsigned)p.Hi) & (qa >= R[j].z) & (qa < R[j].w);
+                const unsigned off = ok ? (unsigned)(R[j].x + rowoff) * 4u : OOB;
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
             }
         } else {
             const int qs = qseg + (tid & 31);
             const int qa = qabs0 + (tid & 31);
-            const long long rowoff = (long long)ky * row_pitch + qa;
+            const int rowoff = ky * row_pitch + qa;
             const bool segok = qs < p.SEG;
 #pragma unroll
             for (int j = 0; j < A_ELEMS_S; ++j) {
                 const int4 ri = rinfo[(tid >> 5) + 8 * j];
-                const bool ok = segok && (unsigned)(ri.y + ky) < (unsigned)p.Hi && qa >= ri.z && qa < ri.w;
-                float v = 0.f;
-                if (ok) v = p.in[(long long)ri.x + rowoff];
-                ras[j] = v;
+                const bool ok = segok & ((unsigned)(ri.y + ky) < (unsigned)p.Hi) & (qa >= ri.z) & (qa < ri.w);
+                const unsigned off = ok ? (unsigned)(ri.x + rowoff) * 4u : OOB;
+                ras[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, off, 0, 0));
             }
         }
-        const float *ws = wbase + (long long)kt * p.Npad * 32;
+        const unsigned woff = wvoff0 + (unsigned)kt * (unsigned)(p.Npad * 128);
 #pragma unroll
-        for (int jb = 0; jb < B_PASS; ++jb) rb[jb] = *reinterpret_cast<const f32x4 *>(ws + jb * 1024);
+        for (int jb = 0; jb < B_PASS; ++jb)
+            rb[jb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rwt, woff + jb * 4096, 0, 0));
     };
 
     auto store_tile = [&](int buf) {
@@ -180,47 +195,92 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     const int a_row0 = (wm * MB * 32 + li) * 32;
     const int b_row0 = (wn * NB * 32 + li) * 32;
 
-    auto compute = [&](int buf) {
+    // operand fragments of one k-group (8 k): two named sets so that the LDS reads of group g+1
+    // are in flight while the 4*MB*NB MFMAs of group g issue -- also across the tile barrier
+    f32x4 fa0[MB], fb0[NB], fa1[MB], fb1[NB];
+    auto rd = [&](int buf, int q, f32x4 (&a)[MB], f32x4 (&b)[NB]) {
         const float *cA = sA + buf * (BM * 32) + a_row0;
         const float *cB = sB + buf * (BN * 32) + b_row0;
+        const int chunk = ((2 * q + lh) ^ sw) * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int chunk = ((2 * q + lh) ^ sw) * 4;
-            f32x4 a[MB], b[NB];
+        for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const f32x4 *>(cA + mb * 1024 + chunk);
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const f32x4 *>(cA + mb * 1024 + chunk);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const f32x4 *>(cB + nb * 1024 + chunk);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][jj], b[nb][jj], acc[mb][nb], 0, 0, 0);
-        }
+        for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const f32x4 *>(cB + nb * 1024 + chunk);
     };
+    auto mm = [&](const f32x4 (&a)[MB], const f32x4 (&b)[NB]) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][jj], b[nb][jj], acc[mb][nb], 0, 0, 0);
+    };
+
+    // Issue order of one steady-state tile, pinned with sched_group_barrier (hipcc left alone sinks
+    // the weight loads to their ds_write and waits for the L2 round trip, and issues the fragment
+    // reads only after the previous group's MFMAs):
+    //   k-group 0: reads of group 1, then one global load (+ its address arithmetic) per MFMA
+    //   k-group 1: reads of group 2, MFMAs
+    //   k-group 2: reads of group 3, MFMAs with the LDS writes of tile t+1 between them
+    //   barrier;   reads of group 0 of tile t+1, MFMAs of group 3
+    constexpr int G = 4 * MB * NB;                                    // MFMAs per k-group
+    constexpr int NRD = MB + NB;                                      // ds_read_b128 per k-group
+    constexpr int NLD = (VEC ? A_ROWS_V : A_ELEMS_S) + B_PASS;        // global loads per tile
+    constexpr int NST = NLD;                                          // LDS writes per tile
+    constexpr bool PIN = (NLD <= G) && (NST <= G);
 
     if (kt0 < kt1) {
         load_tile(kt0);
         store_tile(0);
         __syncthreads();
         int buf = 0;
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const bool more = (kt + 1 < kt1);
-#ifndef VSTAB_ABL          // tuning-harness ablations (tools/conv_bench); never defined in the product build
-            if (more) load_tile(kt + 1);
-            compute(buf);
-            if (more) store_tile(buf ^ 1);
+        rd(0, 0, fa0, fb0);
+        for (int kt = kt0; kt + 1 < kt1; ++kt) {
+            load_tile(kt + 1);                 // global -> registers (tile t+1)
+            rd(buf, 1, fa1, fb1);
+            mm(fa0, fb0);                      // k-group 0
+            rd(buf, 2, fa0, fb0);
+            mm(fa1, fb1);                      // k-group 1
+            rd(buf, 3, fa1, fb1);
+            mm(fa0, fb0);                      // k-group 2
+            store_tile(buf ^ 1);               // registers -> the other LDS buffer
+            if constexpr (PIN) {
+                __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, G - NLD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, G - NST, 0);
+#pragma unroll
+                for (int i = 0; i < NST; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            }
             __syncthreads();
-#else
-            if (more && !(VSTAB_ABL & 1)) load_tile(kt + 1);
-            if (!(VSTAB_ABL & 8)) compute(buf);
-            if (more && !(VSTAB_ABL & 2)) store_tile(buf ^ 1);
-            if (!(VSTAB_ABL & 4)) __syncthreads();
-#endif
+            rd(buf ^ 1, 0, fa0, fb0);          // first fragments of tile t+1 ...
+            mm(fa1, fb1);                      // ... fly under k-group 3 of tile t
+            if constexpr (PIN) {
+                __builtin_amdgcn_sched_group_barrier(0x100, NRD, 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, G, 1);
+            }
             buf ^= 1;
         }
+        // last tile of this split: nothing left to fetch
+        rd(buf, 1, fa1, fb1);
+        mm(fa0, fb0);
+        rd(buf, 2, fa0, fb0);
+        mm(fa1, fb1);
+        rd(buf, 3, fa1, fb1);
+        mm(fa0, fb0);
+        mm(fa1, fb1);
     }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -320,6 +380,7 @@ hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_
 {
     const int BM = 128;
     const int BN = tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32);
+    if (p.in_bytes >= 0x80000000u || p.w_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.Npad % BN != 0 || p.SEGP % 32 != 0 || p.SEGP < p.SEG || p.NSEG < 1 || p.ksplit < 1 || p.nphase < 1 || p.nphase > 4)
         return hipErrorInvalidValue;
     if (vec4 && ((p.Cs_in & 3) || (p.SEG & 3) || (p.SEG_STRIDE & 3))) return hipErrorInvalidValue;

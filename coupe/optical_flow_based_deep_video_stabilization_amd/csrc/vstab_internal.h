@@ -38,6 +38,8 @@ struct ConvParams {
     const float *bias;      // [Npad] (BatchNorm already folded in)
     float *out;
     float *partial;         // split-K slabs [(phase*ksplit+split)][Mmax][Npad]
+    unsigned in_bytes;      // size of the input tensor   (< 2^31: buffer-descriptor range checks)
+    unsigned w_bytes;       // size of ONE phase's packed weights
     int B, Hi, Wi, Cs_in;
     int KH;                 // row taps
     int NSEG, SEG, SEGP;    // segments per row tap, floats per segment, SEG rounded up to 32

@@ -98,8 +98,8 @@ class Context:
         _lib.check(_lib.lib().vstab_profile_reset(self._h), self._h)
 
     def profile_read(self):
-        """(ms summed over recorded forwards, algorithmic flops per forward, forwards), per launch slot.
-        The stream must have been synchronised."""
+        """(ms, algorithmic flops) per launch slot, both summed over the recorded passes, and the
+        number of passes.  The stream must have been synchronised."""
         ms = (C.c_double * 15)()
         fl = (C.c_double * 15)()
         n = C.c_int()

@@ -82,7 +82,9 @@ VSTAB_API const char *vstab_version(void);
  * "1/W_conv2d" (27 in the reference). */
 VSTAB_API int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *tensors, int count);
 
-/* Bytes of workspace vstab_flownets_forward needs for this problem (0 on bad shape). */
+/* Bytes of workspace vstab_flownets_forward needs for this problem (0 on bad shape).  No
+ * single tensor may reach 2 GiB (32-bit buffer offsets): larger batches are processed in
+ * chunks of the largest batch that fits, and the workspace is sized for one chunk. */
 VSTAB_API size_t vstab_workspace_bytes(int B, int H, int W, int Cin);
 
 /* Names/offsets of the intermediate tensors inside the workspace.  Returns the number
@@ -102,9 +104,10 @@ VSTAB_API int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B, 
  * vstab_flownets_forward (15 per forward: encoder stages 1..6_1, deconv5..2, predict2 tap
  * table; the GEMM kernel itself, not the split-K combine that may follow it) is bracketed by
  * hipEvents recorded on the forward's stream.  vstab_profile_read must be called after that stream has been
- * synchronised: it returns, summed over the forwards recorded since the last reset, the
- * elapsed milliseconds per launch slot, and the ALGORITHMIC flops of one forward per slot
- * (2*MAC of the layer as SURVEY.md 8d counts it; deconvs at 4 taps/output). */
+ * synchronised: it returns, both summed over the forward passes recorded since the last
+ * reset (a batch split into chunks records one pass per chunk; *n_forwards counts them), the
+ * elapsed milliseconds per launch slot and the ALGORITHMIC flops per slot (2*MAC of the layer
+ * as SURVEY.md 8d counts it; deconvs at 4 taps/output). */
 VSTAB_API int vstab_profile_enable(vstab_ctx *ctx, int enable);
 VSTAB_API int vstab_profile_reset(vstab_ctx *ctx);
 VSTAB_API int vstab_profile_read(vstab_ctx *ctx, double *ms_sum15, double *flops15, int *n_forwards);

@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for l in 2 5; do
-for a in 0 1 2 3 7 8; do echo "ABL=$a"; ./tools/conv_bench_abl$a $l 8 512 512 -1 -1 20; done
-echo "1 block/CU:"; VSTAB_LDS_PAD=20000 ./tools/conv_bench_abl0 $l 8 512 512 -1 -1 20
-VSTAB_LDS_PAD=20000 ./tools/conv_bench_abl3 $l 8 512 512 -1 -1 20
-VSTAB_LDS_PAD=20000 ./tools/conv_bench_abl7 $l 8 512 512 -1 -1 20
+export TMPDIR=/tmp
+for a in 0 7; do
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d gpurun_out/clk_$a -- ./tools/conv_bench_abl$a 2 8 512 512 -1 -1 20 > gpurun_out/clk_$a.log 2>&1
 done
