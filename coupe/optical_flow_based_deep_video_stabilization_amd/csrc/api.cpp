@@ -531,9 +531,12 @@ extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B,
     if (!feats || !pf6 || !pf5 || !pf4 || !pf3 || !pf2 || !workspace) return fail(ctx, VSTAB_E_STATE, "forward: NULL buffer");
     int eh[10], ew[10];
     if (B < 1 || !level_sizes(H, W, eh, ew)) return fail(ctx, VSTAB_E_SHAPE, "forward: unsupported problem %dx%dx%dx%d", B, H, W, Cin);
-    const int chunk = max_chunk(B, H, W, Cin);
-    if (chunk < 1) return fail(ctx, VSTAB_E_SHAPE, "forward: one %dx%dx%d sample exceeds the 2 GiB tensor limit", H, W, Cin);
-    // samples are independent: process the batch in chunks that keep every tensor below 2 GiB
+    const int cmax = max_chunk(B, H, W, Cin);
+    if (cmax < 1) return fail(ctx, VSTAB_E_SHAPE, "forward: one %dx%dx%d sample exceeds the 2 GiB tensor limit", H, W, Cin);
+    // samples are independent: process the batch in (equalised) chunks that keep every tensor below
+    // 2 GiB; equal chunks share one launch plan, so their results are bit-identical
+    const int nchunks = (B + cmax - 1) / cmax;
+    const int chunk = (B + nchunks - 1) / nchunks;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int bc = std::min(chunk, B - b0);
         const int rc = forward_chunk(ctx, feats + (size_t)b0 * H * W * Cin, bc, H, W, Cin,
