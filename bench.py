@@ -157,20 +157,11 @@ def main():
     # by kernel instantiation (as rocprofv3 names them) and the one with the most time is reported.
     roofline = None
     if use_events:
-        import ctypes as C
-        from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
         ms, flops, _nrec = ctx.profile_read()      # sums over every recorded pass of the timed region
         ctx.profile(False)
         nf = max(args.steps, 1)
         flops = [f / nf for f in flops]
-        inst = []
-        for slot in range(15):
-            buf = (C.c_int32 * 64)()
-            _lib.lib().vstab_host_layer_plan(B, H, W, Cin, slot, buf, 64)
-            tile, vec4 = buf[21], buf[22]
-            bn = (128, 64, 32)[tile]
-            wm, wn = ((2, 2), (2, 2), (4, 1))[tile]
-            inst.append(f"conv_mfma_kernel<128, {bn}, {wm}, {wn}, {'true' if vec4 else 'false'}>")
+        inst = ctx.profile_kernel_names()
         groups = {}
         for name, m, f in zip(inst, ms, flops):
             g_ = groups.setdefault(name, [0.0, 0.0, 0])

@@ -34,6 +34,7 @@ struct vstab_ctx {
     std::vector<hipEvent_t> prof_ev;     // [forward][15][2]
     int prof_forwards = 0;
     double prof_flops[15] = {0};
+    std::string prof_kernel[15];         // kernel instantiation each slot launched last
 };
 
 static int fail(vstab_ctx *ctx, int code, const char *fmt, ...)
@@ -520,6 +521,7 @@ static int max_chunk(int B, int H, int W, int Cin)
 
 static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5,
                          float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_);
+static std::string conv_kernel_name(ConvTile t, bool vec4);
 
 extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6,
                                       float *pf5, float *pf4, float *pf3, float *pf2, void *workspace,
@@ -602,6 +604,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
             r.Ho = p.Ho; r.Wo = p.Wo; r.Cs_out = p.Cs_out; r.c_off = 0; r.N = p.N; r.Npad = p.Npad; r.act = 1;
             if (in_bytes < 0x80000000LL && rowwin_applicable(r)) {
                 HIP_TRY(ctx, launch_conv_rowwin(r, stream, EV_A(0), EV_B(0)));
+                ctx->prof_kernel[0] = "conv_rowwin_kernel<7>";
                 continue;
             }
         }
@@ -611,6 +614,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         p.bias = dw + ctx->enc_b[i];
         p.partial = buf(B_PARTIAL);
         HIP_TRY(ctx, launch_conv(p, pl.tile[i], pl.vec4[i], stream, EV_A(i), EV_B(i)));
+        ctx->prof_kernel[i] = conv_kernel_name(pl.tile[i], pl.vec4[i]);
     }
     // decoder (model.py:847-880)
     float *pfs[5] = {pf6, pf5, pf4, pf3, pf2};
@@ -627,6 +631,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         p.bias = dw + ctx->dec_b[l];
         p.partial = buf(B_PARTIAL);
         HIP_TRY(ctx, launch_conv(p, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l)));
+        ctx->prof_kernel[10 + l] = conv_kernel_name(pl.tile[10 + l], true);
         const int ph = pl.eh[lvl_enc[l]], pw = pl.ew[lvl_enc[l]];          // coarser level
         const int h = pl.eh[lvl_enc[l + 1]], w = pl.ew[lvl_enc[l + 1]];    // this level
         HIP_TRY(ctx, launch_upflow(pfs[l], B, ph, pw, ctx->up[l], buf(cat_buf[l]), h, w, CONCAT_CS[l], CONCAT_C[l] - 2, stream));
@@ -640,6 +645,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         p.in = buf(B_CONCAT2); p.out = buf(B_T);
         p.wpk = dw + ctx->tab_w; p.bias = dw + ctx->tab_b; p.partial = nullptr;
         HIP_TRY(ctx, launch_conv(p, pl.tile[14], true, stream, EV_A(14), EV_B(14)));
+        ctx->prof_kernel[14] = conv_kernel_name(pl.tile[14], true);
         HIP_TRY(ctx, launch_pf2(buf(B_T), B, pl.eh[1], pl.ew[1], dw + ctx->pred2_b, pf3, pl.eh[3], pl.ew[3], pf2, H, W, stream));
     }
 #undef EV_A
@@ -648,7 +654,20 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
     return VSTAB_OK;
 }
 
+static std::string conv_kernel_name(ConvTile t, bool vec4)
+{
+    const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : "128, 32, 4, 1");
+    return std::string("conv_mfma_kernel<") + shape + (vec4 ? ", true>" : ", false>");
+}
+
 // ------------------------------------------------------------------------- profiling
+extern "C" int vstab_profile_kernel_name(vstab_ctx *ctx, int slot, char *buf, int cap)
+{
+    if (!ctx || !buf || cap < 1 || slot < 0 || slot > 14) return fail(ctx, VSTAB_E_STATE, "profile_kernel_name: bad argument");
+    std::snprintf(buf, (size_t)cap, "%s", ctx->prof_kernel[slot].c_str());
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_profile_enable(vstab_ctx *ctx, int enable)
 {
     if (!ctx) return fail(nullptr, VSTAB_E_STATE, "profile_enable: ctx is NULL");

@@ -106,6 +106,14 @@ class Context:
         _lib.check(_lib.lib().vstab_profile_read(self._h, ms, fl, C.byref(n)), self._h)
         return list(ms), list(fl), n.value
 
+    def profile_kernel_names(self):
+        out = []
+        for slot in range(15):
+            b = C.create_string_buffer(96)
+            _lib.check(_lib.lib().vstab_profile_kernel_name(self._h, slot, b, 96), self._h)
+            out.append(b.value.decode())
+        return out
+
     def internals(self, B, H, W, Cin):
         """Views of the intermediate tensors in the workspace of the last forward (tests)."""
         ws = self.workspace(B, H, W, Cin)

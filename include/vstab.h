@@ -111,6 +111,8 @@ VSTAB_API int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B, 
 VSTAB_API int vstab_profile_enable(vstab_ctx *ctx, int enable);
 VSTAB_API int vstab_profile_reset(vstab_ctx *ctx);
 VSTAB_API int vstab_profile_read(vstab_ctx *ctx, double *ms_sum15, double *flops15, int *n_forwards);
+/* Name (as rocprofv3 prints it) of the kernel instantiation launch slot `slot` used in the last forward. */
+VSTAB_API int vstab_profile_kernel_name(vstab_ctx *ctx, int slot, char *buf, int cap);
 
 /* ---- glue: main:497-498.  out[B,oh,ow,2] = resize_images(flow * pre, [oh,ow]) with the
  * x channel then multiplied by sx and the y channel by sy (legacy TF bilinear,
