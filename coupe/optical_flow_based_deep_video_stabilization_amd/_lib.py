@@ -36,6 +36,11 @@ EXPORTS = {
     "vstab_resize_bilinear": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]),
     "vstab_warp_flow": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "vstab_get_pixel_value": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
+    "vstab_st_transform": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_st_bilinear_interp": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "vstab_st_meshgrid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_homography_warp": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_vec2mtrx": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_level_sizes": (C.c_int, [C.c_int, C.c_int, c_int32_p]),
     "vstab_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_profile_reset": (C.c_int, [C.c_void_p]),

@@ -733,3 +733,49 @@ extern "C" int vstab_get_pixel_value(const float *img, const int32_t *x, const i
     HIP_TRY(nullptr, launch_get_pixel_value(img, x, y, out, B, H, W, C, Hi, Wi, (hipStream_t)stream));
     return VSTAB_OK;
 }
+
+// ------------------------------------------------------------------------- secondary samplers
+extern "C" int vstab_st_transform(const float *img, int B, int H, int W, int C, const float *theta, int theta_dim,
+                                  float *out, int oh, int ow, void *stream)
+{
+    if (!img || !theta || !out) return fail(nullptr, VSTAB_E_STATE, "st_transform: NULL buffer");
+    if (B < 1 || H < 1 || W < 1 || C < 1 || oh < 1 || ow < 1 || (theta_dim != 6 && theta_dim != 8))
+        return fail(nullptr, VSTAB_E_SHAPE, "st_transform: bad shape (theta must be [B,6] or [B,8])");
+    HIP_TRY(nullptr, launch_st_transform(img, B, H, W, C, theta, theta_dim, out, oh, ow, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_st_bilinear_interp(const float *img, int B, int H, int W, int C, const float *x, const float *y,
+                                        int npix, float *out, void *stream)
+{
+    if (!img || !x || !y || !out) return fail(nullptr, VSTAB_E_STATE, "st_bilinear_interp: NULL buffer");
+    if (B < 1 || H < 1 || W < 1 || C < 1 || npix < 1) return fail(nullptr, VSTAB_E_SHAPE, "st_bilinear_interp: bad shape");
+    HIP_TRY(nullptr, launch_st_interp(img, B, H, W, C, x, y, npix, out, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_st_meshgrid(float *out, int oh, int ow, void *stream)
+{
+    if (!out) return fail(nullptr, VSTAB_E_STATE, "st_meshgrid: NULL buffer");
+    if (oh < 1 || ow < 1 || (long long)oh * ow > 0x7fffffffLL / 3) return fail(nullptr, VSTAB_E_SHAPE, "st_meshgrid: bad shape");
+    HIP_TRY(nullptr, launch_st_meshgrid(out, oh, ow, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_homography_warp(const float *img, int B, int Hi, int Wi, int C, const float *M, float *out, int oh,
+                                     int ow, void *stream)
+{
+    if (!img || !M || !out) return fail(nullptr, VSTAB_E_STATE, "homography_warp: NULL buffer");
+    if (B < 1 || Hi < 1 || Wi < 1 || C < 1 || oh < 1 || ow < 1) return fail(nullptr, VSTAB_E_SHAPE, "homography_warp: bad shape");
+    HIP_TRY(nullptr, launch_homography_warp(img, B, Hi, Wi, C, M, out, oh, ow, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_vec2mtrx(const float *p, int B, int dim, int warp_approx, float *out, void *stream)
+{
+    if (!p || !out) return fail(nullptr, VSTAB_E_STATE, "vec2mtrx: NULL buffer");
+    if (B < 1 || (dim != 8 && dim != 6) || warp_approx < 1 || warp_approx > 64)
+        return fail(nullptr, VSTAB_E_SHAPE, "vec2mtrx: p must be [B,8] or [B,6], 1 <= warpApprox <= 64");
+    HIP_TRY(nullptr, launch_vec2mtrx(p, B, dim, warp_approx, out, (hipStream_t)stream));
+    return VSTAB_OK;
+}

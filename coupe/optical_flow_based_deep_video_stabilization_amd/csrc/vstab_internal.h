@@ -120,6 +120,18 @@ hipError_t launch_get_pixel_value(const float *img, const int32_t *x, const int3
                                   int B, int H, int W, int C, int Hi, int Wi, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------
+// Secondary samplers (sampler_ops.hip): spatial_transformer.py / warp.py rows S1-S3.
+// ---------------------------------------------------------------------------------
+hipError_t launch_st_interp(const float *img, int B, int H, int W, int C, const float *x, const float *y,
+                            int npix, float *out, hipStream_t stream);
+hipError_t launch_st_transform(const float *img, int B, int H, int W, int C, const float *theta, int tdim,
+                               float *out, int oh, int ow, hipStream_t stream);
+hipError_t launch_st_meshgrid(float *out, int oh, int ow, hipStream_t stream);
+hipError_t launch_homography_warp(const float *img, int B, int Hi, int Wi, int C, const float *M, float *out,
+                                  int oh, int ow, hipStream_t stream);
+hipError_t launch_vec2mtrx(const float *p, int B, int dim, int approx, float *out, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------
 // Host-side weight packing (pack.cpp): pure CPU code.
 // ---------------------------------------------------------------------------------
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

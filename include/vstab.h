@@ -135,6 +135,27 @@ VSTAB_API int vstab_warp_flow(const float *img, const float *flow, float *out, i
 VSTAB_API int vstab_get_pixel_value(const float *img, const int32_t *x, const int32_t *y, float *out, int B,
                           int H, int W, int C, int Hi, int Wi, void *stream);
 
+/* ---- secondary samplers named by north_star (never executed by the reference's live scripts) ---- */
+/* AffineTransformer.transform / ProjectiveTransformer.transform / transformer()
+ * (spatial_transformer.py:400-452, 539-608, 34-38): theta [B,6] or [B,8] (theta_dim = 6 | 8; the
+ * projective 3x3 gets a trailing 1), sampling grid linspace(-1,1) of the OUTPUT size, bilinear_interp
+ * sampler with a 1-pixel zero border.  img [B,H,W,C] -> out [B,oh,ow,C]. */
+VSTAB_API int vstab_st_transform(const float *img, int B, int H, int W, int C, const float *theta, int theta_dim,
+                                 float *out, int oh, int ow, void *stream);
+/* bilinear_interp(im, x, y, out_size) / _interpolate (spatial_transformer.py:902-964, 787-792): x, y flat
+ * [B*npix] normalised to [-1,1]; out [B*npix, C]. */
+VSTAB_API int vstab_st_bilinear_interp(const float *img, int B, int H, int W, int C, const float *x, const float *y,
+                                       int npix, float *out, void *stream);
+/* _meshgrid(out_size) (spatial_transformer.py:755-779): out[3*oh*ow] = x_t row, y_t row, ones. */
+VSTAB_API int vstab_st_meshgrid(float *out, int oh, int ow, void *stream);
+/* warp.transformImage / transformCropImage (warp.py:46-86, 89-129): M [B,9] = refMtrx . pMtrx maps the canonical
+ * linspace(-1,1) grid of the OUTPUT size to source pixel coordinates; floor/ceil taps, zero outside. */
+VSTAB_API int vstab_homography_warp(const float *img, int B, int Hi, int Wi, int C, const float *M, float *out, int oh,
+                                    int ow, void *stream);
+/* warp.vec2mtrx (warp.py:25-43): p [B,8] (homography, sl(3) generator) or [B,6] (affine) -> [B,9]
+ * Taylor matrix exponential with `warp_approx` terms. */
+VSTAB_API int vstab_vec2mtrx(const float *p, int B, int dim, int warp_approx, float *out, void *stream);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU tests) --------------------- */
 /* Level sizes of the encoder for an HxW input: hw[2*i], hw[2*i+1] = (h, w) of stage i
  * (10 stages).  Returns 0 or VSTAB_E_SHAPE. */

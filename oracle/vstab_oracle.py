@@ -287,3 +287,122 @@ def stabilise_native(feats, weights, dtype=torch.float64):
     unstab = resize_bilinear_legacy(x[..., 24:27] if x.shape[3] >= 27 else x[..., -3:], H - 2, W - 2)
     warped = tf_warp(unstab, flows["predict_flow2"].to(torch.float32), H - 2, W - 2, dtype)
     return flows, warped
+
+
+# --------------------------------------------------------------------------- secondary samplers
+# spatial_transformer.py ("ST") and warp.py of the reference; never executed by its live scripts.
+def st_linspace(n: int) -> np.ndarray:
+    """tf.linspace(-1.0, 1.0, n) in fp32: start + i*step, step = 2/(n-1)  (ST:766-767)."""
+    step = np.float32(2.0) / np.float32(n - 1) if n > 1 else np.float32(0)
+    return (np.float32(-1.0) + np.arange(n, dtype=np.float32) * step).astype(np.float32)
+
+
+def st_meshgrid(out_size) -> np.ndarray:
+    """_meshgrid (ST:755-779): flat [3*H*W] = x_t (x fastest), y_t, ones."""
+    oh, ow = out_size
+    xt, yt = np.meshgrid(st_linspace(ow), st_linspace(oh))
+    return np.concatenate([xt.reshape(-1), yt.reshape(-1), np.ones(oh * ow, np.float32)]).astype(np.float32)
+
+
+def st_bilinear_interp(im, x, y, out_size, dtype=torch.float32):
+    """bilinear_interp (ST:902-964), line by line.  im [B,H,W,C]; x, y flat [B*oh*ow] in [-1,1]."""
+    im = _t(im, dtype)
+    B, H, W, C = im.shape
+    imp = F.pad(im, (0, 0, 1, 1, 1, 1))                                   # edge_size = 1, zeros (:905-906)
+    x = _t(x, torch.float32).reshape(-1)
+    y = _t(y, torch.float32).reshape(-1)
+    wf, hf = np.float32(W), np.float32(H)
+    x = (x + 1.0) / 2.0 * (wf - 1.0)                                      # :916-917
+    y = (y + 1.0) / 2.0 * (hf - 1.0)
+    x = torch.clamp(x, -1.0, float(wf - 1 + 1)) + 1.0                     # :918-922
+    y = torch.clamp(y, -1.0, float(hf - 1 + 1)) + 1.0
+    x0f, y0f = torch.floor(x), torch.floor(y)
+    x1f, y1f = x0f + 1, y0f + 1
+    x0, y0 = x0f.long(), y0f.long()
+    x1 = torch.minimum(x1f, torch.tensor(float(wf - 1 + 2))).long()      # :932-933
+    y1 = torch.minimum(y1f, torch.tensor(float(hf - 1 + 2))).long()
+    dim2, dim1 = W + 2, (W + 2) * (H + 2)
+    npix = out_size[0] * out_size[1]
+    base = torch.arange(B).repeat_interleave(npix) * dim1                 # _repeat (:938)
+    flat = imp.reshape(-1, C)
+    I00, I01 = flat[base + y0 * dim2 + x0], flat[base + y0 * dim2 + x1]
+    I10, I11 = flat[base + y1 * dim2 + x0], flat[base + y1 * dim2 + x1]
+    xd, yd = x.to(dtype), y.to(dtype)
+    x0d, x1d, y0d, y1d = x0f.to(dtype), x1f.to(dtype), y0f.to(dtype), y1f.to(dtype)
+    w00 = ((x1d - xd) * (y1d - yd)).unsqueeze(1)                          # :958-961 (unclipped x1_f)
+    w01 = ((xd - x0d) * (y1d - yd)).unsqueeze(1)
+    w10 = ((x1d - xd) * (yd - y0d)).unsqueeze(1)
+    w11 = ((xd - x0d) * (yd - y0d)).unsqueeze(1)
+    return w00 * I00 + w01 * I01 + w10 * I10 + w11 * I11
+
+
+def st_transform(im, theta, out_size, dtype=torch.float32):
+    """AffineTransformer.transform (ST:400-452) for theta [B,6], ProjectiveTransformer.transform
+    (ST:539-608) for theta [B,8]."""
+    im = _t(im, dtype)
+    B = im.shape[0]
+    th = _t(theta, torch.float32).reshape(B, -1)
+    grid = torch.from_numpy(st_meshgrid(out_size)).reshape(3, -1)
+    if th.shape[1] == 6:
+        T = torch.matmul(th.reshape(B, 2, 3), grid.unsqueeze(0).expand(B, 3, -1))
+        xs, ys = T[:, 0], T[:, 1]
+    else:
+        th9 = torch.cat([th, torch.ones(B, 1)], 1).reshape(B, 3, 3)
+        T = torch.matmul(th9, grid.unsqueeze(0).expand(B, 3, -1))
+        z = T[:, 2]
+        z = torch.where(z == 0, z + np.float32(1e-8), z)                  # safe_z (:598)
+        xs, ys = T[:, 0] / z, T[:, 1] / z
+    out = st_bilinear_interp(im, xs.reshape(-1), ys.reshape(-1), out_size, dtype)
+    return out.reshape(B, out_size[0], out_size[1], im.shape[3])
+
+
+def warp_vec2mtrx(p, warp_type: str, warp_approx: int):
+    """warp.vec2mtrx (warp.py:25-43) in fp32."""
+    p = _t(p, torch.float32)
+    B = p.shape[0]
+    if warp_type == "homography":
+        p1, p2, p3, p4, p5, p6, p7, p8 = p.unbind(1)
+        A = torch.stack([torch.stack([p3, p2, p1], 1), torch.stack([p6, -p3 - p7, p5], 1), torch.stack([p4, p8, p7], 1)], 1)
+    else:
+        O = torch.zeros(B)
+        p1, p2, p3, p4, p5, p6 = p.unbind(1)
+        A = torch.stack([torch.stack([p1, p2, p3], 1), torch.stack([p4, p5, p6], 1), torch.stack([O, O, O], 1)], 1)
+    pM = torch.eye(3).repeat(B, 1, 1)
+    numer = torch.eye(3).repeat(B, 1, 1)
+    denom = 1.0
+    for i in range(1, warp_approx):
+        numer = torch.matmul(numer, A)
+        denom *= i
+        pM = pM + numer / denom
+    return pM
+
+
+def warp_transform_image(image, M, oh: int, ow: int, dtype=torch.float32):
+    """warp.transformImage / transformCropImage (warp.py:46-86, 89-129) given M = refMtrx . pMtrx [B,3,3];
+    image [B,Hi,Wi,C] -> [B,oh,ow,C]."""
+    image = _t(image, dtype)
+    B, Hi, Wi, C = image.shape
+    M = _t(M, torch.float32).reshape(B, 3, 3)
+    X, Y = np.meshgrid(np.linspace(-1, 1, ow), np.linspace(-1, 1, oh))
+    XYhom = torch.from_numpy(np.stack([X.flatten(), Y.flatten(), np.ones(oh * ow)], 0).astype(np.float32))
+    W3 = torch.matmul(M, XYhom.unsqueeze(0).expand(B, 3, -1))
+    xw = (W3[:, 0] / (W3[:, 2] + np.float32(1e-8))).reshape(B, oh, ow)
+    yw = (W3[:, 1] / (W3[:, 2] + np.float32(1e-8))).reshape(B, oh, ow)
+    xf, xc, yf, yc = torch.floor(xw), torch.ceil(xw), torch.floor(yw), torch.ceil(yw)
+    xfi, xci, yfi, yci = (t.clamp(-1e9, 1e9).long() for t in (xf, xc, yf, yc))
+    vec = torch.cat([image.reshape(-1, C), torch.zeros(1, C, dtype=dtype)], 0)
+    bidx = torch.arange(B).view(B, 1, 1)
+    outside = B * Hi * Wi
+
+    def gather(xi, yi):
+        inside = (xi >= 0) & (xi < Wi) & (yi >= 0) & (yi < Hi)
+        idx = torch.where(inside, (bidx * Hi + yi) * Wi + xi, torch.full_like(xi, outside))
+        return vec[idx]
+
+    xr = (xw - xf).to(dtype).unsqueeze(3)
+    yr = (yw - yf).to(dtype).unsqueeze(3)
+    UL = gather(xfi, yfi) * (1 - xr) * (1 - yr)
+    UR = gather(xci, yfi) * xr * (1 - yr)
+    BL = gather(xfi, yci) * (1 - xr) * yr
+    BR = gather(xci, yci) * xr * yr
+    return UL + UR + BL + BR

@@ -120,3 +120,60 @@ def test_flow_glue_constants():
     assert torch.allclose(f, torch.full_like(f, float(np.float32(384.0) / np.float32(382.0))), atol=1e-12)
     f2 = vo.flow_to_output_res(pf2, 384, 512, 768, 1024)
     assert torch.allclose(f2[..., 0] / f[0, 0, 0, 0], torch.full((1, 768, 1024), 2.0, dtype=F64))
+
+
+# --------------------------------------------------------------------------- secondary samplers
+def test_st_identity_theta_reproduces_image_and_meshgrid():
+    # identity affine theta on the same output size samples every pixel centre exactly
+    im = torch.rand(2, 5, 7, 3, dtype=F64)
+    th = torch.tensor([[1., 0, 0, 0, 1, 0]]).repeat(2, 1)
+    out = vo.st_transform(im, th, (5, 7), F64)
+    assert torch.allclose(out, im, atol=1e-6)
+    g = vo.st_meshgrid((2, 3)).reshape(3, 6)
+    assert g[0].tolist() == [-1, 0, 1, -1, 0, 1] and g[1].tolist() == [-1, -1, -1, 1, 1, 1] and g[2].tolist() == [1] * 6
+
+
+def test_st_zero_border_and_clipping():
+    # a shift by one pixel to the right pulls zeros in from the 1-pixel border; far outside is all zero
+    im = torch.ones(1, 4, 4, 1, dtype=F64)
+    shift = 2.0 / 3.0                                  # one pixel in normalised units for W = 4
+    out = vo.st_transform(im, torch.tensor([[1., 0, -shift, 0, 1, 0]]), (4, 4), F64)[0, :, :, 0]
+    assert torch.allclose(out[:, 0], torch.zeros(4, dtype=F64), atol=1e-6) and torch.allclose(out[:, 1:], torch.ones(4, 3, dtype=F64), atol=1e-6)
+    far = vo.st_transform(im, torch.tensor([[1., 0, 10, 0, 1, 0]]), (4, 4), F64)
+    assert far.abs().max() == 0
+    half = vo.st_transform(im, torch.tensor([[1., 0, -shift / 2, 0, 1, 0]]), (4, 4), F64)[0, :, :, 0]
+    assert torch.allclose(half[:, 0], torch.full((4,), 0.5, dtype=F64), atol=1e-6)     # halfway into the zero border
+
+
+def test_projective_equals_affine_when_bottom_row_is_zero():
+    im = torch.rand(1, 6, 6, 2, dtype=F64)
+    a = torch.tensor([[0.9, 0.1, 0.05, -0.1, 1.1, 0.0]])
+    p = torch.cat([a, torch.zeros(1, 2)], 1)
+    assert torch.allclose(vo.st_transform(im, a, (5, 4), F64), vo.st_transform(im, p, (5, 4), F64), atol=1e-12)
+
+
+def test_vec2mtrx_is_truncated_expm():
+    # homography generator A = [[p3,p2,p1],[p6,-p3-p7,p5],[p4,p8,p7]] (trace 0); one term = identity
+    p = torch.tensor([[0.1, -0.2, 0.05, 0.01, 0.3, -0.1, 0.02, 0.03]])
+    assert torch.equal(vo.warp_vec2mtrx(p, "homography", 1), torch.eye(3).unsqueeze(0))
+    A = torch.tensor([[0.05, -0.2, 0.1], [-0.1, -0.05 - 0.02, 0.3], [0.01, 0.03, 0.02]])
+    two = vo.warp_vec2mtrx(p, "homography", 3)[0]                  # I + A + A^2/2
+    assert torch.allclose(two, torch.eye(3) + A + A @ A / 2, atol=1e-6)
+    import scipy.linalg
+    full = vo.warp_vec2mtrx(p, "homography", 12)[0].double().numpy()
+    assert np.abs(full - scipy.linalg.expm(A.double().numpy())).max() < 1e-6
+    aff = vo.warp_vec2mtrx(torch.tensor([[0.1, 0.2, 0.3, 0.4, 0.5, 0.6]]), "affine", 2)[0]
+    assert torch.allclose(aff, torch.tensor([[1.1, 0.2, 0.3], [0.4, 1.5, 0.6], [0, 0, 1.0]]))
+
+
+def test_transform_image_identity_and_outside():
+    # refMtrx mapping the canonical box onto the pixel box reproduces the image; a far shift gives zeros
+    im = torch.rand(1, 4, 6, 3, dtype=F64)
+    M = torch.tensor([[[2.5, 0, 2.5], [0, 1.5, 1.5], [0, 0, 1.0]]])     # x: [-1,1] -> [0,5], y: -> [0,3]
+    out = vo.warp_transform_image(im, M, 4, 6, F64)
+    assert torch.allclose(out, im, atol=1e-5)
+    Mfar = M.clone(); Mfar[0, 0, 2] = 100.0
+    assert vo.warp_transform_image(im, Mfar, 4, 6, F64).abs().max() == 0
+    Mhalf = M.clone(); Mhalf[0, 0, 2] = 2.0                          # half a pixel to the left
+    o = vo.warp_transform_image(torch.ones(1, 4, 6, 1, dtype=F64), Mhalf, 4, 6, F64)[0, :, :, 0]
+    assert torch.allclose(o[:, 0], torch.full((4,), 0.5, dtype=F64), atol=1e-5) and torch.allclose(o[:, 1:], torch.ones(4, 5, dtype=F64), atol=1e-5)
