@@ -35,6 +35,10 @@ struct vstab_ctx {
     int prof_forwards = 0;
     double prof_flops[15] = {0};
     std::string prof_kernel[15];         // kernel instantiation each slot launched last
+    // VGG16 trunk (vstab_vgg16_*)
+    bool vgg_loaded = false;
+    float *vgg_weights = nullptr;
+    size_t vgg_w[13], vgg_b[13];
 };
 
 static int fail(vstab_ctx *ctx, int code, const char *fmt, ...)
@@ -308,6 +312,7 @@ extern "C" void vstab_destroy(vstab_ctx *ctx)
     if (!ctx) return;
     if (ctx->dev_weights) (void)hipFree(ctx->dev_weights);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    if (ctx->vgg_weights) (void)hipFree(ctx->vgg_weights);
     delete ctx;
 }
 
@@ -777,5 +782,172 @@ extern "C" int vstab_vec2mtrx(const float *p, int B, int dim, int warp_approx, f
     if (B < 1 || (dim != 8 && dim != 6) || warp_approx < 1 || warp_approx > 64)
         return fail(nullptr, VSTAB_E_SHAPE, "vec2mtrx: p must be [B,8] or [B,6], 1 <= warpApprox <= 64");
     HIP_TRY(nullptr, launch_vec2mtrx(p, B, dim, warp_approx, out, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+// ------------------------------------------------------------------------- VGG16 trunk (vgg16.py)
+namespace {
+struct VggLayer { const char *name; int cin, cout; bool pool_after; };
+const VggLayer VGG[13] = {{"conv1_1", 3, 64, false},   {"conv1_2", 64, 64, true},    {"conv2_1", 64, 128, false},
+                          {"conv2_2", 128, 128, true}, {"conv3_1", 128, 256, false}, {"conv3_2", 256, 256, false},
+                          {"conv3_3", 256, 256, true}, {"conv4_1", 256, 512, false}, {"conv4_2", 512, 512, false},
+                          {"conv4_3", 512, 512, true}, {"conv5_1", 512, 512, false}, {"conv5_2", 512, 512, false},
+                          {"conv5_3", 512, 512, true}};
+
+// plain conv (k x k, stride, zero pad) on an NHWC tensor with cs_in == cin
+bool fill_plain_conv(ConvParams &p, ConvTile &tile, bool &vec4, int B, int Hi, int Wi, int cin, int k, int stride, int pad,
+                     int cout, int cs_out, int c_off, int act)
+{
+    std::memset(&p, 0, sizeof p);
+    const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+    if (Ho < 1 || Wo < 1) return false;
+    p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cs_in = cin;
+    set_layout(p, klayout_run(k, k, cin));
+    p.s_in = stride; p.s_out = 1; p.Ho = Ho; p.Wo = Wo; p.Cs_out = cs_out; p.c_off = c_off;
+    p.N = cout;
+    const int BN = cout >= 128 ? 128 : 64;
+    tile = cout >= 128 ? TILE_128x128 : TILE_128x64;
+    p.Npad = round_up(cout, BN);
+    p.act = act; p.nphase = 1;
+    p.ph[0].Hg = Ho; p.ph[0].Wg = Wo; p.ph[0].M = B * Ho * Wo; p.ph[0].off_y = -pad; p.ph[0].off_x = -pad;
+    p.Mmax = p.ph[0].M;
+    vec4 = (cin % 4 == 0);
+    if ((long long)B * Hi * Wi * cin * 4 >= 0x80000000LL || (long long)B * Ho * Wo * cs_out * 4 >= 0x80000000LL) return false;
+    set_ranges(p);
+    choose_split(p, BN);
+    return true;
+}
+
+struct VggPlan { int h[18], w[18], c[18]; size_t partial_floats; };
+
+bool vgg_plan(int B, int H, int W, VggPlan &v)
+{
+    if (B < 1 || H < 1 || W < 1) return false;
+    int h = H, w = W, o = 0;
+    v.partial_floats = 0;
+    for (int l = 0; l < 13; ++l) {
+        ConvParams p; ConvTile t; bool vec;
+        if (!fill_plain_conv(p, t, vec, B, h, w, VGG[l].cin, 3, 1, 1, VGG[l].cout, VGG[l].cout, 0, 2)) return false;
+        if (p.ksplit > 1) v.partial_floats = std::max(v.partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
+        v.h[o] = h; v.w[o] = w; v.c[o] = VGG[l].cout; ++o;
+        if (VGG[l].pool_after) {
+            h = (h + 1) / 2; w = (w + 1) / 2;
+            v.h[o] = h; v.w[o] = w; v.c[o] = VGG[l].cout; ++o;
+        }
+    }
+    return true;
+}
+
+int vgg_max_chunk(int B, int H, int W)
+{
+    VggPlan v;
+    if (vgg_plan(B, H, W, v)) return B;
+    int lo = 0, hi = B;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (vgg_plan(mid, H, W, v)) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+}  // namespace
+
+extern "C" int vstab_vgg16_shapes(int H, int W, int32_t *hwc54)
+{
+    VggPlan v;
+    if (!hwc54 || !vgg_plan(1, H, W, v)) return fail(nullptr, VSTAB_E_SHAPE, "vgg16: unsupported input %dx%d", H, W);
+    for (int i = 0; i < 18; ++i) { hwc54[3 * i] = v.h[i]; hwc54[3 * i + 1] = v.w[i]; hwc54[3 * i + 2] = v.c[i]; }
+    return VSTAB_OK;
+}
+
+extern "C" size_t vstab_vgg16_workspace_bytes(int B, int H, int W)
+{
+    const int chunk = B >= 1 ? vgg_max_chunk(B, H, W) : 0;
+    VggPlan v;
+    if (chunk < 1 || !vgg_plan(chunk, H, W, v)) { fail(nullptr, VSTAB_E_SHAPE, "vgg16: unsupported problem %dx%dx%d", B, H, W); return 0; }
+    return std::max<size_t>(v.partial_floats * 4, 256);
+}
+
+extern "C" int vstab_vgg16_load(vstab_ctx *ctx, const vstab_tensor *t, int count)
+{
+    if (!ctx) return fail(nullptr, VSTAB_E_STATE, "vgg16_load: ctx is NULL");
+    if (!t || count <= 0) return fail(ctx, VSTAB_E_WEIGHTS, "vgg16_load: no tensors");
+    std::vector<float> host;
+    auto reserve = [&](size_t n) { size_t o = (host.size() + 63) / 64 * 64; host.resize(o + n, 0.f); return o; };
+    std::vector<double> ones;
+    for (int l = 0; l < 13; ++l) {
+        const std::string n = VGG[l].name;
+        const vstab_tensor *W = find(t, count, n + "/filter"), *b = find(t, count, n + "/biases");
+        if (!shape_is(W, {3, 3, VGG[l].cin, VGG[l].cout}) || !shape_is(b, {VGG[l].cout}))
+            return fail(ctx, VSTAB_E_WEIGHTS, "missing or mis-shaped variable %s/{filter,biases}", n.c_str());
+        const int BN = VGG[l].cout >= 128 ? 128 : 64, npad = round_up(VGG[l].cout, BN);
+        const KLayout L = klayout_run(3, 3, VGG[l].cin);
+        ones.assign(npad, 1.0);
+        ctx->vgg_b[l] = reserve(npad);
+        fold_bn(b->data, nullptr, nullptr, nullptr, VGG[l].cout, npad, ones.data(), host.data() + ctx->vgg_b[l]);
+        ctx->vgg_w[l] = reserve((size_t)L.ktiles() * npad * 32);
+        pack_conv(W->data, ones.data(), 3, 3, VGG[l].cin, VGG[l].cin, VGG[l].cout, npad, L, host.data() + ctx->vgg_w[l]);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->vgg_weights) { (void)hipFree(ctx->vgg_weights); ctx->vgg_weights = nullptr; }
+    ctx->vgg_loaded = false;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->vgg_weights), host.size() * sizeof(float));
+    if (e != hipSuccess) return fail(ctx, VSTAB_E_NOMEM, "hipMalloc(%zu bytes of VGG16 weights): %s", host.size() * 4, hipGetErrorString(e));
+    HIP_TRY(ctx, hipMemcpy(ctx->vgg_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->vgg_loaded = true;
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_vgg16_forward(vstab_ctx *ctx, const float *input, int B, int H, int W, float *const *outs, void *workspace,
+                                   size_t workspace_bytes, void *stream_)
+{
+    if (!ctx) return fail(nullptr, VSTAB_E_STATE, "vgg16_forward: ctx is NULL");
+    if (!ctx->vgg_loaded) return fail(ctx, VSTAB_E_STATE, "vgg16_forward: vstab_vgg16_load has not been called");
+    if (!input || !outs || !workspace) return fail(ctx, VSTAB_E_STATE, "vgg16_forward: NULL buffer");
+    for (int i = 0; i < 18; ++i)
+        if (!outs[i] || ((uintptr_t)outs[i] & 15)) return fail(ctx, VSTAB_E_ALIGN, "vgg16_forward: output %d NULL or not 16-byte aligned", i);
+    const int cmax = B >= 1 ? vgg_max_chunk(B, H, W) : 0;
+    if (cmax < 1) return fail(ctx, VSTAB_E_SHAPE, "vgg16_forward: unsupported problem %dx%dx%d", B, H, W);
+    const int nchunks = (B + cmax - 1) / cmax, chunk = (B + nchunks - 1) / nchunks;
+    VggPlan v;
+    if (!vgg_plan(chunk, H, W, v)) return fail(ctx, VSTAB_E_SHAPE, "vgg16_forward: plan failed");
+    if (workspace_bytes < v.partial_floats * 4) return fail(ctx, VSTAB_E_NOMEM, "vgg16_forward: workspace %zu < %zu bytes", workspace_bytes, v.partial_floats * 4);
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int bc = std::min(chunk, B - b0);
+        const float *cur = input + (size_t)b0 * H * W * 3;
+        int h = H, w = W, o = 0;
+        for (int l = 0; l < 13; ++l) {
+            ConvParams p; ConvTile tile; bool vec;
+            if (!fill_plain_conv(p, tile, vec, bc, h, w, VGG[l].cin, 3, 1, 1, VGG[l].cout, VGG[l].cout, 0, 2))
+                return fail(ctx, VSTAB_E_SHAPE, "vgg16_forward: layer %s does not fit", VGG[l].name);
+            float *dst = outs[o] + (size_t)b0 * v.h[o] * v.w[o] * v.c[o];
+            p.in = cur; p.out = dst; p.wpk = ctx->vgg_weights + ctx->vgg_w[l]; p.bias = ctx->vgg_weights + ctx->vgg_b[l];
+            p.partial = (float *)workspace;
+            HIP_TRY(ctx, launch_conv(p, tile, vec, stream));
+            cur = dst; ++o;
+            if (VGG[l].pool_after) {
+                float *pd = outs[o] + (size_t)b0 * v.h[o] * v.w[o] * v.c[o];
+                HIP_TRY(ctx, launch_maxpool2x2(cur, bc, h, w, VGG[l].cout, pd, stream));
+                h = (h + 1) / 2; w = (w + 1) / 2;
+                cur = pd; ++o;
+            }
+        }
+    }
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_scale_shift(const float *x, long long npix, int C, float scale, const float *mean, float *out, void *stream)
+{
+    if (!x || !mean || !out) return fail(nullptr, VSTAB_E_STATE, "scale_shift: NULL buffer");
+    if (npix < 1 || C < 1 || C > 4) return fail(nullptr, VSTAB_E_SHAPE, "scale_shift: bad shape");
+    HIP_TRY(nullptr, launch_scale_shift(x, npix, C, scale, mean, out, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, void *stream)
+{
+    if (!x || !out) return fail(nullptr, VSTAB_E_STATE, "maxpool2x2: NULL buffer");
+    if (B < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return fail(nullptr, VSTAB_E_SHAPE, "maxpool2x2: bad shape (C must be a multiple of 4)");
+    HIP_TRY(nullptr, launch_maxpool2x2(x, B, H, W, C, out, (hipStream_t)stream));
     return VSTAB_OK;
 }

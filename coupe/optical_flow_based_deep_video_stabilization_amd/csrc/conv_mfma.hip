@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
                     const int oo = ooff[row];
                     if (cok && oo >= 0) {
                         float v = acc[mb][nb][r] + bv;
-                        if (p.act) v = fmaxf(v, 0.1f * v);
+                        if (p.act) v = fmaxf(v, (p.act == 1 ? 0.1f : 0.0f) * v);
                         p.out[(long long)oo + col] = v;
                     }
                 }
@@ -341,8 +341,9 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const ConvParams p)
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + c4 * 4);
     s += bv;
     if (p.act) {
+        const float slope = p.act == 1 ? 0.1f : 0.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e], 0.1f * s[e]);
+        for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e], slope * s[e]);
     }
     const int hw = ph.Hg * ph.Wg;
     const int n = m / hw, r2 = m - n * hw;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
                 const int ox = ox0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (ox < p.Wo) {
                     float v = acc[mb][r] + bv;
-                    if (p.act) v = fmaxf(v, 0.1f * v);
+                    if (p.act) v = fmaxf(v, (p.act == 1 ? 0.1f : 0.0f) * v);
                     p.out[((long long)(n * p.Ho + oy) * p.Wo + ox) * p.Cs_out + p.c_off + col] = v;
                 }
             }

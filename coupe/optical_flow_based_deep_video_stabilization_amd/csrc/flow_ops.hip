@@ -325,6 +325,61 @@ hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int
     return hipGetLastError();
 }
 
+// tf.nn.max_pool(ksize 2, strides 2, SAME) (vgg16.py:51-53): out = ceil(n/2); the window's taps beyond
+// the bottom/right edge do not take part.  One thread per 4 output channels.
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float *__restrict__ x, int B, int H, int W, int C4,
+                                                         float *__restrict__ out, int oh, int ow)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * oh * ow * C4;
+    if (idx >= total) return;
+    const int c = (int)(idx % C4);
+    const long long pix = idx / C4;
+    const int n = (int)(pix / (oh * ow));
+    const int rem = (int)(pix - (long long)n * oh * ow);
+    const int oy = rem / ow, ox = rem - oy * ow;
+    const int y0 = 2 * oy, x0 = 2 * ox;
+    const bool y1ok = y0 + 1 < H, x1ok = x0 + 1 < W;
+    const f32x4 *b = reinterpret_cast<const f32x4 *>(x) + (long long)n * H * W * C4 + c;
+    f32x4 m = b[((long long)y0 * W + x0) * C4];
+    if (x1ok) { const f32x4 v = b[((long long)y0 * W + x0 + 1) * C4]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
+    if (y1ok) {
+        const f32x4 v = b[((long long)(y0 + 1) * W + x0) * C4]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        if (x1ok) { const f32x4 u = b[((long long)(y0 + 1) * W + x0 + 1) * C4]; m.x = fmaxf(m.x, u.x); m.y = fmaxf(m.y, u.y); m.z = fmaxf(m.z, u.z); m.w = fmaxf(m.w, u.w); }
+    }
+    reinterpret_cast<f32x4 *>(out)[idx] = m;
+}
+
+hipError_t launch_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, hipStream_t stream)
+{
+    if (C & 3) return hipErrorInvalidValue;
+    const int oh = (H + 1) / 2, ow = (W + 1) / 2;
+    const long long total = (long long)B * oh * ow * (C / 4);
+    maxpool2x2_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(x, B, H, W, C / 4, out, oh, ow);
+    return hipGetLastError();
+}
+
+// NLDF.py:29: input * 255 - VGG_MEAN (per channel)
+struct Mean4 { float m[4]; };
+__global__ __launch_bounds__(256) void scale_shift_kernel(const float *__restrict__ x, long long n, int C, float scale, Mean4 mean,
+                                                          float *__restrict__ out)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % C);
+    out[idx] = x[idx] * scale - mean.m[c];
+}
+
+hipError_t launch_scale_shift(const float *x, long long npix, int C, float scale, const float *mean4, float *out, hipStream_t stream)
+{
+    if (C < 1 || C > 4) return hipErrorInvalidValue;
+    Mean4 m{};
+    for (int c = 0; c < C; ++c) m.m[c] = mean4[c];
+    const long long n = npix * C;
+    scale_shift_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(x, n, C, scale, m, out);
+    return hipGetLastError();
+}
+
 // get_pixel_value (main:44-68): out[b,h,w,:] = img[b, y[b,h,w], x[b,h,w], :]
 __global__ __launch_bounds__(256) void get_pixel_value_kernel(const float *__restrict__ img, const int32_t *__restrict__ x,
                                                               const int32_t *__restrict__ y, float *__restrict__ out,

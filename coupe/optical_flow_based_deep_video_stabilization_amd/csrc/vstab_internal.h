@@ -47,7 +47,7 @@ struct ConvParams {
     int s_in, s_out;
     int Ho, Wo, Cs_out, c_off;
     int N, Npad;
-    int act;                // 1 = leaky relu 0.1
+    int act;                // 0 = none, 1 = leaky relu 0.1 (max(v, 0.1 v)), 2 = relu
     int nphase, ksplit, Mmax;
     ConvPhase ph[4];
 };
@@ -116,6 +116,11 @@ hipError_t launch_resize_bilinear(const float *x, int B, int h, int w, int C, fl
                                   int ow, hipStream_t stream);
 hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W,
                             int C, hipStream_t stream);
+// 2x2 stride-2 SAME max pool (vgg16.py:51-53), NHWC, C % 4 == 0
+hipError_t launch_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, hipStream_t stream);
+// y = x * scale - mean[c]  (NLDF.py:29 preprocessing), C <= 4
+hipError_t launch_scale_shift(const float *x, long long npix, int C, float scale, const float *mean4, float *out,
+                              hipStream_t stream);
 hipError_t launch_get_pixel_value(const float *img, const int32_t *x, const int32_t *y, float *out,
                                   int B, int H, int W, int C, int Hi, int Wi, hipStream_t stream);
 

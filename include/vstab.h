@@ -156,6 +156,26 @@ VSTAB_API int vstab_homography_warp(const float *img, int B, int Hi, int Wi, int
  * Taylor matrix exponential with `warp_approx` terms. */
 VSTAB_API int vstab_vec2mtrx(const float *p, int B, int dim, int warp_approx, float *out, void *stream);
 
+/* ---- VGG16 convolutional trunk (vgg16.py:25-64; BASELINE config 5) ------------------------------
+ * 13 x (conv 3x3 SAME + bias + ReLU) and 5 x (max pool 2x2 stride 2 SAME).  Weights in the layout of
+ * vgg16.npy: for every layer L in conv1_1 .. conv5_3 a tensor "L/filter" [3][3][Cin][Cout] and
+ * "L/biases" [Cout] (HOST pointers).  The input is whatever the caller feeds vgg.build -- NLDF.py:29
+ * feeds x*255 - VGG_MEAN, see vstab_scale_shift. */
+VSTAB_API int vstab_vgg16_load(vstab_ctx *ctx, const vstab_tensor *tensors, int count);
+VSTAB_API size_t vstab_vgg16_workspace_bytes(int B, int H, int W);
+/* Shapes of the 18 outputs in build() order (conv1_1, conv1_2, pool1, conv2_1, conv2_2, pool2, conv3_1,
+ * conv3_2, conv3_3, pool3, conv4_1..3, pool4, conv5_1..3, pool5): hwc54[3*i..3*i+2] = (h, w, c). */
+VSTAB_API int vstab_vgg16_shapes(int H, int W, int32_t *hwc54);
+/* input [B,H,W,3] -> outputs[18] (device pointers, caller-allocated, NHWC, shapes as above).  Batches whose
+ * conv1 activations would reach 2 GiB are processed in chunks. */
+VSTAB_API int vstab_vgg16_forward(vstab_ctx *ctx, const float *input, int B, int H, int W, float *const *outputs18,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+/* out = x * scale - mean[c]  (NLDF.py:29: input_holder * 255. - vgg16.VGG_MEAN), x [npix, C], C <= 4, mean HOST. */
+VSTAB_API int vstab_scale_shift(const float *x, long long npix, int C, float scale, const float *mean, float *out,
+                                void *stream);
+/* tf.nn.max_pool(ksize 2, strides 2, SAME) on NHWC, C % 4 == 0 (vgg16.py:51-53). */
+VSTAB_API int vstab_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, void *stream);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU tests) --------------------- */
 /* Level sizes of the encoder for an HxW input: hw[2*i], hw[2*i+1] = (h, w) of stage i
  * (10 stages).  Returns 0 or VSTAB_E_SHAPE. */

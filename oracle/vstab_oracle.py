@@ -406,3 +406,29 @@ def warp_transform_image(image, M, oh: int, ow: int, dtype=torch.float32):
     BL = gather(xfi, yci) * (1 - xr) * yr
     BR = gather(xci, yci) * xr * yr
     return UL + UR + BL + BR
+
+
+# --------------------------------------------------------------------------- VGG16 trunk
+VGG_LAYERS = (("conv1_1", "conv1_2"), ("conv2_1", "conv2_2"), ("conv3_1", "conv3_2", "conv3_3"),
+              ("conv4_1", "conv4_2", "conv4_3"), ("conv5_1", "conv5_2", "conv5_3"))
+
+
+def vgg16_build(x, data_dict, dtype=torch.float32):
+    """Vgg16.build (vgg16.py:25-48): conv 3x3 stride 1 SAME + bias + ReLU (:55-64), max pool 2x2
+    stride 2 SAME (:51-53; -inf padding on the high side for odd sizes).  Returns {name: NHWC tensor}."""
+    cur = _t(x, dtype).permute(0, 3, 1, 2)
+    out = {}
+    for bi, block in enumerate(VGG_LAYERS, 1):
+        for name in block:
+            W = _t(data_dict[name][0], dtype).permute(3, 2, 0, 1)
+            b = _t(data_dict[name][1], dtype)
+            cur = torch.relu(F.conv2d(cur, W, b, stride=1, padding=1))
+            out[name] = cur.permute(0, 2, 3, 1).contiguous()
+        cur = F.max_pool2d(cur, 2, 2, ceil_mode=True)
+        out[f"pool{bi}"] = cur.permute(0, 2, 3, 1).contiguous()
+    return out
+
+
+def vgg_preprocess(x, dtype=torch.float32):
+    """NLDF.py:29: input * 255. - VGG_MEAN (vgg16.py:7)."""
+    return _t(x, dtype) * 255.0 - torch.tensor([103.939, 116.779, 123.68], dtype=dtype)

@@ -1,0 +1,52 @@
+"""GPU parity of the VGG16 trunk drop-in (BASELINE config 5) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from coupe.optical_flow_based_deep_video_stabilization_amd import vgg16 as vvgg
+from oracle import vstab_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 45, 70), (3, 64, 96)])
+def test_vgg16_every_output_vs_oracle(B, H, W):
+    dd = vvgg.synthetic_data_dict(seed=3)
+    x = torch.rand(B, H, W, 3, generator=torch.Generator().manual_seed(H))
+    pre = vvgg.preprocess(x.cuda())
+    assert float((pre.cpu() - vo.vgg_preprocess(x)).abs().max()) <= 1e-4
+    net = vvgg.Vgg16(data_dict=dd).build(pre)
+    ref = vo.vgg16_build(vo.vgg_preprocess(x, torch.float64), dd, torch.float64)
+    for name in vvgg.OUTPUTS:
+        got, r = getattr(net, name), ref[name]
+        assert tuple(got.shape) == tuple(r.shape), name
+        err = float((got.double().cpu() - r).abs().max())
+        assert err <= 2e-4 * max(1.0, float(r.abs().max())), (name, err, float(r.abs().max()))
+    assert net.pool5.shape == (B, -(-H // 32), -(-W // 32), 512)
+
+
+def test_maxpool_same_on_odd_sizes():
+    x = torch.randn(1, 5, 7, 8)
+    dd = vvgg.synthetic_data_dict(seed=1)
+    from coupe.optical_flow_based_deep_video_stabilization_amd import _lib, runtime
+    out = torch.empty(1, 3, 4, 8, device="cuda")
+    _lib.check(_lib.lib().vstab_maxpool2x2(x.cuda().data_ptr(), 1, 5, 7, 8, out.data_ptr(), runtime.stream_ptr()))
+    ref = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_vgg16_one_1080p_sample_is_finite_and_chunk_consistent():
+    # config-5 resolution; conv1 activations of 2 samples are 1.06 GB each -> chunks of 3
+    dd = vvgg.synthetic_data_dict(seed=4)
+    x = torch.rand(1, 1080, 1920, 3, device="cuda").expand(4, -1, -1, -1).contiguous()
+    net = vvgg.Vgg16(data_dict=dd).build(vvgg.preprocess(x))
+    assert net.pool5.shape == (4, 34, 60, 512) and torch.isfinite(net.pool5).all()
+    assert torch.equal(net.pool5[0], net.pool5[3]) and torch.equal(net.conv3_3[1], net.conv3_3[2])
+
+
+def test_vgg_errors():
+    with pytest.raises(ValueError):
+        vvgg.Vgg16(seed=1).build(torch.zeros(1, 8, 8, 4, device="cuda"))
+    bad = vvgg.synthetic_data_dict(1); bad.pop("conv4_2")
+    with pytest.raises(KeyError):
+        vvgg.Vgg16(data_dict=bad).build(torch.zeros(1, 8, 8, 3, device="cuda"))
