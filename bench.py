@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of warped frames (N>1)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--vgg16", action="store_true",
+                    help="BASELINE config 5: also run the VGG16 trunk (preprocess + 13 conv + 5 pool) on the warped frames")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,7 +104,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("VSTAB_FORCE_DIST") == "1"      # rehearse the RCCL path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -119,11 +122,18 @@ def main():
     ctx = runtime.get_context()
 
     gather = None
-    if world > 1 and not args.no_gather:
+    if (world > 1 or force_dist) and not args.no_gather:
         gather = vdist.FrameGatherer((B, H, W, 3), world, torch.device("cuda", local_rank))
+
+    vgg = None
+    if args.vgg16:
+        from coupe.optical_flow_based_deep_video_stabilization_amd import vgg16 as vvgg
+        vgg = vvgg.Vgg16(seed=7, reuse_outputs=True)
 
     def step():
         flows, outflow, warped = vs.stabilise_originalsize(feats, frame)
+        if vgg is not None:
+            vgg.build(vvgg.preprocess(warped))
         if gather is not None:
             gather.submit(warped)
         return flows, outflow, warped
@@ -215,7 +225,7 @@ def main():
                                f"(5 flows) + flow resize/scale + tf_warp at {H}x{W}",
                    "batch_per_gpu": B, "height": H, "width": W, "cin": Cin,
                    "gflop_per_sample": round(netspec.gflop_per_sample(H, W, Cin), 2),
-                   "all_gather": bool(gather is not None)},
+                   "all_gather": bool(gather is not None), "vgg16_trunk": bool(args.vgg16)},
         "roofline": roofline,
     }
     if rank == 0:

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for a in 0 7; do
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d gpurun_out/clk_$a -- ./tools/conv_bench_abl$a 2 8 512 512 -1 -1 20 > gpurun_out/clk_$a.log 2>&1
-done
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/vggprof -- python3 bench.py --batch 2 --height 1080 --width 1920 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --vgg16 > gpurun_out/vggprof.log 2>&1
+find gpurun_out/vggprof -name '*kernel_stats.csv' | xargs head -12
