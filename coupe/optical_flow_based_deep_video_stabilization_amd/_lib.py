@@ -47,6 +47,9 @@ EXPORTS = {
     "vstab_vgg16_forward": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p]),
     "vstab_scale_shift": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_float, c_float_p, C.c_void_p, C.c_void_p]),
     "vstab_maxpool2x2": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
+    "vstab_nldf_load": (C.c_int, [C.c_void_p, C.POINTER(VstabTensor), C.c_int]),
+    "vstab_nldf_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "vstab_nldf_forward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
     "vstab_level_sizes": (C.c_int, [C.c_int, C.c_int, c_int32_p]),
     "vstab_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_profile_reset": (C.c_int, [C.c_void_p]),

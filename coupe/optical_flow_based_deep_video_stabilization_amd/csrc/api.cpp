@@ -1,47 +1,15 @@
 // C ABI of libvstab_hip.so (include/vstab.h): context, weight packing/upload, the
 // FlowNetS-pyramid forward schedule (model.py:786-893) and the glue/warp entry points.
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
 #include <map>
-#include <string>
-#include <vector>
 
-#include "../../../include/vstab.h"
-#include "vstab_internal.h"
+#include "api_internal.h"
 
 using namespace vstab;
 
 // ------------------------------------------------------------------------- errors
 static thread_local std::string g_last_error;
 
-struct vstab_ctx {
-    int device = 0;
-    bool loaded = false;
-    int cin = 0;
-    std::string err;
-    float *dev_weights = nullptr;        // one allocation holding every packed tensor
-    size_t dev_weight_floats = 0;
-    // float offsets into dev_weights
-    size_t enc_w[10], enc_b[10];
-    size_t enc0_rw = 0;                  // layer-1 weights in the row-window layout (conv_rowwin.hip)
-    size_t dec_w[4], dec_b[4];
-    size_t pred_w[4], pred_b[4];         // predict6,5,4,3
-    size_t tab_w, tab_b, pred2_b;        // predict2 tap table (bias of the table = 0)
-    UpflowW up[4];
-    // profiling (vstab_profile_*): event pairs per conv-like launch, one row per forward
-    bool prof = false;
-    std::vector<hipEvent_t> prof_ev;     // [forward][15][2]
-    int prof_forwards = 0;
-    double prof_flops[15] = {0};
-    std::string prof_kernel[15];         // kernel instantiation each slot launched last
-    // VGG16 trunk (vstab_vgg16_*)
-    bool vgg_loaded = false;
-    float *vgg_weights = nullptr;
-    size_t vgg_w[13], vgg_b[13];
-};
-
-static int fail(vstab_ctx *ctx, int code, const char *fmt, ...)
+int fail(vstab_ctx *ctx, int code, const char *fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -52,12 +20,6 @@ static int fail(vstab_ctx *ctx, int code, const char *fmt, ...)
     if (ctx) ctx->err = buf;
     return code;
 }
-#define HIP_TRY(ctx, expr)                                                                  \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess) return fail(ctx, VSTAB_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
 // ------------------------------------------------------------------------- net spec
 namespace {
 
@@ -78,9 +40,9 @@ const int PRED_CIN[4] = {1024, 1026, 770, 386};             // predict6,5,4,3
 const int PRED_CS[4] = {1024, 1028, 772, 388};
 
 enum Buf { B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV4, B_CONCAT4, B_CONV5, B_CONCAT5, B_CONV6, B_CONV6_1, B_T,
-           B_PARTIAL, N_BUF };
+           B_T6, B_T5, B_T4, B_T3, B_PARTIAL, N_BUF };
 const char *BUF_NAME[N_BUF] = {"conv1", "concat2", "conv3", "concat3", "conv4", "concat4", "conv5", "concat5",
-                               "conv6", "conv6_1", "pf2_taps", "splitk"};
+                               "conv6", "conv6_1", "pf2_taps", "pf6_taps", "pf5_taps", "pf4_taps", "pf3_taps", "splitk"};
 
 // where each encoder stage reads and writes: {in buf (-1 = feats), out buf, out stride, used in channels, in stride}
 struct EncIO { int in_buf, out_buf, cs_out, cs_in; };
@@ -97,10 +59,10 @@ struct Plan {
     size_t bytes[N_BUF];
     int buf_h[N_BUF], buf_w[N_BUF], buf_c[N_BUF], buf_cs[N_BUF];
     size_t total;
-    // conv-like launches: 10 encoder, 4 deconv, 1 tap table
-    ConvParams cp[15];
-    ConvTile tile[15];
-    bool vec4[15];
+    // conv-like launches: 10 encoder, 4 deconv, predict2 tap table, predict6..3 tap tables
+    ConvParams cp[19];
+    ConvTile tile[19];
+    bool vec4[19];
 };
 
 bool level_sizes(int H, int W, int *eh, int *ew)
@@ -119,7 +81,9 @@ bool level_sizes(int H, int W, int *eh, int *ew)
     return H >= 3 && W >= 3;
 }
 
-void choose_split(ConvParams &p, int BN, int BM = 128)
+}  // namespace
+
+void choose_split(ConvParams &p, int BN, int BM)
 {
     const int KT = p.KH * p.NSEG * (p.SEGP / 32);
     const long long tiles = (long long)((p.Mmax + BM - 1) / BM) * (p.Npad / BN) * p.nphase;
@@ -135,6 +99,7 @@ void choose_split(ConvParams &p, int BN, int BM = 128)
     p.ksplit = ks;
 }
 
+namespace {
 KLayout enc_layout(int i, int cin_first)
 {
     const Enc &e = ENC[i];
@@ -143,6 +108,8 @@ KLayout enc_layout(int i, int cin_first)
     if (cs_in == cin) return klayout_run(e.k, e.k, cs_in);
     return klayout_tap(e.k, e.k, cin, cs_in);
 }
+
+}  // namespace
 
 void set_layout(ConvParams &p, const KLayout &L)
 {
@@ -156,6 +123,7 @@ void set_ranges(ConvParams &p)
     p.w_bytes = (unsigned)std::min<long long>((long long)p.KH * p.NSEG * (p.SEGP / 32) * p.Npad * 128, 0xFFFFFFFFLL);
 }
 
+namespace {
 bool make_plan(int B, int H, int W, int Cin, Plan &pl)
 {
     if (B < 1 || Cin < 1 || Cin > 4096) return false;
@@ -179,6 +147,10 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
     setbuf(B_CONV6, pl.eh[8], pl.ew[8], 1024, 1024);
     setbuf(B_CONV6_1, pl.eh[9], pl.ew[9], 1024, 1024);
     setbuf(B_T, pl.eh[1], pl.ew[1], 32, 32);
+    setbuf(B_T6, pl.eh[9], pl.ew[9], 32, 32);
+    setbuf(B_T5, pl.eh[7], pl.ew[7], 32, 32);
+    setbuf(B_T4, pl.eh[5], pl.ew[5], 32, 32);
+    setbuf(B_T3, pl.eh[3], pl.ew[3], 32, 32);
     setbuf(B_PARTIAL, 0, 0, 0, 0);
     for (int b = 0; b < N_BUF; ++b) {
         const long long n = (long long)B * pl.buf_h[b] * pl.buf_w[b] * pl.buf_cs[b];
@@ -257,6 +229,25 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         pl.tile[14] = TILE_128x32; pl.vec4[14] = true;
         set_ranges(p);
     }
+    // ---- predict6..3 tap tables: 1x1 conv of the level's (concat) tensor -> 18 (pad 32) columns
+    {
+        const int src[4] = {B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3}, dst[4] = {B_T6, B_T5, B_T4, B_T3};
+        for (int l = 0; l < 4; ++l) {
+            ConvParams &p = pl.cp[15 + l];
+            std::memset(&p, 0, sizeof p);
+            p.B = B; p.Hi = pl.buf_h[src[l]]; p.Wi = pl.buf_w[src[l]]; p.Cs_in = pl.buf_cs[src[l]];
+            set_layout(p, klayout_run(1, 1, p.Cs_in));
+            p.s_in = 1; p.s_out = 1;
+            p.Ho = p.Hi; p.Wo = p.Wi; p.Cs_out = 32; p.c_off = 0;
+            p.N = 32; p.Npad = 32; p.act = 0; p.nphase = 1;
+            p.ph[0].Hg = p.Hi; p.ph[0].Wg = p.Wi; p.ph[0].M = B * p.Hi * p.Wi; p.Mmax = p.ph[0].M;
+            pl.tile[15 + l] = TILE_128x32; pl.vec4[15 + l] = true;
+            set_ranges(p);
+            choose_split(p, 32);
+            if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
+            (void)dst;
+        }
+    }
     pl.bytes[B_PARTIAL] = partial_floats * 4;
     size_t off = 0;
     for (int b = 0; b < N_BUF; ++b) {
@@ -266,6 +257,8 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
     pl.total = off;
     return true;
 }
+
+}  // namespace
 
 const vstab_tensor *find(const vstab_tensor *t, int n, const std::string &name)
 {
@@ -283,7 +276,6 @@ bool shape_is(const vstab_tensor *t, std::initializer_list<int> s)
     return t->data != nullptr;
 }
 
-}  // namespace
 
 // ------------------------------------------------------------------------- context
 extern "C" const char *vstab_version(void) { return "vstab-hip 0.1 (gfx950)"; }
@@ -313,6 +305,7 @@ extern "C" void vstab_destroy(vstab_ctx *ctx)
     if (ctx->dev_weights) (void)hipFree(ctx->dev_weights);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->vgg_weights) (void)hipFree(ctx->vgg_weights);
+    vstab_nldf_free(ctx->nldf);
     delete ctx;
 }
 
@@ -354,15 +347,15 @@ extern "C" int vstab_workspace_layout(int B, int H, int W, int Cin, vstab_ws_ent
 }
 
 // ------------------------------------------------------------------------- host-only helpers
-static const int LAYER_IN[15] = {-1, B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV4, B_CONCAT4, B_CONV5, B_CONCAT5, B_CONV6,
-                                 B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2};
-static const int LAYER_OUT[15] = {B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV4, B_CONCAT4, B_CONV5, B_CONCAT5, B_CONV6,
-                                  B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2, B_T};
+static const int LAYER_IN[19] = {-1, B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV4, B_CONCAT4, B_CONV5, B_CONCAT5, B_CONV6,
+                                 B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2, B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3};
+static const int LAYER_OUT[19] = {B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV4, B_CONCAT4, B_CONV5, B_CONCAT5, B_CONV6,
+                                  B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2, B_T, B_T6, B_T5, B_T4, B_T3};
 
 extern "C" int vstab_host_layer_plan(int B, int H, int W, int Cin, int layer, int32_t *out, int cap)
 {
     Plan pl;
-    if (!out || layer < 0 || layer > 14 || !make_plan(B, H, W, Cin, pl))
+    if (!out || layer < 0 || layer > 18 || !make_plan(B, H, W, Cin, pl))
         return fail(nullptr, VSTAB_E_SHAPE, "layer_plan: bad arguments");
     const ConvParams &p = pl.cp[layer];
     const int need = 26 + 7 * p.nphase;
@@ -382,7 +375,7 @@ extern "C" int vstab_host_layer_plan(int B, int H, int W, int Cin, int layer, in
 extern "C" long long vstab_host_pack_layer(int Cin, int layer, const float *W, const double *scale, float *wpk,
                                            long long cap)
 {
-    if (!W || !wpk || layer < 0 || layer > 14 || Cin < 1) return fail(nullptr, VSTAB_E_SHAPE, "pack_layer: bad arguments");
+    if (!W || !wpk || layer < 0 || layer > 18 || Cin < 1) return fail(nullptr, VSTAB_E_SHAPE, "pack_layer: bad arguments");
     std::vector<double> ones;
     if (layer < 10) {
         const Enc &e = ENC[layer];
@@ -403,9 +396,10 @@ extern "C" long long vstab_host_pack_layer(int Cin, int layer, const float *W, c
         pack_deconv(W, scale, DEC_CIN[l], DEC_CS_IN[l], co, npad, wpk);
         return n;
     }
-    const long long n = (long long)klayout_run(1, 1, 196).ktiles() * 32 * 32;
+    const int tcin = layer == 14 ? 194 : PRED_CIN[layer - 15], tcs = layer == 14 ? 196 : PRED_CS[layer - 15];
+    const long long n = (long long)klayout_run(1, 1, tcs).ktiles() * 32 * 32;
     if (cap < n) return fail(nullptr, VSTAB_E_NOMEM, "pack_layer: need %lld floats", n);
-    pack_predict2_table(W, 194, 196, 32, wpk);
+    pack_predict2_table(W, tcin, tcs, 32, wpk);
     return n;
 }
 
@@ -481,8 +475,8 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
         const std::string n = PRED_NAME[l];
         NEED(W, n + "/W_conv2d", 3, 3, PRED_CIN[l], 2)
         NEED(b, n + "/b_conv2d", 2)
-        ctx->pred_w[l] = reserve((size_t)18 * PRED_CS[l]);
-        pack_predict(W->data, PRED_CIN[l], PRED_CS[l], host.data() + ctx->pred_w[l]);
+        ctx->pred_w[l] = reserve((size_t)klayout_run(1, 1, PRED_CS[l]).ktiles() * 32 * 32);
+        pack_predict2_table(W->data, PRED_CIN[l], PRED_CS[l], 32, host.data() + ctx->pred_w[l]);
         ctx->pred_b[l] = reserve(4);
         host[ctx->pred_b[l]] = b->data[0]; host[ctx->pred_b[l] + 1] = b->data[1];
     }
@@ -625,8 +619,16 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
     float *pfs[5] = {pf6, pf5, pf4, pf3, pf2};
     const int cat_buf[4] = {B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2};
     const int lvl_enc[5] = {9, 7, 5, 3, 1};              // encoder stage giving each level's size
-    HIP_TRY(ctx, launch_predict_flow(buf(B_CONV6_1), B, pl.eh[9], pl.ew[9], 1024, dw + ctx->pred_w[0], dw + ctx->pred_b[0],
-                                     nullptr, 0, 0, pf6, stream));
+    const int tab_src[4] = {B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3}, tab_dst[4] = {B_T6, B_T5, B_T4, B_T3};
+    auto predict_head = [&](int l, const float *prev, int ph_, int pw_, float *out) -> int {     // l: 0 = predict6 .. 3 = predict3
+        ConvParams p = pl.cp[15 + l];
+        p.in = buf(tab_src[l]); p.out = buf(tab_dst[l]);
+        p.wpk = dw + ctx->pred_w[l]; p.bias = dw + ctx->tab_b; p.partial = buf(B_PARTIAL);
+        HIP_TRY(ctx, launch_conv(p, pl.tile[15 + l], true, stream));
+        HIP_TRY(ctx, launch_predict_gather(buf(tab_dst[l]), B, p.Hi, p.Wi, dw + ctx->pred_b[l], prev, ph_, pw_, out, stream));
+        return VSTAB_OK;
+    };
+    { const int rc = predict_head(0, nullptr, 0, 0, pf6); if (rc != VSTAB_OK) return rc; }
     for (int l = 0; l < 4; ++l) {
         ConvParams p = pl.cp[10 + l];
         const int ib = l == 0 ? B_CONV6_1 : cat_buf[l - 1];
@@ -640,9 +642,8 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         const int ph = pl.eh[lvl_enc[l]], pw = pl.ew[lvl_enc[l]];          // coarser level
         const int h = pl.eh[lvl_enc[l + 1]], w = pl.ew[lvl_enc[l + 1]];    // this level
         HIP_TRY(ctx, launch_upflow(pfs[l], B, ph, pw, ctx->up[l], buf(cat_buf[l]), h, w, CONCAT_CS[l], CONCAT_C[l] - 2, stream));
-        if (l < 3)
-            HIP_TRY(ctx, launch_predict_flow(buf(cat_buf[l]), B, h, w, CONCAT_CS[l], dw + ctx->pred_w[l + 1],
-                                             dw + ctx->pred_b[l + 1], pfs[l], ph, pw, pfs[l + 1], stream));
+        if (l < 3) { const int rc = predict_head(l + 1, pfs[l], ph, pw, pfs[l + 1]); if (rc != VSTAB_OK) return rc; }
+        (void)h; (void)w;
     }
     // full-resolution head (model.py:882-887)
     {
@@ -794,30 +795,33 @@ const VggLayer VGG[13] = {{"conv1_1", 3, 64, false},   {"conv1_2", 64, 64, true}
                           {"conv4_3", 512, 512, true}, {"conv5_1", 512, 512, false}, {"conv5_2", 512, 512, false},
                           {"conv5_3", 512, 512, true}};
 
-// plain conv (k x k, stride, zero pad) on an NHWC tensor with cs_in == cin
-bool fill_plain_conv(ConvParams &p, ConvTile &tile, bool &vec4, int B, int Hi, int Wi, int cin, int k, int stride, int pad,
-                     int cout, int cs_out, int c_off, int act)
+}  // namespace
+
+bool fill_plain_conv(ConvParams &p, ConvTile &tile, bool &vec4, int B, int Hi, int Wi, int cin, int cs_in, int k, int stride,
+                     int pad, int cout, int cs_out, int c_off, int act)
 {
     std::memset(&p, 0, sizeof p);
     const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
-    if (Ho < 1 || Wo < 1) return false;
-    p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cs_in = cin;
-    set_layout(p, klayout_run(k, k, cin));
+    if (Ho < 1 || Wo < 1 || cs_in < cin) return false;
+    p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cs_in = cs_in;
+    set_layout(p, cs_in == cin ? klayout_run(k, k, cs_in) : klayout_tap(k, k, cin, cs_in));
     p.s_in = stride; p.s_out = 1; p.Ho = Ho; p.Wo = Wo; p.Cs_out = cs_out; p.c_off = c_off;
     p.N = cout;
-    const int BN = cout >= 128 ? 128 : 64;
-    tile = cout >= 128 ? TILE_128x128 : TILE_128x64;
+    const int BN = cout >= 128 ? 128 : (cout > 32 ? 64 : 32);
+    tile = cout >= 128 ? TILE_128x128 : (cout > 32 ? TILE_128x64 : TILE_128x32);
     p.Npad = round_up(cout, BN);
     p.act = act; p.nphase = 1;
     p.ph[0].Hg = Ho; p.ph[0].Wg = Wo; p.ph[0].M = B * Ho * Wo; p.ph[0].off_y = -pad; p.ph[0].off_x = -pad;
     p.Mmax = p.ph[0].M;
-    vec4 = (cin % 4 == 0);
-    if ((long long)B * Hi * Wi * cin * 4 >= 0x80000000LL || (long long)B * Ho * Wo * cs_out * 4 >= 0x80000000LL) return false;
+    vec4 = (cs_in % 4 == 0) && (p.SEG % 4 == 0);
+    if (!vec4 && tile != TILE_128x64) return false;        // the dword-gather variant exists for 128x64 only
+    if ((long long)B * Hi * Wi * cs_in * 4 >= 0x80000000LL || (long long)B * Ho * Wo * cs_out * 4 >= 0x80000000LL) return false;
     set_ranges(p);
     choose_split(p, BN);
     return true;
 }
 
+namespace {
 struct VggPlan { int h[18], w[18], c[18]; size_t partial_floats; };
 
 bool vgg_plan(int B, int H, int W, VggPlan &v)
@@ -827,7 +831,7 @@ bool vgg_plan(int B, int H, int W, VggPlan &v)
     v.partial_floats = 0;
     for (int l = 0; l < 13; ++l) {
         ConvParams p; ConvTile t; bool vec;
-        if (!fill_plain_conv(p, t, vec, B, h, w, VGG[l].cin, 3, 1, 1, VGG[l].cout, VGG[l].cout, 0, 2)) return false;
+        if (!fill_plain_conv(p, t, vec, B, h, w, VGG[l].cin, VGG[l].cin, 3, 1, 1, VGG[l].cout, VGG[l].cout, 0, 2)) return false;
         if (p.ksplit > 1) v.partial_floats = std::max(v.partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
         v.h[o] = h; v.w[o] = w; v.c[o] = VGG[l].cout; ++o;
         if (VGG[l].pool_after) {
@@ -918,7 +922,7 @@ extern "C" int vstab_vgg16_forward(vstab_ctx *ctx, const float *input, int B, in
         int h = H, w = W, o = 0;
         for (int l = 0; l < 13; ++l) {
             ConvParams p; ConvTile tile; bool vec;
-            if (!fill_plain_conv(p, tile, vec, bc, h, w, VGG[l].cin, 3, 1, 1, VGG[l].cout, VGG[l].cout, 0, 2))
+            if (!fill_plain_conv(p, tile, vec, bc, h, w, VGG[l].cin, VGG[l].cin, 3, 1, 1, VGG[l].cout, VGG[l].cout, 0, 2))
                 return fail(ctx, VSTAB_E_SHAPE, "vgg16_forward: layer %s does not fit", VGG[l].name);
             float *dst = outs[o] + (size_t)b0 * v.h[o] * v.w[o] * v.c[o];
             p.in = cur; p.out = dst; p.wpk = ctx->vgg_weights + ctx->vgg_w[l]; p.bias = ctx->vgg_weights + ctx->vgg_b[l];

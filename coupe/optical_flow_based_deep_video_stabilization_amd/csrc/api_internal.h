@@ -1,0 +1,60 @@
+// Shared between the translation units that implement the C ABI (api.cpp, nldf_api.cpp): the
+// context object, error plumbing and the helpers that turn a plain convolution into a launch plan.
+#pragma once
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <initializer_list>
+#include <string>
+#include <vector>
+
+#include "../../../include/vstab.h"
+#include "vstab_internal.h"
+
+struct vstab_ctx {
+    int device = 0;
+    bool loaded = false;
+    int cin = 0;
+    std::string err;
+    float *dev_weights = nullptr;        // one allocation holding every packed tensor
+    size_t dev_weight_floats = 0;
+    // float offsets into dev_weights
+    size_t enc_w[10], enc_b[10];
+    size_t enc0_rw = 0;                  // layer-1 weights in the row-window layout (conv_rowwin.hip)
+    size_t dec_w[4], dec_b[4];
+    size_t pred_w[4], pred_b[4];         // predict6,5,4,3
+    size_t tab_w, tab_b, pred2_b;        // predict2 tap table (bias of the table = 0)
+    vstab::UpflowW up[4];
+    // profiling (vstab_profile_*): event pairs per conv-like launch, one row per forward
+    bool prof = false;
+    std::vector<hipEvent_t> prof_ev;     // [forward][15][2]
+    int prof_forwards = 0;
+    double prof_flops[15] = {0};
+    std::string prof_kernel[15];         // kernel instantiation each slot launched last
+    // VGG16 trunk (vstab_vgg16_*)
+    void *nldf = nullptr;                // NLDF head state (nldf_api.cpp)
+    bool vgg_loaded = false;
+    float *vgg_weights = nullptr;
+    size_t vgg_w[13], vgg_b[13];
+};
+
+int fail(vstab_ctx *ctx, int code, const char *fmt, ...);
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail(ctx, VSTAB_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+
+void vstab_nldf_free(void *nldf);     // nldf_api.cpp
+
+// ---- helpers defined in api.cpp
+void choose_split(vstab::ConvParams &p, int BN, int BM = 128);
+void set_layout(vstab::ConvParams &p, const vstab::KLayout &L);
+void set_ranges(vstab::ConvParams &p);
+const vstab_tensor *find(const vstab_tensor *t, int n, const std::string &name);
+bool shape_is(const vstab_tensor *t, std::initializer_list<int> s);
+// plain conv (k x k, stride, zero pad) on an NHWC tensor whose pixel stride is cs_in >= cin (run mode
+// when cs_in == cin, tap mode otherwise); output slice [c_off, c_off+cout) of a cs_out-wide pixel
+bool fill_plain_conv(vstab::ConvParams &p, vstab::ConvTile &tile, bool &vec4, int B, int Hi, int Wi, int cin, int cs_in, int k,
+                     int stride, int pad, int cout, int cs_out, int c_off, int act);

@@ -43,67 +43,54 @@ __device__ __forceinline__ f32x2 sample_flow_legacy(const float *f, int n, int h
 }
 
 // ---------------------------------------------------------------------------------
-// predict_flowN: 3x3 pad-1 conv to 2 channels.  One wave per output pixel: lanes stride
-// over the channels with 16-byte loads, two running dot products, butterfly reduction
-// with wavefront shuffles; lane 0 adds bias and the doubled upsampled coarser flow
-// (ElementwiseLayer left fold, model.py:857: (conv + u) + u).
+// predict_flowN (model.py:848,856,865,874): 3x3 pad-1 conv to 2 channels (+bias), then the
+// ElementwiseLayer left fold (conv + u) + u with u = legacy-bilinear upsample of the coarser flow
+// (model.py:857).  N = 2 cannot feed a 32-wide MFMA tile directly, and a wave-per-pixel dot product
+// re-reads every input pixel nine times through L2; instead the MFMA kernel computes, once per
+// SOURCE pixel s, the tap table T[s][tap][o] = sum_c x[s][c] W[tap][c][o] (a 1x1 conv to 18
+// columns), and this kernel gathers out[y,x,o] = b[o] + sum_{dy,dx} T[(y+dy-1, x+dx-1)][3dy+dx][o]
+// over the in-image taps: the same sum in a different association.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void predict_flow_kernel(const float *__restrict__ in, int B, int h, int w, int Cs,
-                                                           const float *__restrict__ wp, const float *__restrict__ bias2,
-                                                           const float *__restrict__ prev, int ph, int pw,
-                                                           float sy, float sx, float *__restrict__ out)
+__global__ __launch_bounds__(256) void predict_gather_kernel(const float *__restrict__ T, int B, int h, int w,
+                                                             const float *__restrict__ bias2, const float *__restrict__ prev,
+                                                             int ph, int pw, float sy, float sx, float *__restrict__ out)
 {
-    const int lane = threadIdx.x & 63;
-    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)B * h * w;
-    if (pix >= total) return;                      // wave-uniform
-    const int n = (int)(pix / (h * w));
-    const int rem = (int)(pix - (long long)n * h * w);
+    if (idx >= total) return;
+    const int n = (int)(idx / (h * w));
+    const int rem = (int)(idx - (long long)n * h * w);
     const int y = rem / w, x = rem - y * w;
-    const int c4n = Cs >> 2;
-    float a0 = 0.f, a1 = 0.f;
-    for (int ty = 0; ty < 3; ++ty) {
-        const int iy = y + ty - 1;
-        if (iy < 0 || iy >= h) continue;
-        for (int tx = 0; tx < 3; ++tx) {
-            const int ix = x + tx - 1;
-            if (ix < 0 || ix >= w) continue;
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(in + ((long long)(n * h + iy) * w + ix) * Cs);
-            const f32x4 *w0 = reinterpret_cast<const f32x4 *>(wp + (long long)((ty * 3 + tx) * 2) * Cs);
-            const f32x4 *w1 = w0 + c4n;
-            for (int c = lane; c < c4n; c += 64) {
-                const f32x4 v = src[c], p = w0[c], q = w1[c];
-                a0 = fmaf(v.x, p.x, a0); a0 = fmaf(v.y, p.y, a0); a0 = fmaf(v.z, p.z, a0); a0 = fmaf(v.w, p.w, a0);
-                a1 = fmaf(v.x, q.x, a1); a1 = fmaf(v.y, q.y, a1); a1 = fmaf(v.z, q.z, a1); a1 = fmaf(v.w, q.w, a1);
-            }
-        }
-    }
+    float a0 = bias2[0], a1 = bias2[1];
+    const float *Tn = T + (long long)n * h * w * 32;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        a0 += __shfl_xor(a0, off, 64);
-        a1 += __shfl_xor(a1, off, 64);
-    }
-    if (lane == 0) {
-        float v0 = a0 + bias2[0], v1 = a1 + bias2[1];
-        if (prev) {
-            const f32x2 u = sample_flow_legacy(prev, n, ph, pw, y, x, sy, sx);
-            v0 = (v0 + u.x) + u.x;
-            v1 = (v1 + u.y) + u.y;
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = y + dy - 1;
+        if (iy < 0 || iy >= h) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = x + dx - 1;
+            if (ix < 0 || ix >= w) continue;
+            const f32x2 t = *reinterpret_cast<const f32x2 *>(Tn + ((long long)iy * w + ix) * 32 + (dy * 3 + dx) * 2);
+            a0 += t.x;
+            a1 += t.y;
         }
-        f32x2 o; o.x = v0; o.y = v1;
-        reinterpret_cast<f32x2 *>(out)[pix] = o;
     }
+    if (prev) {
+        const f32x2 u = sample_flow_legacy(prev, n, ph, pw, y, x, sy, sx);
+        a0 = (a0 + u.x) + u.x;
+        a1 = (a1 + u.y) + u.y;
+    }
+    f32x2 o; o.x = a0; o.y = a1;
+    reinterpret_cast<f32x2 *>(out)[idx] = o;
 }
 
-hipError_t launch_predict_flow(const float *in, int B, int h, int w, int Cs, const float *wp, const float *bias2,
-                               const float *prev, int ph, int pw, float *out, hipStream_t stream)
+hipError_t launch_predict_gather(const float *T, int B, int h, int w, const float *bias2, const float *prev, int ph, int pw,
+                                 float *out, hipStream_t stream)
 {
-    if (Cs & 3) return hipErrorInvalidValue;
     const long long total = (long long)B * h * w;
     const float sy = prev ? (float)ph / (float)h : 0.f, sx = prev ? (float)pw / (float)w : 0.f;
-    // when the coarser level already has this size TF returns it unchanged; scale 1 does that
-    predict_flow_kernel<<<dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream>>>(in, B, h, w, Cs, wp, bias2, prev,
-                                                                                   ph, pw, sy, sx, out);
+    predict_gather_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(T, B, h, w, bias2, prev, ph, pw, sy, sx, out);
     return hipGetLastError();
 }
 

@@ -110,12 +110,32 @@ void pack_deconv(const float *W, const double *scale, int cin, int cs_in, int co
         }
 }
 
-void pack_predict(const float *W, int cin, int cs_in, float *wp)
+void pack_deconv5(const float *W, const double *scale, int cin, int cs_in, int cout, int npad, float *wpk)
 {
-    std::memset(wp, 0, sizeof(float) * 18 * (size_t)cs_in);
-    for (int tap = 0; tap < 9; ++tap)
-        for (int ci = 0; ci < cin; ++ci)
-            for (int o = 0; o < 2; ++o) wp[((size_t)tap * 2 + o) * cs_in + ci] = W[((size_t)tap * cin + ci) * 2 + o];
+    const KLayout L = klayout_run(3, 3, cs_in);
+    const size_t phase_floats = (size_t)L.ktiles() * npad * 32;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            // oy = 2*iy + ky - 1, input row iy = j - 1 + t  <->  ky = (py ? 4 : 3) - 2t  (ky < 0: tap absent)
+            std::memset(wpk + (size_t)(py * 2 + px) * phase_floats, 0, sizeof(float) * phase_floats);
+            const int kps = L.SEGP / 32;
+            float *dst = wpk + (size_t)(py * 2 + px) * phase_floats;
+            for (int t = 0; t < 3; ++t) {
+                const int ky = (py ? 4 : 3) - 2 * t;
+                if (ky < 0) continue;
+                for (int bx = 0; bx < 3; ++bx) {
+                    const int kx = (px ? 4 : 3) - 2 * bx;
+                    if (kx < 0) continue;
+                    for (int ci = 0; ci < cin; ++ci) {
+                        const int q = bx * cs_in + ci;
+                        float *row = dst + ((size_t)t * kps + q / 32) * npad * 32;
+                        for (int n = 0; n < cout; ++n)
+                            row[(size_t)n * 32 + swz32(n, q & 31)] =
+                                (float)((double)W[(((size_t)ky * 5 + kx) * cout + n) * cin + ci] * scale[n]);
+                    }
+                }
+            }
+        }
 }
 
 void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wpk)

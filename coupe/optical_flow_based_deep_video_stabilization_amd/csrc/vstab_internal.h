@@ -93,11 +93,11 @@ void pack_conv_rowwin(const float *W, const double *scale, int kh, int kw, int c
 // ---------------------------------------------------------------------------------
 // Small VALU kernels of the flow pyramid and the warp.
 // ---------------------------------------------------------------------------------
-// predict_flowN = 3x3 pad-1 conv to 2 channels (+bias) [+ (.. + u) + u with
-// u = legacy-bilinear upsample of the coarser flow]; model.py:848,856-857,865-866,874-875
-hipError_t launch_predict_flow(const float *in, int B, int h, int w, int Cs, const float *wp,
-                               const float *bias2, const float *prev, int ph, int pw, float *out,
-                               hipStream_t stream);
+// predict_flowN from its tap table T[B,h,w,32] (T[.., tap*2 + o] = sum_c x[.., c] W[tap][c][o], computed by
+// the MFMA kernel as a 1x1 conv) + bias [+ (.. + u) + u, u = legacy-bilinear upsample of the coarser
+// flow]; model.py:848,856-857,865-866,874-875
+hipError_t launch_predict_gather(const float *T, int B, int h, int w, const float *bias2, const float *prev,
+                                 int ph, int pw, float *out, hipStream_t stream);
 
 // upsample_flowN = 4x4 s2 SAME transposed conv 2->2 + bias, written as (u, v, 0, 0) into
 // the last four floats of the concat pixel; model.py:852,861,870,879
@@ -136,6 +136,11 @@ hipError_t launch_homography_warp(const float *img, int B, int Hi, int Wi, int C
                                   int oh, int ow, hipStream_t stream);
 hipError_t launch_vec2mtrx(const float *p, int B, int dim, int approx, float *out, hipStream_t stream);
 
+// NLDF head helpers (nldf_ops.hip)
+hipError_t launch_contrast(float *buf, int B, int H, int W, int C, int Cs, int c_dst, hipStream_t stream);
+hipError_t launch_nldf_score(const float *local2, const float *global2, int B, int npix, float *score, float *prob,
+                             hipStream_t stream);
+
 // ---------------------------------------------------------------------------------
 // Host-side weight packing (pack.cpp): pure CPU code.
 // ---------------------------------------------------------------------------------
@@ -170,11 +175,12 @@ void pack_deconv(const float *W, const double *scale, int cin, int cs_in, int co
                  float *wpk);
 KLayout klayout_deconv(int cs_in);
 
-// predict conv W[3][3][Cin][2] -> [9][2][cs_in]
-void pack_predict(const float *W, int cin, int cs_in, float *wp);
+// 5x5 stride-2 SAME transposed conv W[5][5][Cout][Cin] (NLDF.py:57-64) -> 4 phase matrices of a 3-row-tap conv
+// in run mode (run = 3*cs_in); the even phases use 2 of the 3 taps (the third gets zero weights).
+void pack_deconv5(const float *W, const double *scale, int cin, int cs_in, int cout, int npad, float *wpk);
 
-// predict2 W[3][3][Cin][2] -> 1x1 conv (run mode over cs_in) with 18 (pad npad) output
-// columns, col = tap*2 + o
+// predict head W[3][3][Cin][2] -> tap-table weights: 1x1 conv (run mode over cs_in) with 18 (pad npad)
+// output columns, col = tap*2 + o
 void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wpk);
 
 }  // namespace vstab

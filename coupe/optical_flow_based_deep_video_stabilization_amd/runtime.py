@@ -117,8 +117,8 @@ class Context:
     def internals(self, B, H, W, Cin):
         """Views of the intermediate tensors in the workspace of the last forward (tests)."""
         ws = self.workspace(B, H, W, Cin)
-        ent = (_lib.VstabWsEntry * 16)()
-        n = _lib.lib().vstab_workspace_layout(B, H, W, Cin, ent, 16)
+        ent = (_lib.VstabWsEntry * 24)()
+        n = _lib.lib().vstab_workspace_layout(B, H, W, Cin, ent, 24)
         if n < 0:
             _lib.check(n)
         out = {}

@@ -176,13 +176,26 @@ VSTAB_API int vstab_scale_shift(const float *x, long long npix, int C, float sca
 /* tf.nn.max_pool(ksize 2, strides 2, SAME) on NHWC, C % 4 == 0 (vgg16.py:51-53). */
 VSTAB_API int vstab_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, void *stream);
 
+/* ---- NLDF saliency head (NLDF.py:24-101; tertiary, never instantiated by the reference) ----------
+ * Weights: "<L>/W", "<L>/b" for L in Fea_Global_1, Fea_Global_2, Fea_Global, Fea_P1..Fea_P5, Local_Fea,
+ * Local_Score, Global_Score (conv [k][k][Cin][Cout]) and Fea_P2_Deconv..Fea_P5_Deconv ([5][5][Cout][Cin]).
+ * pools5 = device pointers to the VGG16 pool1..pool5 of a 352x352 input (176/88/44/22/11, NHWC).
+ * prob [B,176,176,1] (required); score [B,176,176,2], local_fea [B,176,176,640], fea_global [B,1,1,128]
+ * optional (NULL to skip). */
+VSTAB_API int vstab_nldf_load(vstab_ctx *ctx, const vstab_tensor *tensors, int count);
+VSTAB_API size_t vstab_nldf_workspace_bytes(int B);
+VSTAB_API int vstab_nldf_forward(vstab_ctx *ctx, const float *const *pools5, int B, float *prob, float *score,
+                                 float *local_fea, float *fea_global, void *workspace, size_t workspace_bytes,
+                                 void *stream);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU tests) --------------------- */
 /* Level sizes of the encoder for an HxW input: hw[2*i], hw[2*i+1] = (h, w) of stage i
  * (10 stages).  Returns 0 or VSTAB_E_SHAPE. */
 VSTAB_API int vstab_level_sizes(int H, int W, int32_t *hw20);
 
 /* Host-side view of one conv-like launch of the forward schedule (layer 0-9 = encoder
- * stages 1..6_1, 10-13 = deconv5..2, 14 = predict2 tap table): writes 26 + 7*nphase ints
+ * stages 1..6_1, 10-13 = deconv5..2, 14 = predict2 tap table, 15-18 = predict6..3 tap tables):
+ * writes 26 + 7*nphase ints
  *   B Hi Wi Cs_in KH NSEG SEG SEGP SEG_STRIDE s_in s_out Ho Wo Cs_out c_off N Npad act
  *   nphase ksplit Mmax tile vec4 in_buf out_buf reserved, then per phase
  *   Hg Wg M off_y off_x o_y o_x

@@ -432,3 +432,41 @@ def vgg16_build(x, data_dict, dtype=torch.float32):
 def vgg_preprocess(x, dtype=torch.float32):
     """NLDF.py:29: input * 255. - VGG_MEAN (vgg16.py:7)."""
     return _t(x, dtype) * 255.0 - torch.tensor([103.939, 116.779, 123.68], dtype=dtype)
+
+
+# --------------------------------------------------------------------------- NLDF head (NLDF.py:24-101)
+def nldf_build_model(x, vgg_dict, hw, dtype=torch.float64):
+    """Model.build_model (NLDF.py:24-101) on a [B,352,352,3] input in [0,1].  `hw` = head variables
+    {'<layer>/W', '<layer>/b'}.  Returns dict with Prob, Score, Local_Fea, Fea_Global."""
+    v = vgg16_build(vgg_preprocess(x, dtype), vgg_dict, dtype)             # :29-31
+    W = {k: _t(a, dtype) for k, a in hw.items()}
+
+    def conv(t, name, pad):                                               # Conv_2d (:103-114)
+        w = W[name + "/W"].permute(3, 2, 0, 1)
+        return F.conv2d(t, w, W[name + "/b"], stride=1, padding=pad)
+
+    def deconv(t, name, out_hw):                                          # Deconv_2d 5x5 s2 SAME (:116-129)
+        w = W[name + "/W"].permute(3, 2, 0, 1)                           # [Cin, Cout, kh, kw]
+        y = F.conv_transpose2d(t, w, W[name + "/b"], stride=2, padding=1)
+        return y[:, :, :out_hw, :out_hw]
+
+    def contrast(t):                                                      # Contrast_Layer (:131-134)
+        return t - F.avg_pool2d(F.pad(t, (1, 1, 1, 1), mode="replicate"), 3, 1)
+
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    p1, p2, p3, p4, p5 = (nchw(v[f"pool{i}"]) for i in range(1, 6))
+    g1 = torch.relu(conv(p5, "Fea_Global_1", 0))
+    g2 = torch.relu(conv(g1, "Fea_Global_2", 0))
+    fg = conv(g2, "Fea_Global", 0)
+    fp = [torch.relu(conv(p, f"Fea_P{i}", 1)) for i, p in zip(range(1, 6), (p1, p2, p3, p4, p5))]
+    lc = [contrast(t) for t in fp]
+    up5 = torch.relu(deconv(torch.cat([fp[4], lc[4]], 1), "Fea_P5_Deconv", 22))
+    up4 = torch.relu(deconv(torch.cat([fp[3], lc[3], up5], 1), "Fea_P4_Deconv", 44))
+    up3 = torch.relu(deconv(torch.cat([fp[2], lc[2], up4], 1), "Fea_P3_Deconv", 88))
+    up2 = torch.relu(deconv(torch.cat([fp[1], lc[1], up3], 1), "Fea_P2_Deconv", 176))
+    lf = conv(torch.cat([fp[0], lc[0], up2], 1), "Local_Fea", 0)
+    ls = conv(lf, "Local_Score", 0)
+    gs = conv(fg, "Global_Score", 0)
+    score = (ls + gs).permute(0, 2, 3, 1)
+    prob = torch.softmax(score, dim=3)[..., 0:1]
+    return {"Prob": prob, "Score": score, "Local_Fea": lf.permute(0, 2, 3, 1), "Fea_Global": fg.permute(0, 2, 3, 1)}

@@ -128,9 +128,22 @@ def test_predict2_tap_table():
     assert np.abs(got[..., 18:32]).max() == 0
 
 
+@pytest.mark.parametrize("layer,cin,cs", [(15, 1024, 1024), (16, 1026, 1028), (17, 770, 772), (18, 386, 388)])
+def test_predict_head_tap_tables(layer, cin, cs):
+    p = layer_plan(1, 64, 64, 27, layer)
+    assert p["Cs_in"] == cs
+    rng = np.random.default_rng(layer)
+    inp = rng.standard_normal((1, p["Hi"], p["Wi"], cs))
+    Wt = rng.standard_normal((3, 3, cin, 2)).astype(np.float32)
+    got = emulate(inp, p, pack_layer(27, layer, Wt))
+    ref = np.einsum("bhwc,tco->bhwto", inp[..., :cin], Wt.reshape(9, cin, 2).astype(np.float64)).reshape(1, p["Hi"], p["Wi"], 18)
+    assert np.abs(got[..., :18] - ref).max() < 1e-9 * max(1, np.abs(ref).max())
+    assert np.abs(got[..., 18:32]).max() == 0
+
+
 def test_split_k_plan_is_consistent():
     for (B, H, W) in ((8, 512, 512), (1, 256, 256), (2, 720, 1280)):
-        for layer in range(15):
+        for layer in range(19):
             p = layer_plan(B, H, W, 27, layer)
             KT = p["KH"] * p["NSEG"] * p["SEGP"] // 32
             kts = -(-KT // p["ksplit"])
@@ -144,9 +157,9 @@ def test_split_k_plan_is_consistent():
 
 def test_workspace_layout_is_disjoint_and_aligned():
     L = _lib.lib()
-    ent = (_lib.VstabWsEntry * 16)()
-    n = L.vstab_workspace_layout(8, 512, 512, 27, ent, 16)
-    assert n == 12
+    ent = (_lib.VstabWsEntry * 24)()
+    n = L.vstab_workspace_layout(8, 512, 512, 27, ent, 24)
+    assert n == 16
     total = L.vstab_workspace_bytes(8, 512, 512, 27)
     spans = []
     for e in ent[:n]:
