@@ -50,6 +50,10 @@ EXPORTS = {
     "vstab_nldf_load": (C.c_int, [C.c_void_p, C.POINTER(VstabTensor), C.c_int]),
     "vstab_nldf_workspace_bytes": (C.c_size_t, [C.c_int]),
     "vstab_nldf_forward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
+    "vstab_resize_u8": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_assemble_input": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
+    "vstab_frame_to_float": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "vstab_quantise_output": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "vstab_level_sizes": (C.c_int, [C.c_int, C.c_int, c_int32_p]),
     "vstab_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_profile_reset": (C.c_int, [C.c_void_p]),

@@ -1,0 +1,97 @@
+"""Autoregressive clip driver: the per-frame loop of the reference's `evaluate_originalSize`
+(main:535-630, "main" = main_flownetS_pyramid_noprevloss_dataloader.py) with everything kept on the
+device.  Frame i's network input stacks the previously OUTPUT (stabilised) frames at lags
+31,23,15,7,4,3,2,1 (main:553), quantised through uint8 and resized to the network resolution with
+cv2.resize, plus the current unstable frame; the stabilised frame is the current frame warped by the
+predicted flow brought to output resolution.  Frames of one clip are therefore sequential; throughput
+comes from running several clips in lockstep (the batch dimension = clips).
+
+Frames are uint8 [n_clips, out_h, out_w, 3] CUDA tensors in cv2's BGR order, as `cap.read()` yields
+them (the reference's own COLOR_BGR2RGB/RGB2BGR juggling is reproduced, main:530,550,568,625)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib, runtime
+from .pipeline import stabilise_originalsize
+
+STAB_LAGS = (31, 23, 15, 7, 4, 3, 2, 1)          # stabidxs, main:553
+RING = 32
+
+
+def _u8(t, name):
+    if not torch.is_tensor(t) or not t.is_cuda or t.dtype != torch.uint8 or t.dim() != 4 or t.shape[3] != 3:
+        raise ValueError(f"{name} must be a uint8 CUDA tensor [n,H,W,3]")
+    return t.contiguous()
+
+
+def resize_u8(src: torch.Tensor, size_hw) -> torch.Tensor:
+    """cv2.resize(src, (w, h)) with INTER_LINEAR on uint8 frames [n,H,W,3]."""
+    src = _u8(src, "src")
+    n, sh, sw, _ = src.shape
+    dh, dw = int(size_hw[0]), int(size_hw[1])
+    dst = torch.empty((n, dh, dw, 3), dtype=torch.uint8, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.lib().vstab_resize_u8(src.data_ptr(), n, sh, sw, dst.data_ptr(), dh, dw, runtime.stream_ptr()))
+    return dst
+
+
+class ClipStabiliser:
+    def __init__(self, out_h: int, out_w: int, n_clips: int = 1, net_hw=(384, 512), scope: str = 'flownetS',
+                 device: Optional[int] = None):
+        runtime._require_gpu()
+        self.out_h, self.out_w, self.n = int(out_h), int(out_w), int(n_clips)
+        self.net_h, self.net_w = int(net_hw[0]), int(net_hw[1])
+        self.scope = scope
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.device = dev
+        self.ring = torch.zeros((RING, self.n, self.net_h, self.net_w, 3), dtype=torch.uint8, device=dev)
+        self.feats = torch.empty((self.n, self.net_h, self.net_w, 27), dtype=torch.float32, device=dev)
+        self.frame_f = torch.empty((self.n, self.out_h, self.out_w, 3), dtype=torch.float32, device=dev)
+        self.i = 0
+        self.last_flows = None
+
+    def reset(self):
+        self.i = 0
+        self.last_flows = None
+
+    def step(self, frame_bgr_u8: torch.Tensor) -> torch.Tensor:
+        """One frame of every clip: uint8 [n,out_h,out_w,3] BGR -> stabilised uint8 [n,out_h,out_w,3] BGR."""
+        f = _u8(frame_bgr_u8, "frame")
+        if tuple(f.shape) != (self.n, self.out_h, self.out_w, 3):
+            raise ValueError(f"frame must be {(self.n, self.out_h, self.out_w, 3)}, got {tuple(f.shape)}")
+        L = _lib.lib()
+        i = self.i
+        cur_small = resize_u8(f, (self.net_h, self.net_w))                       # main:550
+        slots = []
+        for lag in STAB_LAGS:                                                    # main:553-558
+            if i == 0:
+                slots.append(cur_small)      # totaloutputFrame[0] is still the raw first frame (main:548-549)
+            else:
+                slots.append(self.ring[max(i - lag, 0) % RING])
+        slots.append(cur_small)
+        ptrs = (C.c_void_p * 9)(*[s.data_ptr() for s in slots])
+        with torch.cuda.device(self.device):
+            _lib.check(L.vstab_assemble_input(ptrs, self.n, self.net_h, self.net_w, self.feats.data_ptr(), runtime.stream_ptr()))
+            _lib.check(L.vstab_frame_to_float(f.data_ptr(), self.n * self.out_h * self.out_w, self.frame_f.data_ptr(),
+                                              runtime.stream_ptr()))                                   # main:568
+        flows, outflow, warped = stabilise_originalsize(self.feats, self.frame_f, scope=self.scope)    # main:569
+        out = torch.empty_like(f)
+        with torch.cuda.device(self.device):
+            _lib.check(L.vstab_quantise_output(warped.data_ptr(), self.n * self.out_h * self.out_w, out.data_ptr(),
+                                               runtime.stream_ptr()))                                  # main:625,630
+        self.ring[i % RING].copy_(resize_u8(out, (self.net_h, self.net_w)))      # what later frames read back (main:556)
+        self.last_flows = flows
+        self.i += 1
+        return out
+
+    def run(self, clip_bgr_u8: torch.Tensor) -> torch.Tensor:
+        """clip [T, n, out_h, out_w, 3] (or [T, out_h, out_w, 3] for one clip) -> stabilised clip, same shape."""
+        single = clip_bgr_u8.dim() == 4
+        clip = clip_bgr_u8.unsqueeze(1) if single else clip_bgr_u8
+        self.reset()
+        out = torch.stack([self.step(clip[t]) for t in range(clip.shape[0])])
+        return out[:, 0] if single else out

@@ -955,3 +955,36 @@ extern "C" int vstab_maxpool2x2(const float *x, int B, int H, int W, int C, floa
     HIP_TRY(nullptr, launch_maxpool2x2(x, B, H, W, C, out, (hipStream_t)stream));
     return VSTAB_OK;
 }
+
+// ------------------------------------------------------------------------- clip driver pieces
+extern "C" int vstab_resize_u8(const uint8_t *src, int B, int sh, int sw, uint8_t *dst, int dh, int dw, void *stream)
+{
+    if (!src || !dst) return fail(nullptr, VSTAB_E_STATE, "resize_u8: NULL buffer");
+    if (B < 1 || sh < 1 || sw < 1 || dh < 1 || dw < 1) return fail(nullptr, VSTAB_E_SHAPE, "resize_u8: bad shape");
+    HIP_TRY(nullptr, launch_resize_u8(src, B, sh, sw, dst, dh, dw, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_assemble_input(const uint8_t *const *slots9, int B, int h, int w, float *feats, void *stream)
+{
+    if (!slots9 || !feats) return fail(nullptr, VSTAB_E_STATE, "assemble_input: NULL buffer");
+    for (int j = 0; j < 9; ++j)
+        if (!slots9[j]) return fail(nullptr, VSTAB_E_STATE, "assemble_input: slot %d is NULL", j);
+    if (B < 1 || h < 1 || w < 1) return fail(nullptr, VSTAB_E_SHAPE, "assemble_input: bad shape");
+    HIP_TRY(nullptr, launch_assemble_input(slots9, B, h, w, feats, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_frame_to_float(const uint8_t *frame, long long npix, float *out, void *stream)
+{
+    if (!frame || !out || npix < 1) return fail(nullptr, VSTAB_E_STATE, "frame_to_float: bad argument");
+    HIP_TRY(nullptr, launch_frame_to_float(frame, npix, out, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_quantise_output(const float *warped, long long npix, uint8_t *out, void *stream)
+{
+    if (!warped || !out || npix < 1) return fail(nullptr, VSTAB_E_STATE, "quantise_output: bad argument");
+    HIP_TRY(nullptr, launch_quantise_output(warped, npix, out, (hipStream_t)stream));
+    return VSTAB_OK;
+}

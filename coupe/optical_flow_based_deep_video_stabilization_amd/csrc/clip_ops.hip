@@ -1,0 +1,125 @@
+// Kernels of the autoregressive clip driver (the per-frame loop of evaluate_originalSize,
+// main:535-630): everything the reference does on the host with cv2/numpy between
+// two sess.run calls, kept on the device so a clip never leaves HBM.
+#include "vstab_internal.h"
+
+namespace vstab {
+
+// cv2.resize(src, (dw, dh)) with the default INTER_LINEAR on 8-bit images (main:550,556-558).  OpenCV is an
+// un-vendored dependency of the reference and is not installed here, so this restates its published 8u
+// path (imgproc/resize.cpp: half-pixel centres, 11-bit fixed-point coefficients, HResizeLinear then
+// VResizeLinear<uchar,int,short>):
+//   fx = (dx+0.5)*sw/dw - 0.5; sx = floor(fx); fx -= sx; sx<0 -> (0, fx=0); sx>=sw-1 -> (sw-1, fx=0)
+//   a = {sat16(round((1-fx)*2048)), sat16(round(fx*2048))};   row value  R = S[sx]*a0 + S[sx+1]*a1
+//   dst = ( ((b0*(R0>>4))>>16) + ((b1*(R1>>4))>>16) + 2 ) >> 2
+// UNVERIFIED against cv2 (documented in DESIGN.md); the oracle restates the same arithmetic.
+struct Tap { int i0, i1; int a0, a1; };
+__device__ __forceinline__ Tap cv_tap(int d, int dn, int sn)
+{
+    const float scale = (float)((double)sn / (double)dn);
+    float f = (float)(((double)d + 0.5) * (double)scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= sn - 1) { f = 0.f; s = sn - 1; }
+    Tap t;
+    t.i0 = s; t.i1 = min(s + 1, sn - 1);
+    t.a0 = (int)rintf((1.f - f) * 2048.f);
+    t.a1 = (int)rintf(f * 2048.f);
+    return t;
+}
+
+// src u8 [B,sh,sw,3] -> dst u8 [B,dh,dw,3]
+__global__ __launch_bounds__(256) void resize_u8_kernel(const unsigned char *__restrict__ src, int B, int sh, int sw,
+                                                        unsigned char *__restrict__ dst, int dh, int dw)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * dh * dw) return;
+    const int n = (int)(idx / (dh * dw));
+    const int rem = (int)(idx - (long long)n * dh * dw);
+    const int dy = rem / dw, dx = rem - dy * dw;
+    const Tap X = cv_tap(dx, dw, sw), Y = cv_tap(dy, dh, sh);
+    const unsigned char *b = src + (long long)n * sh * sw * 3;
+    const unsigned char *r0 = b + (long long)Y.i0 * sw * 3, *r1 = b + (long long)Y.i1 * sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int R0 = r0[X.i0 * 3 + c] * X.a0 + r0[X.i1 * 3 + c] * X.a1;
+        const int R1 = r1[X.i0 * 3 + c] * X.a0 + r1[X.i1 * 3 + c] * X.a1;
+        const int v = (((Y.a0 * (R0 >> 4)) >> 16) + ((Y.a1 * (R1 >> 4)) >> 16) + 2) >> 2;
+        dst[idx * 3 + c] = (unsigned char)min(max(v, 0), 255);
+    }
+}
+
+// curinput (main:550-558): feats[n,y,x,3j+c] = hist_j[n,y,x,2-c]/255 for the 8 history slots and the current
+// small frame (slot 8).  slots: 9 device pointers to u8 [B,h,w,3] frames (BGR as cv2 stores them).
+struct Slots9 { const unsigned char *p[9]; };
+__global__ __launch_bounds__(256) void assemble_input_kernel(Slots9 s, int B, int h, int w, float *__restrict__ feats)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * h * w) return;
+    float *o = feats + idx * 27;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const unsigned char *q = s.p[j] + idx * 3;
+        o[3 * j + 0] = (float)q[2] / 255.0f;        // cv2.cvtColor(.., COLOR_RGB2BGR) swaps channels 0 and 2
+        o[3 * j + 1] = (float)q[1] / 255.0f;
+        o[3 * j + 2] = (float)q[0] / 255.0f;
+    }
+}
+
+// resizedInput (main:568): swap(frame)/255 as float
+__global__ __launch_bounds__(256) void frame_to_float_kernel(const unsigned char *__restrict__ f, long long npix, float *__restrict__ out)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npix) return;
+    const unsigned char *q = f + idx * 3;
+    out[idx * 3 + 0] = (float)q[2] / 255.0f;
+    out[idx * 3 + 1] = (float)q[1] / 255.0f;
+    out[idx * 3 + 2] = (float)q[0] / 255.0f;
+}
+
+// totaloutputFrame[i] = swap(warped*255) (main:625) and its np.uint8 view used for history and the writer
+// (main:556,630): truncation toward zero; values outside [0,255] (possible where tf_warp extrapolates) saturate
+// here, where numpy's float->uint8 cast is undefined.
+__global__ __launch_bounds__(256) void quantise_output_kernel(const float *__restrict__ warped, long long npix,
+                                                              unsigned char *__restrict__ out)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npix) return;
+    const float *q = warped + idx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = q[2 - c] * 255.0f;
+        out[idx * 3 + c] = (unsigned char)fminf(fmaxf(truncf(v), 0.f), 255.f);
+    }
+}
+
+hipError_t launch_resize_u8(const unsigned char *src, int B, int sh, int sw, unsigned char *dst, int dh, int dw, hipStream_t stream)
+{
+    const long long total = (long long)B * dh * dw;
+    resize_u8_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(src, B, sh, sw, dst, dh, dw);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_input(const unsigned char *const *slots9, int B, int h, int w, float *feats, hipStream_t stream)
+{
+    Slots9 s;
+    for (int j = 0; j < 9; ++j) s.p[j] = slots9[j];
+    const long long total = (long long)B * h * w;
+    assemble_input_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(s, B, h, w, feats);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_to_float(const unsigned char *f, long long npix, float *out, hipStream_t stream)
+{
+    frame_to_float_kernel<<<dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream>>>(f, npix, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantise_output(const float *warped, long long npix, unsigned char *out, hipStream_t stream)
+{
+    quantise_output_kernel<<<dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream>>>(warped, npix, out);
+    return hipGetLastError();
+}
+
+}  // namespace vstab

@@ -136,6 +136,12 @@ hipError_t launch_homography_warp(const float *img, int B, int Hi, int Wi, int C
                                   int oh, int ow, hipStream_t stream);
 hipError_t launch_vec2mtrx(const float *p, int B, int dim, int approx, float *out, hipStream_t stream);
 
+// clip driver helpers (clip_ops.hip)
+hipError_t launch_resize_u8(const unsigned char *src, int B, int sh, int sw, unsigned char *dst, int dh, int dw, hipStream_t stream);
+hipError_t launch_assemble_input(const unsigned char *const *slots9, int B, int h, int w, float *feats, hipStream_t stream);
+hipError_t launch_frame_to_float(const unsigned char *f, long long npix, float *out, hipStream_t stream);
+hipError_t launch_quantise_output(const float *warped, long long npix, unsigned char *out, hipStream_t stream);
+
 // NLDF head helpers (nldf_ops.hip)
 hipError_t launch_contrast(float *buf, int B, int H, int W, int C, int Cs, int c_dst, hipStream_t stream);
 hipError_t launch_nldf_score(const float *local2, const float *global2, int B, int npix, float *score, float *prob,

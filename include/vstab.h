@@ -188,6 +188,18 @@ VSTAB_API int vstab_nldf_forward(vstab_ctx *ctx, const float *const *pools5, int
                                  float *local_fea, float *fea_global, void *workspace, size_t workspace_bytes,
                                  void *stream);
 
+/* ---- autoregressive clip driver pieces (per-frame loop of evaluate_originalSize, main:535-630) ----
+ * All frames are uint8 [B,h,w,3] in cv2's BGR order, device memory. */
+/* cv2.resize(src, (dw, dh)), INTER_LINEAR, 8-bit (main:550,556-558): restated fixed-point algorithm, see clip_ops.hip. */
+VSTAB_API int vstab_resize_u8(const uint8_t *src, int B, int sh, int sw, uint8_t *dst, int dh, int dw, void *stream);
+/* curinput (main:550-558): feats[B,h,w,27]; slot j < 8 = history frame of lag {31,23,15,7,4,3,2,1}[j], slot 8 = current
+ * frame, each u8 [B,h,w,3] at network resolution; channels swapped (COLOR_RGB2BGR) and divided by 255. */
+VSTAB_API int vstab_assemble_input(const uint8_t *const *slots9, int B, int h, int w, float *feats, void *stream);
+/* resizedInput (main:568): swap(frame)/255 -> float [npix,3]. */
+VSTAB_API int vstab_frame_to_float(const uint8_t *frame, long long npix, float *out, void *stream);
+/* np.uint8(swap(warped*255)) (main:625,630,556): float [npix,3] -> u8, truncating, saturating outside [0,255]. */
+VSTAB_API int vstab_quantise_output(const float *warped, long long npix, uint8_t *out, void *stream);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU tests) --------------------- */
 /* Level sizes of the encoder for an HxW input: hw[2*i], hw[2*i+1] = (h, w) of stage i
  * (10 stages).  Returns 0 or VSTAB_E_SHAPE. */

@@ -470,3 +470,56 @@ def nldf_build_model(x, vgg_dict, hw, dtype=torch.float64):
     score = (ls + gs).permute(0, 2, 3, 1)
     prob = torch.softmax(score, dim=3)[..., 0:1]
     return {"Prob": prob, "Score": score, "Local_Fea": lf.permute(0, 2, 3, 1), "Fea_Global": fg.permute(0, 2, 3, 1)}
+
+
+# --------------------------------------------------------------------------- clip driver (main:535-630)
+def cv_resize_u8(src: np.ndarray, dh: int, dw: int) -> np.ndarray:
+    """cv2.resize(src, (dw, dh)) INTER_LINEAR for uint8 HxWxC, restating OpenCV's 8-bit path (imgproc/resize.cpp:
+    half-pixel centres, 11-bit coefficients, HResizeLinear + VResizeLinear<uchar,int,short>).  cv2 is not
+    installed here: UNVERIFIED against the real library; the HIP kernel restates the same arithmetic."""
+    sh, sw = src.shape[:2]
+
+    def taps(dn, sn):
+        scale = np.float32(np.float64(sn) / np.float64(dn))
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * np.float64(scale) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        f[lo] = 0; s[lo] = 0
+        hi = s >= sn - 1
+        f[hi] = 0; s[hi] = sn - 1
+        a0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        a1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s, np.minimum(s + 1, sn - 1), a0, a1
+
+    x0, x1, ax0, ax1 = taps(dw, sw)
+    y0, y1, ay0, ay1 = taps(dh, sh)
+    S = src.astype(np.int64)
+    R = S[:, x0] * ax0[None, :, None] + S[:, x1] * ax1[None, :, None]                 # [sh, dw, C]
+    R0, R1 = R[y0], R[y1]
+    v = (((ay0[:, None, None] * (R0 >> 4)) >> 16) + ((ay1[:, None, None] * (R1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32):
+    """The loop of evaluate_originalSize (main:540-630) on a clip [T,H,W,3] uint8 BGR -> stabilised uint8 clip."""
+    T, H, W, _ = frames_bgr_u8.shape
+    nh, nw = net_hw
+    lags = (31, 23, 15, 7, 4, 3, 2, 1)                                             # main:553
+    total = np.zeros((T, H, W, 3), np.float64)                                     # totaloutputFrame (main:534)
+    outs = []
+    for i in range(T):
+        frame = frames_bgr_u8[i]
+        if i == 0:
+            total[0] = frame                                                       # main:548-549
+        cur = np.zeros((1, nh, nw, 27), np.float32)
+        cur[0, :, :, 24:27] = cv_resize_u8(frame, nh, nw)[..., ::-1] / 255.0      # main:550
+        for j, lag in enumerate(lags):                                             # main:554-558
+            src = total[0] if i - lag < 0 else total[i - lag]
+            q = np.clip(np.trunc(src), 0, 255).astype(np.uint8)                    # np.uint8(...)
+            cur[0, :, :, 3 * j:3 * j + 3] = np.float32(cv_resize_u8(q, nh, nw)[..., ::-1]) / 255.0
+        frame_f = (frame[..., ::-1] / 255.0).astype(np.float32)[None]              # main:568
+        _, _, warped = stabilise_originalsize(cur, frame_f, weights, dtype)        # main:569
+        total[i] = (warped[0].numpy().astype(np.float64) * 255.0)[..., ::-1]       # main:625
+        outs.append(np.clip(np.trunc(total[i]), 0, 255).astype(np.uint8))          # main:630
+    return np.stack(outs)
