@@ -988,3 +988,27 @@ extern "C" int vstab_quantise_output(const float *warped, long long npix, uint8_
     HIP_TRY(nullptr, launch_quantise_output(warped, npix, out, (hipStream_t)stream));
     return VSTAB_OK;
 }
+
+// ------------------------------------------------------------------------- flow post-filters
+extern "C" int vstab_flow_box_blur(const float *flow, int B, int h, int w, int k, float *tmp, float *out, void *stream)
+{
+    if (!flow || !tmp || !out) return fail(nullptr, VSTAB_E_STATE, "flow_box_blur: NULL buffer");
+    if (B < 1 || h < 1 || w < 1 || k < 1 || !(k & 1)) return fail(nullptr, VSTAB_E_SHAPE, "flow_box_blur: bad shape (k must be odd)");
+    HIP_TRY(nullptr, launch_flow_box_blur(flow, B, h, w, k, tmp, out, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_axpby(const float *x, float a, const float *y, float b, float *out, long long n, void *stream)
+{
+    if (!x || !y || !out || n < 1) return fail(nullptr, VSTAB_E_STATE, "axpby: bad argument");
+    HIP_TRY(nullptr, launch_axpby(x, a, y, b, out, n, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_flow_mean_fill(const float *flow, int B, int h, int w, float *out, void *stream)
+{
+    if (!flow || !out) return fail(nullptr, VSTAB_E_STATE, "flow_mean_fill: NULL buffer");
+    if (B < 1 || h < 1 || w < 1) return fail(nullptr, VSTAB_E_SHAPE, "flow_mean_fill: bad shape");
+    HIP_TRY(nullptr, launch_flow_mean_fill(flow, B, h, w, out, (hipStream_t)stream));
+    return VSTAB_OK;
+}

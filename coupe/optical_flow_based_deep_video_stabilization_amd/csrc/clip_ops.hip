@@ -123,3 +123,85 @@ hipError_t launch_quantise_output(const float *warped, long long npix, unsigned 
 }
 
 }  // namespace vstab
+
+// ---------------------------------------------------------------------------------
+// Flow post-filters of the reference's other evaluators.
+// ---------------------------------------------------------------------------------
+namespace vstab {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// tf.nn.conv2d(of_c, constant(1/(k*k), [k,k,1,1]), SAME) per flow channel (main_flownetS_pyramid.py:634-641):
+// a k x k box sum with zero padding times 1/(k*k).  Separable: this kernel sums k taps along one axis.
+__global__ __launch_bounds__(256) void box_sum_axis_kernel(const float *__restrict__ in, int B, int h, int w, int k, int axis,
+                                                           float scale, float *__restrict__ out)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * h * w) return;
+    const int n = (int)(idx / (h * w));
+    const int rem = (int)(idx - (long long)n * h * w);
+    const int y = rem / w, x = rem - y * w;
+    const int r = (k - 1) / 2;                 // odd k: SAME pads (k-1)/2 on both sides
+    const f32x2 *b = reinterpret_cast<const f32x2 *>(in) + (long long)n * h * w;
+    f32x2 s = {0.f, 0.f};
+    if (axis == 0) {
+        const int lo = max(x - r, 0), hi = min(x + (k - 1 - r), w - 1);
+        for (int i = lo; i <= hi; ++i) s += b[y * w + i];
+    } else {
+        const int lo = max(y - r, 0), hi = min(y + (k - 1 - r), h - 1);
+        for (int i = lo; i <= hi; ++i) s += b[i * w + x];
+    }
+    s.x *= scale; s.y *= scale;
+    reinterpret_cast<f32x2 *>(out)[idx] = s;
+}
+
+hipError_t launch_flow_box_blur(const float *flow, int B, int h, int w, int k, float *tmp, float *out, hipStream_t stream)
+{
+    if (k < 1 || !(k & 1)) return hipErrorInvalidValue;
+    const long long total = (long long)B * h * w;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    box_sum_axis_kernel<<<grid, block, 0, stream>>>(flow, B, h, w, k, 0, 1.0f, tmp);
+    box_sum_axis_kernel<<<grid, block, 0, stream>>>(tmp, B, h, w, k, 1, 1.0f / ((float)k * (float)k), out);
+    return hipGetLastError();
+}
+
+// out = a*x + b*y  (0.9*smoothof + 0.1*prevof, main_flownetS_pyramid.py:643; prevof EMA :695)
+__global__ __launch_bounds__(256) void axpby_kernel(const float *__restrict__ x, float a, const float *__restrict__ y, float b,
+                                                    float *__restrict__ out, long long n)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) out[idx] = a * x[idx] + b * y[idx];
+}
+
+hipError_t launch_axpby(const float *x, float a, const float *y, float b, float *out, long long n, hipStream_t stream)
+{
+    axpby_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(x, a, y, b, out, n);
+    return hipGetLastError();
+}
+
+// out[b,:,:,c] = mean over (h,w) of flow[b,:,:,c]  (main_flownetS_pyramid_highTV_noBBloss.py:629): one workgroup
+// per sample, wavefront-shuffle + LDS reduction, then the same workgroup fills the field.
+__global__ __launch_bounds__(256) void mean_fill_kernel(const float *__restrict__ flow, int hw, float *__restrict__ out)
+{
+    __shared__ float red[8];
+    const f32x2 *b = reinterpret_cast<const f32x2 *>(flow) + (long long)blockIdx.x * hw;
+    float sx = 0.f, sy = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) { const f32x2 v = b[i]; sx += v.x; sy += v.y; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave * 2] = sx; red[wave * 2 + 1] = sy; }
+    __syncthreads();
+    const float mx = (red[0] + red[2] + red[4] + red[6]) / (float)hw, my = (red[1] + red[3] + red[5] + red[7]) / (float)hw;
+    f32x2 m; m.x = mx; m.y = my;
+    f32x2 *o = reinterpret_cast<f32x2 *>(out) + (long long)blockIdx.x * hw;
+    for (int i = threadIdx.x; i < hw; i += 256) o[i] = m;
+}
+
+hipError_t launch_flow_mean_fill(const float *flow, int B, int h, int w, float *out, hipStream_t stream)
+{
+    mean_fill_kernel<<<dim3((unsigned)B), dim3(256), 0, stream>>>(flow, h * w, out);
+    return hipGetLastError();
+}
+
+}  // namespace vstab

@@ -142,6 +142,10 @@ hipError_t launch_assemble_input(const unsigned char *const *slots9, int B, int 
 hipError_t launch_frame_to_float(const unsigned char *f, long long npix, float *out, hipStream_t stream);
 hipError_t launch_quantise_output(const float *warped, long long npix, unsigned char *out, hipStream_t stream);
 
+hipError_t launch_flow_box_blur(const float *flow, int B, int h, int w, int k, float *tmp, float *out, hipStream_t stream);
+hipError_t launch_axpby(const float *x, float a, const float *y, float b, float *out, long long n, hipStream_t stream);
+hipError_t launch_flow_mean_fill(const float *flow, int B, int h, int w, float *out, hipStream_t stream);
+
 // NLDF head helpers (nldf_ops.hip)
 hipError_t launch_contrast(float *buf, int B, int H, int W, int C, int Cs, int c_dst, hipStream_t stream);
 hipError_t launch_nldf_score(const float *local2, const float *global2, int B, int npix, float *score, float *prob,

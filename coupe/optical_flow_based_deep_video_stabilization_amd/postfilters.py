@@ -1,0 +1,64 @@
+"""Flow post-filters the reference's other evaluators wrap around the same hot path:
+`evaluate_blurNma` (main_flownetS_pyramid.py:582-700: 75x75 box blur of predict_flow2 blended with a temporal
+EMA) and the mean-global-flow variant (main_flownetS_pyramid_highTV_noBBloss.py:629-631, 679-685).  The
+RANSAC homography evaluator (main:735-743) needs cv2.findHomography and stays out of scope."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, runtime
+
+
+def _flow(t, name="flow"):
+    if not torch.is_tensor(t) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4 or t.shape[3] != 2:
+        raise ValueError(f"{name} must be a float32 CUDA tensor [B,h,w,2]")
+    return t.contiguous()
+
+
+def box_blur_flow(flow, k: int = 75):
+    """tf.nn.conv2d(channel, constant(1/(k*k), [k,k,1,1]), SAME) on both flow channels (:634-640)."""
+    f = _flow(flow)
+    B, h, w, _ = f.shape
+    tmp, out = torch.empty_like(f), torch.empty_like(f)
+    with torch.cuda.device(f.device):
+        _lib.check(_lib.lib().vstab_flow_box_blur(f.data_ptr(), B, h, w, int(k), tmp.data_ptr(), out.data_ptr(),
+                                                  runtime.stream_ptr()))
+    return out
+
+
+def axpby(a: float, x, b: float, y):
+    """a*x + b*y on equally shaped float32 CUDA tensors."""
+    x, y = x.contiguous(), y.contiguous()
+    if x.shape != y.shape or x.dtype != torch.float32 or not x.is_cuda or not y.is_cuda:
+        raise ValueError("x and y must be equally shaped float32 CUDA tensors")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().vstab_axpby(x.data_ptr(), float(a), y.data_ptr(), float(b), out.data_ptr(), x.numel(),
+                                          runtime.stream_ptr()))
+    return out
+
+
+def mean_flow(flow):
+    """ones_like(flow_c) * reduce_mean(flow_c, axis=[1,2]) per channel: the global-translation flow (:629)."""
+    f = _flow(flow)
+    B, h, w, _ = f.shape
+    out = torch.empty_like(f)
+    with torch.cuda.device(f.device):
+        _lib.check(_lib.lib().vstab_flow_mean_fill(f.data_ptr(), B, h, w, out.data_ptr(), runtime.stream_ptr()))
+    return out
+
+
+class BlurEmaFilter:
+    """State of evaluate_blurNma's loop: warp flow = 0.9*blur75(of) + 0.1*prevof (:643), then
+    prevof = 0.9*prevof + 0.1*of (:695); prevof starts at zero (:670)."""
+
+    def __init__(self, k: int = 75, alpha: float = 0.9):
+        self.k, self.alpha, self.prev = k, alpha, None
+
+    def __call__(self, of):
+        of = _flow(of)
+        if self.prev is None:
+            self.prev = torch.zeros_like(of)
+        out = axpby(self.alpha, box_blur_flow(of, self.k), 1.0 - self.alpha, self.prev)
+        self.prev = axpby(self.alpha, self.prev, 1.0 - self.alpha, of)
+        return out

@@ -200,6 +200,15 @@ VSTAB_API int vstab_frame_to_float(const uint8_t *frame, long long npix, float *
 /* np.uint8(swap(warped*255)) (main:625,630,556): float [npix,3] -> u8, truncating, saturating outside [0,255]. */
 VSTAB_API int vstab_quantise_output(const float *warped, long long npix, uint8_t *out, void *stream);
 
+/* ---- flow post-filters of the reference's other evaluators ---------------------
+ * k x k box blur of a flow field with zero (SAME) padding, weights 1/(k*k), k odd
+ * (main_flownetS_pyramid.py:634-641, k = 75).  tmp: scratch of the same size as flow. */
+VSTAB_API int vstab_flow_box_blur(const float *flow, int B, int h, int w, int k, float *tmp, float *out, void *stream);
+/* out = a*x + b*y elementwise (0.9*smooth + 0.1*prev, :643; prev = 0.9*prev + 0.1*cur, :695). */
+VSTAB_API int vstab_axpby(const float *x, float a, const float *y, float b, float *out, long long n, void *stream);
+/* out[b,:,:,c] = mean over the image of flow[b,:,:,c] (main_flownetS_pyramid_highTV_noBBloss.py:629). */
+VSTAB_API int vstab_flow_mean_fill(const float *flow, int B, int h, int w, float *out, void *stream);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU tests) --------------------- */
 /* Level sizes of the encoder for an HxW input: hw[2*i], hw[2*i+1] = (h, w) of stage i
  * (10 stages).  Returns 0 or VSTAB_E_SHAPE. */

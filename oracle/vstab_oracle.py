@@ -523,3 +523,17 @@ def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32):
         total[i] = (warped[0].numpy().astype(np.float64) * 255.0)[..., ::-1]       # main:625
         outs.append(np.clip(np.trunc(total[i]), 0, 255).astype(np.uint8))          # main:630
     return np.stack(outs)
+
+
+# --------------------------------------------------------------------------- flow post-filters
+def box_blur_flow(flow, k: int = 75, dtype=torch.float64):
+    """tf.nn.conv2d(of_c, constant(1/(k*k), [k,k,1,1]), SAME) per channel (main_flownetS_pyramid.py:634-641)."""
+    f = _t(flow, dtype).permute(0, 3, 1, 2)
+    w = torch.full((2, 1, k, k), 1.0 / (k * k), dtype=dtype)
+    return F.conv2d(f, w, padding=(k - 1) // 2, groups=2).permute(0, 2, 3, 1)
+
+
+def mean_flow(flow, dtype=torch.float64):
+    """main_flownetS_pyramid_highTV_noBBloss.py:629."""
+    f = _t(flow, dtype)
+    return f.mean(dim=(1, 2), keepdim=True).expand_as(f)
