@@ -21,17 +21,45 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+STAMP = os.path.join(HERE, "libvstab_hip.so.srchash")
+
+
+def source_hash() -> str:
+    """Content hash of everything the library is built from (mtimes do not survive the copy to a GPU box)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for dep in [os.path.join(CSRC, s) for s in SOURCES + HEADERS]:
+        with open(dep, "rb") as f:
+            h.update(os.path.basename(dep).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    try:
+        return open(STAMP).read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
+    # one builder at a time: several ranks of a torchrun job may import the package at once
+    import fcntl
+    lock = open(os.path.join(HERE, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not stale():          # another process built it while we waited
+            return LIB
+        return _build_locked(verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(verbose: bool) -> str:
     objs = []
     obj_dir = os.path.join(HERE, "build")
     os.makedirs(obj_dir, exist_ok=True)
@@ -45,6 +73,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     tmp = LIB + ".tmp"
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp])
     os.replace(tmp, LIB)
+    with open(STAMP + ".tmp", "w") as f:
+        f.write(source_hash())
+    os.replace(STAMP + ".tmp", STAMP)
     return LIB
 
 
