@@ -1,5 +1,6 @@
 // C ABI of libvstab_hip.so (include/vstab.h): context, weight packing/upload, the
 // FlowNetS-pyramid forward schedule (model.py:786-893) and the glue/warp entry points.
+#include <cstdlib>
 #include <map>
 
 #include "api_internal.h"
@@ -243,7 +244,7 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
             p.ph[0].Hg = p.Hi; p.ph[0].Wg = p.Wi; p.ph[0].M = B * p.Hi * p.Wi; p.Mmax = p.ph[0].M;
             pl.tile[15 + l] = TILE_128x32; pl.vec4[15 + l] = true;
             set_ranges(p);
-            choose_split(p, 32);
+            choose_split(p, 32);   // A/B on one box: split-K + combine beats 4..256 long-running workgroups by ~90 us/step
             if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
             (void)dst;
         }
