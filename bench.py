@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--cin", type=int, default=27)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of warped frames (N>1)")
+    ap.add_argument("--gather-fp32", action="store_true",
+                    help="all-gather the fp32 warped frames instead of the uint8 video frames the reference writes (main:630)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--vgg16", action="store_true",
                     help="BASELINE config 5: also run the VGG16 trunk (preprocess + 13 conv + 5 pool) on the warped frames")
@@ -123,19 +125,33 @@ def main():
 
     gather = None
     if (world > 1 or force_dist) and not args.no_gather:
-        gather = vdist.FrameGatherer((B, H, W, 3), world, torch.device("cuda", local_rank))
+        gather = vdist.FrameGatherer((B, H, W, 3), world, torch.device("cuda", local_rank),
+                                     dtype=torch.float32 if args.gather_fp32 else torch.uint8)
+    quantise = None
+    if gather is not None and not args.gather_fp32:
+        import ctypes as C
+        from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
+        u8 = [torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+
+        def quantise(warped):           # np.uint8(cvtColor(warped*255)) as the reference's writer does (main:625,630)
+            slot = gather.reserve()     # the collective that last read u8[slot] has completed
+            _lib.check(_lib.lib().vstab_quantise_output(warped.data_ptr(), B * H * W, u8[slot].data_ptr(), runtime.stream_ptr()))
+            return u8[slot]
 
     vgg = None
     if args.vgg16:
         from coupe.optical_flow_based_deep_video_stabilization_amd import vgg16 as vvgg
         vgg = vvgg.Vgg16(seed=7, reuse_outputs=True)
 
+    nstep = [0]
+
     def step():
         flows, outflow, warped = vs.stabilise_originalsize(feats, frame)
         if vgg is not None:
             vgg.build(vvgg.preprocess(warped))
         if gather is not None:
-            gather.submit(warped)
+            gather.submit(quantise(warped) if quantise is not None else warped)
+        nstep[0] += 1
         return flows, outflow, warped
 
     for _ in range(args.warmup):
@@ -225,7 +241,8 @@ def main():
                                f"(5 flows) + flow resize/scale + tf_warp at {H}x{W}",
                    "batch_per_gpu": B, "height": H, "width": W, "cin": Cin,
                    "gflop_per_sample": round(netspec.gflop_per_sample(H, W, Cin), 2),
-                   "all_gather": bool(gather is not None), "vgg16_trunk": bool(args.vgg16)},
+                   "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL") if gather is not None else False,
+                   "vgg16_trunk": bool(args.vgg16)},
         "roofline": roofline,
     }
     if rank == 0:

@@ -56,6 +56,13 @@ class FrameGatherer:
         self.pending: List[Optional[tuple]] = [None] * depth
         self.count = 0
 
+    def reserve(self) -> int:
+        """Slot the next submit() will use, after waiting for the collective that last used it: a caller that
+        stages its frames in a per-slot buffer of its own may overwrite that buffer once this returns."""
+        slot = self.count % self.depth
+        self._wait(slot)
+        return slot
+
     def submit(self, frames: torch.Tensor) -> int:
         slot = self.count % self.depth
         self._wait(slot)
