@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--gather-fp32", action="store_true",
                     help="all-gather the fp32 warped frames instead of the uint8 video frames the reference writes (main:630)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="record the per-launch HIP events on every n-th step of the timed region (they cost ~2 %% of a step)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step into a HIP graph (torch.cuda.CUDAGraph) and replay it; single GPU, no kernel events")
     ap.add_argument("--vgg16", action="store_true",
                     help="BASELINE config 5: also run the VGG16 trunk (preprocess + 13 conv + 5 pool) on the warped frames")
     args = ap.parse_args()
@@ -154,6 +158,19 @@ def main():
         nstep[0] += 1
         return flows, outflow, warped
 
+    graph = None
+    if args.graph:
+        if gather is not None:
+            raise SystemExit("--graph is for the single-GPU path (no collective inside the capture)")
+        args.no_kernel_events = True
+        step()                                   # allocate workspaces / load kernels outside the capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = step()
+        eager_step = step
+        step = lambda: (graph.replay(), graph_out)[1]
+
     for _ in range(args.warmup):
         step()
     if gather is not None:
@@ -164,8 +181,14 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    ev_every = max(1, args.event_every)
+    n_event_steps = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if use_events:
+            on = (k % ev_every == 0)
+            ctx.profile_set(on)
+            n_event_steps += int(on)
         out = step()
     if gather is not None:
         gather.drain()
@@ -185,7 +208,7 @@ def main():
     if use_events:
         ms, flops, _nrec = ctx.profile_read()      # sums over every recorded pass of the timed region
         ctx.profile(False)
-        nf = max(args.steps, 1)
+        nf = max(n_event_steps, 1)                 # steps of the timed region that carried events
         flops = [f / nf for f in flops]
         inst = ctx.profile_kernel_names()
         groups = {}
@@ -215,7 +238,7 @@ def main():
         all_tf = tot_fl / (tot_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "kernel": dom, "launches_per_step": d_n,
+                    "kernel": dom, "launches_per_step": d_n, "event_steps": n_event_steps,
                     "avg_launch_us": round(d_ms / d_n * 1e3, 2),
                     "alg_flops_per_launch_avg": d_fl / d_n,
                     "all_mfma_launches": {"launches_per_step": 15, "ms_per_step": round(tot_ms, 4),

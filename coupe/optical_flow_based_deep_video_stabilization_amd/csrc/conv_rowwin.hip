@@ -23,6 +23,8 @@
 // the image are loaded as zeros via the buffer descriptor's range check (no branches).
 // Requires (s*C_in) even, (W*C_in) % 4 == 0, 16-byte aligned input; otherwise the generic
 // scalar-gather kernel runs instead.
+#include <hip/hip_ext.h>
+
 #include "vstab_internal.h"
 
 namespace vstab {
@@ -183,11 +185,11 @@ hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEven
 {
     if (!rowwin_applicable(p)) return hipErrorInvalidValue;
     dim3 grid((p.Wo + 127) / 128, p.Ho, p.B), block(256);
-    if (ev_start) (void)hipEventRecord(ev_start, stream);
-    conv_rowwin_kernel<7><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(p);
-    hipError_t e = hipGetLastError();
-    if (ev_stop) (void)hipEventRecord(ev_stop, stream);
-    return e;
+    if (ev_start && ev_stop)      // timestamps of the kernel's own dispatch packet, no marker packets (see conv_mfma.hip)
+        hipExtLaunchKernelGGL(conv_rowwin_kernel<7>, grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, p);
+    else
+        conv_rowwin_kernel<7><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(p);
+    return hipGetLastError();
 }
 
 }  // namespace vstab

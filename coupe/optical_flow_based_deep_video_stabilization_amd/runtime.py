@@ -97,6 +97,10 @@ class Context:
         _lib.check(_lib.lib().vstab_profile_enable(self._h, int(enable)), self._h)
         _lib.check(_lib.lib().vstab_profile_reset(self._h), self._h)
 
+    def profile_set(self, enable: bool):
+        """Switch event recording on/off without clearing what has been recorded (sampling some steps)."""
+        _lib.check(_lib.lib().vstab_profile_enable(self._h, int(enable)), self._h)
+
     def profile_read(self):
         """(ms, algorithmic flops) per launch slot, both summed over the recorded passes, and the
         number of passes.  The stream must have been synchronised."""

@@ -1,11 +1,6 @@
 cd $GRAFT_REPO_ROOT
-(python3 bench.py --steps 600 --warmup 5 --no-cpu-baseline > gpurun_out/long.json 2> gpurun_out/long.err) &
-BP=$!
-sleep 14
-for i in 1 2 3 4; do
-  rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|Power|Temperature \(Sensor (edge|junction)" | head -8
-  echo ---
-  sleep 0.4
+for i in 1 2; do
+python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-kernel-events 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1
+python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>gpurun_out/ev.err | grep -o '"ms_per_step": [0-9.]*\|"avg_launch_us": [0-9.]*' | head -3 | tr '\n' ' '; echo "(events)"
 done
-wait $BP
-grep -o '"ms_per_step": [0-9.]*' gpurun_out/long.json | head -1
+tail -18 gpurun_out/ev.err
