@@ -1,0 +1,59 @@
+// Kernel-tuning harness (not part of the product): times ONE conv-like launch of the forward
+// schedule in isolation with random data, for tile / split-K experiments.
+//   conv_bench <layer 0..14> <B> <H> <W> [tile -1|0|1|2] [ksplit -1|n] [iters]
+// Build: scripts/build_tools.sh ; run on the GPU box.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../include/vstab.h"
+#include "../coupe/optical_flow_based_deep_video_stabilization_amd/csrc/vstab_internal.h"
+using namespace vstab;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) { printf("usage: conv_bench layer B H W [tile] [ksplit] [iters]\n"); return 2; }
+    const int layer = atoi(argv[1]), B = atoi(argv[2]), H = atoi(argv[3]), W = atoi(argv[4]);
+    const int tile_o = argc > 5 ? atoi(argv[5]) : -1, ks_o = argc > 6 ? atoi(argv[6]) : -1, iters = argc > 7 ? atoi(argv[7]) : 20;
+    int32_t v[64];
+    if (vstab_host_layer_plan(B, H, W, 27, layer, v, 64) < 0) { printf("plan failed\n"); return 1; }
+    ConvParams p{};
+    p.B = v[0]; p.Hi = v[1]; p.Wi = v[2]; p.Cs_in = v[3]; p.KH = v[4]; p.NSEG = v[5]; p.SEG = v[6]; p.SEGP = v[7];
+    p.SEG_STRIDE = v[8]; p.s_in = v[9]; p.s_out = v[10]; p.Ho = v[11]; p.Wo = v[12]; p.Cs_out = v[13]; p.c_off = v[14];
+    p.N = v[15]; p.Npad = v[16]; p.act = v[17]; p.nphase = v[18]; p.ksplit = v[19]; p.Mmax = v[20];
+    int tile = v[21]; const bool vec4 = v[22];
+    const int KT = p.KH * p.NSEG * p.SEGP / 32;
+    if (tile_o >= 0) { tile = tile_o; const int BN = tile == 0 ? 128 : (tile == 1 ? 64 : 32); p.Npad = round_up(p.N, BN); }
+    if (ks_o >= 1) p.ksplit = ks_o;
+    double macs = 0;
+    for (int k = 0; k < p.nphase; ++k) {
+        ConvPhase &ph = p.ph[k];
+        ph.Hg = v[26 + 7 * k]; ph.Wg = v[27 + 7 * k]; ph.M = v[28 + 7 * k]; ph.off_y = v[29 + 7 * k]; ph.off_x = v[30 + 7 * k];
+        ph.o_y = v[31 + 7 * k]; ph.o_x = v[32 + 7 * k]; ph.w_off = (long long)k * KT * p.Npad * 32;
+        macs += (double)ph.M * KT * 32 * p.N;       // padded-K MACs actually issued
+    }
+    const size_t in_n = (size_t)p.B * p.Hi * p.Wi * p.Cs_in, out_n = (size_t)p.B * p.Ho * p.Wo * p.Cs_out;
+    const size_t w_n = (size_t)p.nphase * KT * p.Npad * 32, part_n = (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad;
+    std::vector<float> h(std::max(in_n, w_n));
+    for (auto &x : h) x = (float)rand() / RAND_MAX - 0.5f;
+    float *din, *dw, *db, *dout, *dpart;
+    CK(hipMalloc(&din, in_n * 4)); CK(hipMalloc(&dw, w_n * 4)); CK(hipMalloc(&db, p.Npad * 4)); CK(hipMalloc(&dout, out_n * 4));
+    CK(hipMalloc(&dpart, (part_n + 4) * 4));
+    CK(hipMemcpy(din, h.data(), in_n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, h.data(), w_n * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(db, 0, p.Npad * 4));
+    p.in_bytes = (unsigned)(in_n * 4); p.w_bytes = (unsigned)((size_t)KT * p.Npad * 128);
+    p.in = din; p.wpk = dw; p.bias = db; p.out = dout; p.partial = dpart;
+    CK(conv_set_attributes());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) CK(launch_conv(p, (ConvTile)tile, vec4, 0));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) CK(launch_conv(p, (ConvTile)tile, vec4, 0));
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    const int BN = tile == 0 ? 128 : (tile == 1 ? 64 : 32);
+    const long long blocks = (long long)((p.Mmax + 127) / 128) * (p.Npad / BN) * p.nphase * p.ksplit;
+    printf("layer %2d tile %d ksplit %2d blocks %6lld KT %4d  %8.2f us  %7.1f TF(issued)  frac %.3f\n", layer, tile, p.ksplit, blocks, KT,
+           ms * 1e3, 2 * macs / (ms * 1e-3) / 1e12, 2 * macs / (ms * 1e-3) / 1e12 / 157.3);
+    return 0;
+}
