@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3]: an F-frame 1080p synthetic clip sharded across the GPUs of one node,
+reassembled with ONE RCCL all-gather of the stabilised uint8 frames.
+
+Teacher-forced: every frame's 27-channel input stack is given (synthetic), so frames are independent
+samples and the clip shards by contiguous blocks (the autoregressive real-video mode does
+not shard by frame -- that is clip_driver.ClipStabiliser, batched over clips instead).  Strong scaling:
+the clip is fixed, ranks split it.
+
+    python bench_clip.py --frames 1000 [--height 1080 --width 1920 --micro-batch 8]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 bench_clip.py --frames 1000
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--cin", type=int, default=27)
+    ap.add_argument("--micro-batch", type=int, default=8)
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_clip.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    use_dist = world > 1 or os.environ.get("VSTAB_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import coupe.optical_flow_based_deep_video_stabilization_amd as vs
+    from coupe.optical_flow_based_deep_video_stabilization_amd import _lib, runtime, distributed as vdist
+
+    F_, H, W, Cin, MB = args.frames, args.height, args.width, args.cin, args.micro_batch
+    vs.initialize_global_variables(seed=1, cin=Cin)
+    lo, hi = vdist.shard_range(F_, rank, world)
+    n_local = hi - lo
+    g = torch.Generator().manual_seed(2000 + rank)
+    feats = torch.rand(MB, H, W, Cin, generator=g).cuda()            # one synthetic micro-batch, reused
+    frame = torch.rand(MB, H, W, 3, generator=g).cuda()
+    shard = torch.empty((n_local, H, W, 3), dtype=torch.uint8, device="cuda")
+    L = _lib.lib()
+
+    def run_shard():
+        for b0 in range(0, n_local, MB):
+            bc = min(MB, n_local - b0)
+            _, _, warped = vs.stabilise_originalsize(feats[:bc], frame[:bc])
+            _lib.check(L.vstab_quantise_output(warped.data_ptr(), bc * H * W, shard[b0:b0 + bc].data_ptr(), runtime.stream_ptr()))
+
+    # warm-up: one micro-batch (kernels loaded, workspaces allocated)
+    vs.stabilise_originalsize(feats, frame)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_shard()
+    torch.cuda.synchronize()
+    t_compute = time.perf_counter() - t0
+    full = vdist.gather_sequence(shard, F_) if use_dist else shard
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed, t_compute], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, t_compute = float(t[0]), float(t[1])
+    assert full.shape[0] == F_
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"stabilised frames/sec, {F_}-frame {H}x{W} clip sharded over {world} GPU(s), all-gather reassembly",
+            "value": round(F_ / elapsed, 2), "unit": "frames/s", "n_gpus": world, "higher_is_better": True,
+            "scaling": "strong", "dtype": "f32", "data": "synthetic, teacher-forced history",
+            "seconds_total": round(elapsed, 4), "seconds_compute": round(t_compute, 4),
+            "seconds_gather": round(elapsed - t_compute, 4),
+            "config": {"workload": f"{F_} frames {H}x{W}x{Cin}, micro-batch {MB}, uint8 frames gathered",
+                       "gathered_bytes": int(F_) * H * W * 3}}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
