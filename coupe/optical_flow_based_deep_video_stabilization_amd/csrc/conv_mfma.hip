@@ -238,16 +238,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
         __syncthreads();
         int buf = 0;
         rd(0, 0, fa0, fb0);
+#ifndef VSTAB_ABL
+#define VSTAB_ABL 0        // tuning-harness ablations (tools/conv_bench): 1 no global loads, 2 no LDS stores, 4 no barrier
+#endif
         for (int kt = kt0; kt + 1 < kt1; ++kt) {
-            load_tile(kt + 1);                 // global -> registers (tile t+1)
+            if (!(VSTAB_ABL & 1)) load_tile(kt + 1);                 // global -> registers (tile t+1)
             rd(buf, 1, fa1, fb1);
             mm(fa0, fb0);                      // k-group 0
             rd(buf, 2, fa0, fb0);
             mm(fa1, fb1);                      // k-group 1
             rd(buf, 3, fa1, fb1);
             mm(fa0, fb0);                      // k-group 2
-            store_tile(buf ^ 1);               // registers -> the other LDS buffer
-            if constexpr (PIN) {
+            if (!(VSTAB_ABL & 2)) store_tile(buf ^ 1);               // registers -> the other LDS buffer
+            if constexpr (PIN && VSTAB_ABL == 0) {
                 __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
 #pragma unroll
                 for (int i = 0; i < NLD; ++i) {
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
             }
-            __syncthreads();
+            if (!(VSTAB_ABL & 4)) __syncthreads();
             rd(buf ^ 1, 0, fa0, fb0);          // first fragments of tile t+1 ...
             mm(fa1, fb1);                      // ... fly under k-group 3 of tile t
             if constexpr (PIN) {
