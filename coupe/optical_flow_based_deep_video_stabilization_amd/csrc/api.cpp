@@ -664,7 +664,8 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
 static std::string conv_kernel_name(ConvTile t, bool vec4)
 {
     const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : "128, 32, 4, 1");
-    return std::string("conv_mfma_kernel<") + shape + (vec4 ? ", true>" : ", false>");
+    const bool dma = conv_uses_lds_dma(t, vec4);
+    return std::string("conv_mfma_kernel<") + shape + (vec4 ? ", true" : ", false") + (dma ? ", true>" : ", false>");
 }
 
 // ------------------------------------------------------------------------- profiling

@@ -19,8 +19,9 @@
 //   * A tile (BM x 32) gathered from the input with 16-byte loads (dword loads for the
 //     27-channel network input), B tile (BN x 32) is a linear 16-byte copy of the
 //     pre-tiled, pre-swizzled packed weights;
-//   * both staged through registers into double-buffered LDS (loads for tile t+1 are in
-//     flight during the MFMAs of tile t, written to LDS before the single barrier per tile);
+//   * both land in double-buffered LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, no staging registers, no
+//     ds_write; issued for tile t+1 before the MFMAs of tile t, one barrier per tile).  The 27-channel
+//     dword-gather variant and the 128x32 tile still stage through registers;
 //   * LDS rows are 128 B with the 16-byte chunk index XORed by ((row>>1)&7): the
 //     ds_read_b128 operand reads of a wave are bank-conflict free;
 //   * K order inside a tile is permuted so that ONE ds_read_b128 feeds four MFMA k-steps:
@@ -37,10 +38,11 @@ namespace vstab {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, int WM, int WN, bool VEC, bool DMA = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
 {
     static_assert(WM * WN == 4, "four waves per workgroup");
+    static_assert(!DMA || VEC, "LDS-DMA staging needs the 16-byte operand path");
     constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
     static_assert(MB >= 1 && NB >= 1, "wave tile");
     constexpr int A_ROWS_V = BM / 32;   // float4 loads per thread per tile (VEC)
@@ -184,6 +186,46 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
         for (int jb = 0; jb < B_PASS; ++jb) *reinterpret_cast<f32x4 *>(dB + jb * 1024) = rb[jb];
     };
 
+    // LDS-DMA staging (DMA = true): `buffer_load_dwordx4 ... lds` writes the tile straight into LDS -- no
+    // staging registers, no ds_write.  One wave instruction lands 64 x 16 B contiguously (8 rows x 128 B) at
+    // a wave-uniform base, so the XOR swizzle moves to the SOURCE: the lane that fills LDS chunk c' of a row
+    // fetches global chunk c' ^ ((row>>1)&7).  Out-of-range lanes (offset 0xC0000000) land as zeros.
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    auto dma_tile = [&](int kt, int buf) {
+        const int ky = c_ky;
+        const int qseg = c_kc * 32;
+        const int qabs0 = c_sg * p.SEG_STRIDE + qseg;
+        {
+            const int kc1 = c_kc + 1;
+            const bool wrap_kc = kc1 == kps;
+            const int sg1 = c_sg + (wrap_kc ? 1 : 0);
+            const bool wrap_sg = sg1 == p.NSEG;
+            c_kc = wrap_kc ? 0 : kc1;
+            c_sg = wrap_sg ? 0 : sg1;
+            c_ky += wrap_sg ? 1 : 0;
+        }
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < A_ROWS_V; ++j) {
+                const int row = (tid >> 3) + 32 * j;
+                const int c = (tid & 7) ^ ((row >> 1) & 7);              // source chunk for this LDS slot
+                const int qs = qseg + c * 4, qa = qabs0 + c * 4;
+                const bool ok = (qs < p.SEG) & ((unsigned)(R[j].y + ky) < (unsigned)p.Hi) & (qa >= R[j].z) & (qa < R[j].w);
+                const unsigned off = ok ? (unsigned)(R[j].x + ky * row_pitch + qa) * 4u : OOB;
+                __attribute__((address_space(3))) void *dst =
+                    (__attribute__((address_space(3))) void *)(sA + buf * (BM * 32) + (32 * j + 8 * wave_u) * 32);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, dst, 16, off, 0, 0, 0);
+            }
+        }
+        const unsigned woff = wvoff0 + (unsigned)kt * (unsigned)(p.Npad * 128);
+#pragma unroll
+        for (int jb = 0; jb < B_PASS; ++jb) {
+            __attribute__((address_space(3))) void *dst =
+                (__attribute__((address_space(3))) void *)(sB + buf * (BN * 32) + jb * 1024 + wave_u * 256);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, dst, 16, woff + jb * 4096, 0, 0, 0);
+        }
+    };
+
     f32x16 acc[MB][NB];
 #pragma unroll
     for (int a = 0; a < MB; ++a)
@@ -232,7 +274,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     constexpr int NST = NLD;                                          // LDS writes per tile
     constexpr bool PIN = (NLD <= G) && (NST <= G);
 
-    if (kt0 < kt1) {
+    if constexpr (DMA) {
+        if (kt0 < kt1) {
+            dma_tile(kt0, 0);
+            __syncthreads();                       // waits vmcnt(0) for the DMA, then the barrier
+            int buf = 0;
+            rd(0, 0, fa0, fb0);
+            for (int kt = kt0; kt + 1 < kt1; ++kt) {
+                dma_tile(kt + 1, buf ^ 1);         // lands in the idle buffer while this tile computes
+                rd(buf, 1, fa1, fb1);
+                mm(fa0, fb0);
+                rd(buf, 2, fa0, fb0);
+                mm(fa1, fb1);
+                rd(buf, 3, fa1, fb1);
+                mm(fa0, fb0);
+                __syncthreads();
+                rd(buf ^ 1, 0, fa0, fb0);
+                mm(fa1, fb1);
+                buf ^= 1;
+            }
+            rd(buf, 1, fa1, fb1);
+            mm(fa0, fb0);
+            rd(buf, 2, fa0, fb0);
+            mm(fa1, fb1);
+            rd(buf, 3, fa1, fb1);
+            mm(fa0, fb0);
+            mm(fa1, fb1);
+        }
+    } else if (kt0 < kt1) {
         load_tile(kt0);
         store_tile(0);
         __syncthreads();
@@ -378,8 +447,21 @@ hipError_t conv_set_attributes()
     VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, true>), 128, 64)
     VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, false>), 128, 64)
     VSTAB_SET((conv_mfma_kernel<128, 32, 4, 1, true>), 128, 32)
+    VSTAB_SET((conv_mfma_kernel<128, 128, 2, 2, true, true>), 128, 128)
+    VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, true, true>), 128, 64)
 #undef VSTAB_SET
     return hipSuccess;
+}
+
+static bool lds_dma_enabled()
+{
+    static const bool on = getenv("VSTAB_NO_LDS_DMA") == nullptr;     // A/B switch for tuning runs
+    return on;
+}
+
+bool conv_uses_lds_dma(ConvTile tile, bool vec4)
+{
+    return vec4 && lds_dma_enabled() && (tile == TILE_128x128 || tile == TILE_128x64);
 }
 
 hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
@@ -402,7 +484,12 @@ hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_
         if (timed) hipExtLaunchKernelGGL(KERNEL, grid, block, LDS, stream, ev_start, ev_stop, 0, p);      \
         else KERNEL<<<grid, block, LDS, stream>>>(p);                                                     \
     } while (0)
-    if (tile == TILE_128x128 && vec4)
+    const bool use_dma = lds_dma_enabled();
+    if (tile == TILE_128x128 && vec4 && use_dma)
+        VSTAB_LAUNCH((conv_mfma_kernel<128, 128, 2, 2, true, true>), (conv_lds_bytes<128, 128>()));
+    else if (tile == TILE_128x64 && vec4 && use_dma)
+        VSTAB_LAUNCH((conv_mfma_kernel<128, 64, 2, 2, true, true>), (conv_lds_bytes<128, 64>()));
+    else if (tile == TILE_128x128 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 128, 2, 2, true>), (conv_lds_bytes<128, 128>()));
     else if (tile == TILE_128x64 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 64, 2, 2, true>), (conv_lds_bytes<128, 64>()));

@@ -59,6 +59,7 @@ enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2 };
 hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t conv_set_attributes();   // raises the dynamic-LDS limit once per process
+bool conv_uses_lds_dma(ConvTile tile, bool vec4);   // which instantiation launch_conv picks (for reports)
 
 // ---------------------------------------------------------------------------------
 // Row-window convolution (conv_rowwin.hip): first layer, one output-row segment of 128

@@ -1,2 +1,7 @@
 cd $GRAFT_REPO_ROOT
-for l in 2 1 5; do for st in 0 16 32 64 0 32; do echo -n "st=$st "; ./tools/conv_bench_st$st $l 8 512 512 -1 -1 20; done; done
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -q -x 2>&1 | tail -4
+for i in 1 2; do
+python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | tr '\n' ' '; echo "(dma)"
+VSTAB_NO_LDS_DMA=1 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | tr '\n' ' '; echo "(reg staging)"
+done
+python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | grep -E "conv|deconv" | cut -c1-100
