@@ -449,6 +449,7 @@ hipError_t conv_set_attributes()
     VSTAB_SET((conv_mfma_kernel<128, 32, 4, 1, true>), 128, 32)
     VSTAB_SET((conv_mfma_kernel<128, 128, 2, 2, true, true>), 128, 128)
     VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, true, true>), 128, 64)
+    VSTAB_SET((conv_mfma_kernel<128, 32, 4, 1, true, true>), 128, 32)
 #undef VSTAB_SET
     return hipSuccess;
 }
@@ -461,7 +462,7 @@ static bool lds_dma_enabled()
 
 bool conv_uses_lds_dma(ConvTile tile, bool vec4)
 {
-    return vec4 && lds_dma_enabled() && (tile == TILE_128x128 || tile == TILE_128x64);
+    return vec4 && lds_dma_enabled();
 }
 
 hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
@@ -489,6 +490,8 @@ hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_
         VSTAB_LAUNCH((conv_mfma_kernel<128, 128, 2, 2, true, true>), (conv_lds_bytes<128, 128>()));
     else if (tile == TILE_128x64 && vec4 && use_dma)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 64, 2, 2, true, true>), (conv_lds_bytes<128, 64>()));
+    else if (tile == TILE_128x32 && vec4 && use_dma)
+        VSTAB_LAUNCH((conv_mfma_kernel<128, 32, 4, 1, true, true>), (conv_lds_bytes<128, 32>()));
     else if (tile == TILE_128x128 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 128, 2, 2, true>), (conv_lds_bytes<128, 128>()));
     else if (tile == TILE_128x64 && vec4)
