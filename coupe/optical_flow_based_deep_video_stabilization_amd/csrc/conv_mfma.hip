@@ -38,6 +38,10 @@ namespace vstab {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef VSTAB_ABL
+#define VSTAB_ABL 0        // tuning-harness ablations (tools/conv_bench): 1 no operand fetch, 2 no LDS stores, 4 no barrier;
+#endif                     // never defined in the product build
+
 template <int BM, int BN, int WM, int WN, bool VEC, bool DMA = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
 {
@@ -281,14 +285,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
             int buf = 0;
             rd(0, 0, fa0, fb0);
             for (int kt = kt0; kt + 1 < kt1; ++kt) {
-                dma_tile(kt + 1, buf ^ 1);         // lands in the idle buffer while this tile computes
+                if (!(VSTAB_ABL & 1)) dma_tile(kt + 1, buf ^ 1);         // lands in the idle buffer while this tile computes
                 rd(buf, 1, fa1, fb1);
                 mm(fa0, fb0);
                 rd(buf, 2, fa0, fb0);
                 mm(fa1, fb1);
                 rd(buf, 3, fa1, fb1);
                 mm(fa0, fb0);
-                __syncthreads();
+                if (!(VSTAB_ABL & 4)) __syncthreads();
                 rd(buf ^ 1, 0, fa0, fb0);
                 mm(fa1, fb1);
                 buf ^= 1;
@@ -307,9 +311,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
         __syncthreads();
         int buf = 0;
         rd(0, 0, fa0, fb0);
-#ifndef VSTAB_ABL
-#define VSTAB_ABL 0        // tuning-harness ablations (tools/conv_bench): 1 no global loads, 2 no LDS stores, 4 no barrier
-#endif
         for (int kt = kt0; kt + 1 < kt1; ++kt) {
             if (!(VSTAB_ABL & 1)) load_tile(kt + 1);                 // global -> registers (tile t+1)
             rd(buf, 1, fa1, fb1);
