@@ -1,6 +1,11 @@
-cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_vgg.py -m gpu -q -x 2>&1 | tail -3
-for i in 1 2; do
-python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | tr '\n' ' '; echo "(asm reads)"
+#!/bin/bash
+# scratch: tile experiments on the GPU box
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+{
+for l in 13 1 12; do
+  for t in 0 1 3; do
+    timeout -k 10 60 tools/conv_bench_abl0 $l 8 512 512 $t -1 30 || exit 1
+  done
 done
-python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | grep -E "conv|deconv" | cut -c1-100
+} > gpurun_out/sweep.log 2>&1
