@@ -84,20 +84,68 @@ bool level_sizes(int H, int W, int *eh, int *ew)
 
 }  // namespace
 
-void choose_split(ConvParams &p, int BN, int BM)
+// Split-K factor from a small cost model instead of a fixed rule.  A launch is `tiles x ks` workgroups on 512 slots
+// (256 CUs x 2 co-resident workgroups); a K-tile costs TAU2 when two workgroups share a CU and TAU1 when one has
+// the CU to itself, every workgroup pays a fixed prologue/epilogue T0, and splitting adds the combine pass and the
+// slab traffic.  Constants calibrated on the cfg1 / B=1 profiles (profiles/README.md, "split-K model").
+static double split_cost_us(long long tiles, int KT, int ks, double slab_bytes, int BN, int BM, int *ks_eff_out)
+{
+    // 64-row tiles cost half a 128-row tile per K-tile when few workgroups run (measured), a little more than half
+    // on a full chip (1.5x the LDS fragment reads per MFMA), so large layers keep the 128-row tile
+    const double TAU2 = 4.2 * (BN >= 128 ? 1.0 : (BN == 64 ? 0.58 : 0.36)) * (BM == 64 ? 0.55 : 1.0);
+    const double TAU1 = 0.51 * TAU2, T0 = 3.0;
+    const double BW = 5.0e6;                                        // bytes per us for the slab traffic
+    const int kts = (KT + ks - 1) / ks, ks_eff = (KT + kts - 1) / kts;
+    const long long blocks = tiles * ks_eff, full = blocks / 512, rem = blocks % 512;
+    double t = (double)full * (kts * TAU2 + T0);
+    if (rem > 256) t += kts * TAU2 + T0;
+    else if (rem > 0) t += kts * TAU1 + T0;
+    if (ks_eff > 1) t += 6.0 + (2.0 * ks_eff + 1.0) * slab_bytes / BW;
+    *ks_eff_out = ks_eff;
+    return t;
+}
+
+static double best_split(const ConvParams &p, int BN, int BM, int *ks_out)
 {
     const int KT = p.KH * p.NSEG * (p.SEGP / 32);
     const long long tiles = (long long)((p.Mmax + BM - 1) / BM) * (p.Npad / BN) * p.nphase;
-    int ks = 1;
-    if (tiles < 400 && (p.N & 3) == 0) {
-        ks = (int)((512 + tiles - 1) / tiles);
-        const int cap = KT / 4 > 1 ? KT / 4 : 1;
-        if (ks > cap) ks = cap;
-        if (ks > 32) ks = 32;
-        const int kts = (KT + ks - 1) / ks;
-        ks = (KT + kts - 1) / kts;
+    int best = 1, dummy;
+    double best_t = split_cost_us(tiles, KT, 1, 0.0, BN, BM, &dummy);
+    *ks_out = 1;
+    if ((p.N & 3) != 0 || tiles >= 2048) return best_t;
+    const double slab = (double)p.Mmax * p.nphase * p.Npad * 4.0;
+    const int cap = std::min(64, std::max(1, KT / 3));
+    for (int ks = 2; ks <= cap; ++ks) {
+        int eff;
+        const double t = split_cost_us(tiles, KT, ks, slab, BN, BM, &eff);
+        if (eff != ks || slab * ks > 768e6) continue;               // only factors that divide the K-tiles evenly enough
+        if (t < best_t * 0.97) { best_t = t; best = ks; }           // prefer the smaller factor on near ties
     }
+    *ks_out = best;
+    return best_t;
+}
+
+void choose_split(ConvParams &p, int BN, int BM)
+{
+    int ks;
+    best_split(p, BN, BM, &ks);
     p.ksplit = ks;
+}
+
+// Tile + split-K for a 128-column layer: small-M layers (one sample, the 1/32 and 1/64 levels) waste most of a
+// 128-row tile and become fixed-overhead / weight-streaming bound; the 64x128 variant halves the MFMA work per K-tile
+// there (B=1 384x512: conv5..deconv5 29-36 us -> 21-27 us each in tools/conv_bench).
+ConvTile choose_tile_split(ConvParams &p, ConvTile tile, bool vec4)
+{
+    const int BN = tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32);
+    int ks128;
+    const double t128 = best_split(p, BN, 128, &ks128);
+    p.ksplit = ks128;
+    if (tile != TILE_128x128 || !vec4 || !conv_uses_lds_dma(tile, vec4)) return tile;
+    int ks64;
+    const double t64 = best_split(p, 128, 64, &ks64);
+    if (t64 < 0.95 * t128) { p.ksplit = ks64; return TILE_64x128; }
+    return tile;
 }
 
 namespace {
@@ -181,7 +229,7 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         p.Mmax = p.ph[0].M;
         pl.vec4[i] = (p.Cs_in % 4 == 0) && (p.SEG % 4 == 0);
         set_ranges(p);
-        choose_split(p, BN);
+        pl.tile[i] = choose_tile_split(p, pl.tile[i], pl.vec4[i]);
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
     }
     // ---- decoder transposed convs: 4 phases of a 2x2-tap conv
@@ -214,7 +262,7 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
             }
         pl.vec4[10 + l] = true;
         set_ranges(p);
-        choose_split(p, BN);
+        pl.tile[10 + l] = choose_tile_split(p, pl.tile[10 + l], true);
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad);
     }
     // ---- predict2 tap table: 1x1 conv concat2 -> 18 (pad 32) columns
@@ -621,12 +669,17 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
     const int cat_buf[4] = {B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2};
     const int lvl_enc[5] = {9, 7, 5, 3, 1};              // encoder stage giving each level's size
     const int tab_src[4] = {B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3}, tab_dst[4] = {B_T6, B_T5, B_T4, B_T3};
+    // One head per level: tap-table GEMM (split-K slabs left uncombined), then ONE launch that sums the slabs, gathers
+    // predict_flowN, folds the upsampled coarser flow in and writes upsample_flowN into the next concat's flow channels.
     auto predict_head = [&](int l, const float *prev, int ph_, int pw_, float *out) -> int {     // l: 0 = predict6 .. 3 = predict3
         ConvParams p = pl.cp[15 + l];
         p.in = buf(tab_src[l]); p.out = buf(tab_dst[l]);
         p.wpk = dw + ctx->pred_w[l]; p.bias = dw + ctx->tab_b; p.partial = buf(B_PARTIAL);
-        HIP_TRY(ctx, launch_conv(p, pl.tile[15 + l], true, stream));
-        HIP_TRY(ctx, launch_predict_gather(buf(tab_dst[l]), B, p.Hi, p.Wi, dw + ctx->pred_b[l], prev, ph_, pw_, out, stream));
+        HIP_TRY(ctx, launch_conv(p, pl.tile[15 + l], true, stream, nullptr, nullptr, false));
+        const float *src = p.ksplit > 1 ? p.partial : p.out;
+        const int oh = pl.eh[lvl_enc[l + 1]], ow = pl.ew[lvl_enc[l + 1]];      // the finer level the flow is upsampled to
+        HIP_TRY(ctx, launch_predict_up(src, p.ksplit, (long long)p.Mmax * p.Npad, B, p.Hi, p.Wi, dw + ctx->pred_b[l], prev, ph_, pw_,
+                                       out, ctx->up[l], buf(cat_buf[l]), oh, ow, CONCAT_CS[l], CONCAT_C[l] - 2, stream));
         return VSTAB_OK;
     };
     { const int rc = predict_head(0, nullptr, 0, 0, pf6); if (rc != VSTAB_OK) return rc; }
@@ -641,10 +694,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         HIP_TRY(ctx, launch_conv(p, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l)));
         ctx->prof_kernel[10 + l] = conv_kernel_name(pl.tile[10 + l], true);
         const int ph = pl.eh[lvl_enc[l]], pw = pl.ew[lvl_enc[l]];          // coarser level
-        const int h = pl.eh[lvl_enc[l + 1]], w = pl.ew[lvl_enc[l + 1]];    // this level
-        HIP_TRY(ctx, launch_upflow(pfs[l], B, ph, pw, ctx->up[l], buf(cat_buf[l]), h, w, CONCAT_CS[l], CONCAT_C[l] - 2, stream));
         if (l < 3) { const int rc = predict_head(l + 1, pfs[l], ph, pw, pfs[l + 1]); if (rc != VSTAB_OK) return rc; }
-        (void)h; (void)w;
     }
     // full-resolution head (model.py:882-887)
     {
@@ -663,7 +713,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
 
 static std::string conv_kernel_name(ConvTile t, bool vec4)
 {
-    const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : "128, 32, 4, 1");
+    const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : (t == TILE_64x128 ? "64, 128, 1, 4" : "128, 32, 4, 1"));
     const bool dma = conv_uses_lds_dma(t, vec4);
     return std::string("conv_mfma_kernel<") + shape + (vec4 ? ", true" : ", false") + (dma ? ", true>" : ", false>");
 }
@@ -819,7 +869,7 @@ bool fill_plain_conv(ConvParams &p, ConvTile &tile, bool &vec4, int B, int Hi, i
     if (!vec4 && tile != TILE_128x64) return false;        // the dword-gather variant exists for 128x64 only
     if ((long long)B * Hi * Wi * cs_in * 4 >= 0x80000000LL || (long long)B * Ho * Wo * cs_out * 4 >= 0x80000000LL) return false;
     set_ranges(p);
-    choose_split(p, BN);
+    tile = choose_tile_split(p, tile, vec4);
     return true;
 }
 
@@ -1004,6 +1054,17 @@ extern "C" int vstab_axpby(const float *x, float a, const float *y, float b, flo
 {
     if (!x || !y || !out || n < 1) return fail(nullptr, VSTAB_E_STATE, "axpby: bad argument");
     HIP_TRY(nullptr, launch_axpby(x, a, y, b, out, n, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_flow_medfilt(const float *flow, int B, int h, int w, int kh, int kw, int kc, float *out, void *stream)
+{
+    if (!flow || !out) return fail(nullptr, VSTAB_E_STATE, "flow_medfilt: NULL buffer");
+    if (flow == out) return fail(nullptr, VSTAB_E_STATE, "flow_medfilt: in-place filtering is not supported");
+    if (B < 1 || h < 1 || w < 1) return fail(nullptr, VSTAB_E_SHAPE, "flow_medfilt: bad shape");
+    if (kh < 1 || kw < 1 || kc < 1 || !(kh & 1) || !(kw & 1) || !(kc & 1) || kh > 31 || kw > 31 || kc > 5)
+        return fail(nullptr, VSTAB_E_SHAPE, "flow_medfilt: kernel sizes must be odd, kh,kw <= 31, kc <= 5");
+    HIP_TRY(nullptr, launch_flow_medfilt(flow, B, h, w, kh, kw, kc, out, (hipStream_t)stream));
     return VSTAB_OK;
 }
 

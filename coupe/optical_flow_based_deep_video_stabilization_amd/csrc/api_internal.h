@@ -50,6 +50,7 @@ void vstab_nldf_free(void *nldf);     // nldf_api.cpp
 
 // ---- helpers defined in api.cpp
 void choose_split(vstab::ConvParams &p, int BN, int BM = 128);
+vstab::ConvTile choose_tile_split(vstab::ConvParams &p, vstab::ConvTile tile, bool vec4);
 void set_layout(vstab::ConvParams &p, const vstab::KLayout &L);
 void set_ranges(vstab::ConvParams &p);
 const vstab_tensor *find(const vstab_tensor *t, int n, const std::string &name);

@@ -179,6 +179,60 @@ hipError_t launch_axpby(const float *x, float a, const float *y, float b, float 
     return hipGetLastError();
 }
 
+// scipy.signal.medfilt(np.squeeze(of), k) of evaluate_medianNma (main_flownetS_pyramid.py:809): an order filter
+// over a kh x kw x kc window of the [h,w,2] field -- the window also spans the CHANNEL axis (the reference passes
+// the scalar 5, i.e. 5x5x5) -- with zero padding on every axis; the output is element n/2 of the sorted window.
+// One thread per output element; the window sits in LDS (tile + halo) and the median is found by rank counting
+// (the value v with #{w < v} <= n/2 < #{w <= v}), which needs no sorting storage and is exact.
+constexpr int MED_T = 16;                       // output tile edge
+__global__ __launch_bounds__(256) void medfilt_kernel(const float *__restrict__ in, int h, int w, int kh, int kw, int kc,
+                                                      float *__restrict__ out)
+{
+    extern __shared__ float tile[];             // [(MED_T+kh-1)][(MED_T+kw-1)][2]
+    const int ry = kh >> 1, rx = kw >> 1, rc = kc >> 1;
+    const int th = MED_T + kh - 1, tw = MED_T + kw - 1;
+    const int y0 = blockIdx.y * MED_T - ry, x0 = blockIdx.x * MED_T - rx;
+    const float *b = in + (long long)blockIdx.z * h * w * 2;
+    for (int i = threadIdx.x; i < th * tw; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const int y = y0 + ty, x = x0 + tx;
+        f32x2 v = {0.f, 0.f};
+        if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) v = *reinterpret_cast<const f32x2 *>(b + ((long long)y * w + x) * 2);
+        tile[2 * i] = v.x; tile[2 * i + 1] = v.y;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+    const int y = blockIdx.y * MED_T + ly, x = blockIdx.x * MED_T + lx;
+    if (y >= h || x >= w) return;
+    const int n = kh * kw * kc, target = n >> 1;
+    for (int c = 0; c < 2; ++c) {
+        // window value number i: (dy, dx, dc); a tap outside the two channels is a padded zero
+        auto val = [&](int i) -> float {
+            const int dc = i % kc, r = i / kc;
+            const int dx = r % kw, dy = r / kw;
+            const int cc = c + dc - rc;
+            return (unsigned)cc < 2u ? tile[((ly + dy) * tw + lx + dx) * 2 + cc] : 0.f;
+        };
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float v = val(i);
+            int less = 0, leq = 0;
+            for (int j = 0; j < n; ++j) { const float u = val(j); less += u < v; leq += u <= v; }
+            if (less <= target && target < leq) { res = v; break; }
+        }
+        out[(((long long)blockIdx.z * h + y) * w + x) * 2 + c] = res;
+    }
+}
+
+hipError_t launch_flow_medfilt(const float *flow, int B, int h, int w, int kh, int kw, int kc, float *out, hipStream_t stream)
+{
+    if (kh < 1 || kw < 1 || kc < 1 || !(kh & 1) || !(kw & 1) || !(kc & 1) || kh > 31 || kw > 31 || kc > 5) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(MED_T + kh - 1) * (MED_T + kw - 1) * 2 * sizeof(float);
+    dim3 grid((unsigned)((w + MED_T - 1) / MED_T), (unsigned)((h + MED_T - 1) / MED_T), (unsigned)B);
+    medfilt_kernel<<<grid, dim3(256), lds, stream>>>(flow, h, w, kh, kw, kc, out);
+    return hipGetLastError();
+}
+
 // out[b,:,:,c] = mean over (h,w) of flow[b,:,:,c]  (main_flownetS_pyramid_highTV_noBBloss.py:629): one workgroup
 // per sample, wavefront-shuffle + LDS reduction, then the same workgroup fills the field.
 __global__ __launch_bounds__(256) void mean_fill_kernel(const float *__restrict__ flow, int hw, float *__restrict__ out)

@@ -409,9 +409,31 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const ConvParams p)
     const ConvPhase ph = p.ph[phase];
     if (m >= ph.M) return;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < p.ksplit; ++k) {
-        const float *src = p.partial + (((long long)(phase * p.ksplit + k) * p.Mmax + m) * p.Npad + c4 * 4);
-        s += *reinterpret_cast<const f32x4 *>(src);
+    const float *src = p.partial + (((long long)(phase * p.ksplit) * p.Mmax + m) * p.Npad + c4 * 4);
+    const long long slab = (long long)p.Mmax * p.Npad;
+    int k = 0;
+    for (; k + 8 <= p.ksplit; k += 8) {           // eight slab loads in flight, added in slab order
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (k + u) * slab);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    if (k + 4 <= p.ksplit) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (k + u) * slab);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u];
+        k += 4;
+    }
+    if (k < p.ksplit) {                           // up to three left: load all, add in order
+        f32x4 v[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) v[u] = k + u < p.ksplit ? *reinterpret_cast<const f32x4 *>(src + (k + u) * slab) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (k + u < p.ksplit) s += v[u];
     }
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + c4 * 4);
     s += bv;
@@ -451,6 +473,7 @@ hipError_t conv_set_attributes()
     VSTAB_SET((conv_mfma_kernel<128, 128, 2, 2, true, true>), 128, 128)
     VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, true, true>), 128, 64)
     VSTAB_SET((conv_mfma_kernel<128, 32, 4, 1, true, true>), 128, 32)
+    VSTAB_SET((conv_mfma_kernel<64, 128, 1, 4, true, true>), 64, 128)
 #undef VSTAB_SET
     return hipSuccess;
 }
@@ -466,10 +489,11 @@ bool conv_uses_lds_dma(ConvTile tile, bool vec4)
     return vec4 && lds_dma_enabled();
 }
 
-hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
+hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
+                       bool combine)
 {
-    const int BM = 128;
-    const int BN = tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32);
+    const int BM = tile == TILE_64x128 ? 64 : 128;
+    const int BN = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : (tile == TILE_128x64 ? 64 : 32);
     if (p.in_bytes >= 0x80000000u || p.w_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.Npad % BN != 0 || p.SEGP % 32 != 0 || p.SEGP < p.SEG || p.NSEG < 1 || p.ksplit < 1 || p.nphase < 1 || p.nphase > 4)
         return hipErrorInvalidValue;
@@ -493,6 +517,8 @@ hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_
         VSTAB_LAUNCH((conv_mfma_kernel<128, 64, 2, 2, true, true>), (conv_lds_bytes<128, 64>()));
     else if (tile == TILE_128x32 && vec4 && use_dma)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 32, 4, 1, true, true>), (conv_lds_bytes<128, 32>()));
+    else if (tile == TILE_64x128 && vec4)
+        VSTAB_LAUNCH((conv_mfma_kernel<64, 128, 1, 4, true, true>), (conv_lds_bytes<64, 128>()));
     else if (tile == TILE_128x128 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 128, 2, 2, true>), (conv_lds_bytes<128, 128>()));
     else if (tile == TILE_128x64 && vec4)
@@ -506,7 +532,7 @@ hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_
 #undef VSTAB_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (p.ksplit > 1) {
+    if (p.ksplit > 1 && combine) {
         const long long total = (long long)p.Mmax * (p.N >> 2) * p.nphase;
         splitk_combine_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(p);
         e = hipGetLastError();

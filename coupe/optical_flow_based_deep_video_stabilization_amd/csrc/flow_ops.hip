@@ -50,92 +50,120 @@ __device__ __forceinline__ f32x2 sample_flow_legacy(const float *f, int n, int h
 // SOURCE pixel s, the tap table T[s][tap][o] = sum_c x[s][c] W[tap][c][o] (a 1x1 conv to 18
 // columns), and this kernel gathers out[y,x,o] = b[o] + sum_{dy,dx} T[(y+dy-1, x+dx-1)][3dy+dx][o]
 // over the in-image taps: the same sum in a different association.
+//
+// One launch per pyramid level does the whole head: it also sums the split-K slabs of the tap table (the MFMA
+// launch skips its combine pass: `src` = `ks` slabs `slab_stride` floats apart, or the finished table with ks = 1)
+// and applies upsample_flowN -- the 2->2 channel 4x4 stride-2 SAME transposed conv + bias (model.py:852;
+// o = 2*i + k - 1  =>  for output o the taps are k = (o+1)&1 and k+2, i = (o+1-k)/2) -- to the flow it has just
+// produced, writing (u, v, 0, 0) into the next concat's flow channels so its two pad channels are zero every call.
+// A workgroup owns a 16x16 tile of flow pixels, computes them plus a one-pixel halo into LDS (the halo is
+// recomputed, not exchanged), stores the tile, then emits the 32x32 upsampled outputs that depend on it: three
+// dependent launches (combine, gather, upsample) become one.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void predict_gather_kernel(const float *__restrict__ T, int B, int h, int w,
-                                                             const float *__restrict__ bias2, const float *__restrict__ prev,
-                                                             int ph, int pw, float sy, float sx, float *__restrict__ out)
+constexpr int PU_T = 8;                         // flow pixels per workgroup edge
+constexpr int PU_H = PU_T + 2;                  // + halo
+constexpr int PU_S = PU_T + 4;                  // + the source pixels the halo's 3x3 taps reach
+__global__ __launch_bounds__(256) void predict_up_kernel(const float *__restrict__ src, int ks, long long slab_stride, int h, int w,
+                                                         const float *__restrict__ bias2, const float *__restrict__ prev,
+                                                         int ph, int pw, float sy, float sx, float *__restrict__ out,
+                                                         UpflowW W, float *__restrict__ concat, int oh, int ow, int Cs, int c_off)
 {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)B * h * w;
-    if (idx >= total) return;
-    const int n = (int)(idx / (h * w));
-    const int rem = (int)(idx - (long long)n * h * w);
-    const int y = rem / w, x = rem - y * w;
-    float a0 = bias2[0], a1 = bias2[1];
-    const float *Tn = T + (long long)n * h * w * 32;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-        const int iy = y + dy - 1;
-        if (iy < 0 || iy >= h) continue;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int ix = x + dx - 1;
-            if (ix < 0 || ix >= w) continue;
-            const f32x2 t = *reinterpret_cast<const f32x2 *>(Tn + ((long long)iy * w + ix) * 32 + (dy * 3 + dx) * 2);
-            a0 += t.x;
-            a1 += t.y;
+    __shared__ float tab[PU_S * PU_S * 18];      // combined tap-table entries of the source pixels (18 used columns)
+    __shared__ f32x2 tile[PU_H * PU_H];
+    const int n = blockIdx.z, y0 = blockIdx.y * PU_T, x0 = blockIdx.x * PU_T;
+    const float *Tn = src + (long long)n * h * w * 32;
+    // stage A: sum the split-K slabs, one (source pixel, column pair) per work item -- PU_S^2 * 9 independent items,
+    // four slab loads in flight each, added in slab order (the combine pass's association)
+    for (int i = threadIdx.x; i < PU_S * PU_S * 9; i += 256) {
+        const int s = i / 9, t = i - s * 9;
+        const int y = y0 - 2 + s / PU_S, x = x0 - 2 + s % PU_S;
+        float t0 = 0.f, t1 = 0.f;
+        if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) {
+            const float *tp = Tn + ((long long)y * w + x) * 32 + t * 2;
+            int k = 0;
+            for (; k + 4 <= ks; k += 4) {
+                const f32x2 v0 = *reinterpret_cast<const f32x2 *>(tp + (k + 0) * slab_stride);
+                const f32x2 v1 = *reinterpret_cast<const f32x2 *>(tp + (k + 1) * slab_stride);
+                const f32x2 v2 = *reinterpret_cast<const f32x2 *>(tp + (k + 2) * slab_stride);
+                const f32x2 v3 = *reinterpret_cast<const f32x2 *>(tp + (k + 3) * slab_stride);
+                t0 += v0.x; t1 += v0.y; t0 += v1.x; t1 += v1.y; t0 += v2.x; t1 += v2.y; t0 += v3.x; t1 += v3.y;
+            }
+            for (; k < ks; ++k) {
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(tp + k * slab_stride);
+                t0 += v.x; t1 += v.y;
+            }
         }
+        tab[s * 18 + t * 2] = t0;
+        tab[s * 18 + t * 2 + 1] = t1;
     }
-    if (prev) {
-        const f32x2 u = sample_flow_legacy(prev, n, ph, pw, y, x, sy, sx);
-        a0 = (a0 + u.x) + u.x;
-        a1 = (a1 + u.y) + u.y;
+    __syncthreads();
+    // stage B: predict_flowN of the tile + halo: bias + the in-image taps in (dy, dx) order, then the fold with the
+    // upsampled coarser flow
+    for (int i = threadIdx.x; i < PU_H * PU_H; i += 256) {
+        const int ty = i / PU_H, tx = i - ty * PU_H;
+        const int y = y0 - 1 + ty, x = x0 - 1 + tx;
+        f32x2 o = {0.f, 0.f};
+        if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) {
+            float a0 = bias2[0], a1 = bias2[1];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int iy = y + dy - 1;
+                if (iy < 0 || iy >= h) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int ix = x + dx - 1;
+                    if (ix < 0 || ix >= w) continue;
+                    const float *e = tab + ((ty + dy) * PU_S + tx + dx) * 18 + (dy * 3 + dx) * 2;
+                    a0 += e[0];
+                    a1 += e[1];
+                }
+            }
+            if (prev) {
+                const f32x2 u = sample_flow_legacy(prev, n, ph, pw, y, x, sy, sx);
+                a0 = (a0 + u.x) + u.x;
+                a1 = (a1 + u.y) + u.y;
+            }
+            o.x = a0; o.y = a1;
+            if (ty >= 1 && ty <= PU_T && tx >= 1 && tx <= PU_T) reinterpret_cast<f32x2 *>(out)[((long long)n * h + y) * w + x] = o;
+        }
+        tile[i] = o;
     }
-    f32x2 o; o.x = a0; o.y = a1;
-    reinterpret_cast<f32x2 *>(out)[idx] = o;
+    __syncthreads();
+    // stage C: upsample_flowN of the tile
+    for (int i = threadIdx.x; i < 4 * PU_T * PU_T; i += 256) {
+        const int oy = 2 * y0 + i / (2 * PU_T), ox = 2 * x0 + (i & (2 * PU_T - 1));
+        if (oy >= oh || ox >= ow) continue;
+        float u = W.b[0], v = W.b[1];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ky = ((oy + 1) & 1) + 2 * a;
+            const int iy = (oy + 1 - ky) >> 1;
+            if (iy < 0 || iy >= h) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int kx = ((ox + 1) & 1) + 2 * b;
+                const int ix = (ox + 1 - kx) >> 1;
+                if (ix < 0 || ix >= w) continue;
+                const f32x2 f = tile[(iy - y0 + 1) * PU_H + (ix - x0 + 1)];
+                const float *wk = W.w + (ky * 4 + kx) * 4;     // [co][ci]
+                u = fmaf(f.x, wk[0], u); u = fmaf(f.y, wk[1], u);
+                v = fmaf(f.x, wk[2], v); v = fmaf(f.y, wk[3], v);
+            }
+        }
+        f32x4 o = {u, v, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(concat + (((long long)n * oh + oy) * ow + ox) * Cs + c_off) = o;
+    }
 }
 
-hipError_t launch_predict_gather(const float *T, int B, int h, int w, const float *bias2, const float *prev, int ph, int pw,
-                                 float *out, hipStream_t stream)
+hipError_t launch_predict_up(const float *src, int ks, long long slab_stride, int B, int h, int w, const float *bias2,
+                             const float *prev, int ph, int pw, float *out, const UpflowW &W, float *concat, int oh, int ow,
+                             int Cs, int c_off, hipStream_t stream)
 {
-    const long long total = (long long)B * h * w;
+    if ((Cs & 3) || (c_off & 3) || c_off + 4 > Cs || ks < 1 || oh > 2 * h || ow > 2 * w) return hipErrorInvalidValue;
     const float sy = prev ? (float)ph / (float)h : 0.f, sx = prev ? (float)pw / (float)w : 0.f;
-    predict_gather_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(T, B, h, w, bias2, prev, ph, pw, sy, sx, out);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------
-// upsample_flowN: 2->2 channel 4x4 stride-2 SAME transposed conv + bias (model.py:852).
-// o = 2*i + k - 1  =>  for output o the taps are k = (o+1)&1 and k+2, i = (o+1-k)/2.
-// Writes (u, v, 0, 0) so the two pad channels of the concat pixel are zero every call.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void upflow_kernel(const float *__restrict__ flow, int B, int h, int w, UpflowW W,
-                                                     float *__restrict__ concat, int oh, int ow, int Cs, int c_off)
-{
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)B * oh * ow;
-    if (idx >= total) return;
-    const int n = (int)(idx / (oh * ow));
-    const int rem = (int)(idx - (long long)n * oh * ow);
-    const int oy = rem / ow, ox = rem - oy * ow;
-    float u = W.b[0], v = W.b[1];
-    const f32x2 *fb = reinterpret_cast<const f32x2 *>(flow) + (long long)n * h * w;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int ky = ((oy + 1) & 1) + 2 * a;
-        const int iy = (oy + 1 - ky) >> 1;
-        if (iy < 0 || iy >= h) continue;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int kx = ((ox + 1) & 1) + 2 * b;
-            const int ix = (ox + 1 - kx) >> 1;
-            if (ix < 0 || ix >= w) continue;
-            const f32x2 f = fb[iy * w + ix];
-            const float *wk = W.w + (ky * 4 + kx) * 4;     // [co][ci]
-            u = fmaf(f.x, wk[0], u); u = fmaf(f.y, wk[1], u);
-            v = fmaf(f.x, wk[2], v); v = fmaf(f.y, wk[3], v);
-        }
-    }
-    f32x4 o = {u, v, 0.f, 0.f};
-    *reinterpret_cast<f32x4 *>(concat + idx * Cs + c_off) = o;
-}
-
-hipError_t launch_upflow(const float *flow, int B, int h, int w, const UpflowW &W, float *concat, int oh, int ow, int Cs,
-                         int c_off, hipStream_t stream)
-{
-    if ((Cs & 3) || (c_off & 3) || c_off + 4 > Cs) return hipErrorInvalidValue;
-    const long long total = (long long)B * oh * ow;
-    upflow_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(flow, B, h, w, W, concat, oh, ow, Cs, c_off);
+    dim3 grid((unsigned)((w + PU_T - 1) / PU_T), (unsigned)((h + PU_T - 1) / PU_T), (unsigned)B);
+    predict_up_kernel<<<grid, dim3(256), 0, stream>>>(src, ks, slab_stride, h, w, bias2, prev, ph, pw, sy, sx, out, W, concat, oh, ow,
+                                                      Cs, c_off);
     return hipGetLastError();
 }
 

@@ -52,12 +52,13 @@ struct ConvParams {
     ConvPhase ph[4];
 };
 
-enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2 };
+enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 = 3 };
 
 // Launch the implicit-GEMM kernel (and the split-K combine when p.ksplit > 1).
 // ev_start/ev_stop (optional) are recorded immediately around the GEMM kernel itself.
+// combine = false: a split-K launch leaves its slabs in p.partial for the consumer to sum (launch_predict_up)
 hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream,
-                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool combine = true);
 hipError_t conv_set_attributes();   // raises the dynamic-LDS limit once per process
 bool conv_uses_lds_dma(ConvTile tile, bool vec4);   // which instantiation launch_conv picks (for reports)
 
@@ -94,17 +95,15 @@ void pack_conv_rowwin(const float *W, const double *scale, int kh, int kw, int c
 // ---------------------------------------------------------------------------------
 // Small VALU kernels of the flow pyramid and the warp.
 // ---------------------------------------------------------------------------------
-// predict_flowN from its tap table T[B,h,w,32] (T[.., tap*2 + o] = sum_c x[.., c] W[tap][c][o], computed by
-// the MFMA kernel as a 1x1 conv) + bias [+ (.. + u) + u, u = legacy-bilinear upsample of the coarser
-// flow]; model.py:848,856-857,865-866,874-875
-hipError_t launch_predict_gather(const float *T, int B, int h, int w, const float *bias2, const float *prev,
-                                 int ph, int pw, float *out, hipStream_t stream);
-
-// upsample_flowN = 4x4 s2 SAME transposed conv 2->2 + bias, written as (u, v, 0, 0) into
-// the last four floats of the concat pixel; model.py:852,861,870,879
+// predict_flowN + upsample_flowN in one launch.  src: the tap table T[B,h,w,32] (T[.., tap*2 + o] = sum_c x[.., c]
+// W[tap][c][o], computed by the MFMA kernel as a 1x1 conv) or its `ks` split-K slabs `slab_stride` floats apart;
+// out = gather(T) + bias [+ (.. + u) + u, u = legacy-bilinear upsample of the coarser flow `prev`]
+// (model.py:848,856-857,865-866,874-875); then the 4x4 s2 SAME transposed conv 2->2 + bias of `out`, written as
+// (u, v, 0, 0) into the four floats at c_off of the next level's concat pixel (model.py:852,861,870,879).
 struct UpflowW { float w[64]; float b[2]; };   // w[ky][kx][co][ci]
-hipError_t launch_upflow(const float *flow, int B, int h, int w, const UpflowW &W, float *concat,
-                         int oh, int ow, int Cs, int c_off, hipStream_t stream);
+hipError_t launch_predict_up(const float *src, int ks, long long slab_stride, int B, int h, int w, const float *bias2,
+                             const float *prev, int ph, int pw, float *out, const UpflowW &W, float *concat, int oh, int ow,
+                             int Cs, int c_off, hipStream_t stream);
 
 // predict_flow2 (model.py:882-887) from the per-source-pixel tap table T[B,h2,w2,32]
 // (T[.., tap*2 + o] = sum_c concat2[.., c] * W[tap][c][o]) and pf3.
@@ -146,6 +145,7 @@ hipError_t launch_quantise_output(const float *warped, long long npix, unsigned 
 hipError_t launch_flow_box_blur(const float *flow, int B, int h, int w, int k, float *tmp, float *out, hipStream_t stream);
 hipError_t launch_axpby(const float *x, float a, const float *y, float b, float *out, long long n, hipStream_t stream);
 hipError_t launch_flow_mean_fill(const float *flow, int B, int h, int w, float *out, hipStream_t stream);
+hipError_t launch_flow_medfilt(const float *flow, int B, int h, int w, int kh, int kw, int kc, float *out, hipStream_t stream);
 
 // NLDF head helpers (nldf_ops.hip)
 hipError_t launch_contrast(float *buf, int B, int H, int W, int C, int Cs, int c_dst, hipStream_t stream);

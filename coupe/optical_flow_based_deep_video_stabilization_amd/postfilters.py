@@ -1,7 +1,8 @@
 """Flow post-filters the reference's other evaluators wrap around the same hot path:
 `evaluate_blurNma` (main_flownetS_pyramid.py:582-700: 75x75 box blur of predict_flow2 blended with a temporal
-EMA) and the mean-global-flow variant (main_flownetS_pyramid_highTV_noBBloss.py:629-631, 679-685).  The
-RANSAC homography evaluator (main:735-743) needs cv2.findHomography and stays out of scope."""
+EMA), `evaluate_medianNma` (:703-821: scipy.signal.medfilt of the flow, same EMA) and the mean-global-flow variant
+(main_flownetS_pyramid_highTV_noBBloss.py:629-631, 679-685).  The RANSAC homography evaluator (main:735-743)
+needs cv2.findHomography and stays out of scope."""
 from __future__ import annotations
 
 import torch
@@ -38,6 +39,23 @@ def axpby(a: float, x, b: float, y):
     return out
 
 
+def medfilt_flow(flow, kernel_size=5):
+    """scipy.signal.medfilt(np.squeeze(of), kernel_size) per sample (main_flownetS_pyramid.py:809).  As in scipy a
+    scalar applies to EVERY axis of the [h,w,2] field, the channel axis included -- so the reference's `5` is a
+    5x5x5 window of which 75 taps are padded zeros and the result is identically zero; pass (5, 5, 1) for the
+    per-channel 5x5 median its author presumably meant."""
+    f = _flow(flow)
+    B, h, w, _ = f.shape
+    ks = (int(kernel_size),) * 3 if isinstance(kernel_size, int) else tuple(int(k) for k in kernel_size)
+    if len(ks) != 3:
+        raise ValueError("kernel_size must be a scalar or (kh, kw, kc)")
+    out = torch.empty_like(f)
+    with torch.cuda.device(f.device):
+        _lib.check(_lib.lib().vstab_flow_medfilt(f.data_ptr(), B, h, w, ks[0], ks[1], ks[2], out.data_ptr(),
+                                                 runtime.stream_ptr()))
+    return out
+
+
 def mean_flow(flow):
     """ones_like(flow_c) * reduce_mean(flow_c, axis=[1,2]) per channel: the global-translation flow (:629)."""
     f = _flow(flow)
@@ -61,4 +79,21 @@ class BlurEmaFilter:
             self.prev = torch.zeros_like(of)
         out = axpby(self.alpha, box_blur_flow(of, self.k), 1.0 - self.alpha, self.prev)
         self.prev = axpby(self.alpha, self.prev, 1.0 - self.alpha, of)
+        return out
+
+
+class MedianEmaFilter(BlurEmaFilter):
+    """evaluate_medianNma's loop (main_flownetS_pyramid.py:807-815): warp flow = 0.9*medfilt(of) + 0.1*prevof (:761),
+    then prevof = 0.9*prevof + 0.1*medfilt(of) (:815) -- unlike the blur variant the EMA runs on the FILTERED flow."""
+
+    def __init__(self, kernel_size=5, alpha: float = 0.9):
+        super().__init__(k=kernel_size, alpha=alpha)
+
+    def __call__(self, of):
+        of = _flow(of)
+        if self.prev is None:
+            self.prev = torch.zeros_like(of)
+        med = medfilt_flow(of, self.k)
+        out = axpby(self.alpha, med, 1.0 - self.alpha, self.prev)
+        self.prev = axpby(self.alpha, self.prev, 1.0 - self.alpha, med)
         return out

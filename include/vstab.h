@@ -206,6 +206,10 @@ VSTAB_API int vstab_quantise_output(const float *warped, long long npix, uint8_t
 VSTAB_API int vstab_flow_box_blur(const float *flow, int B, int h, int w, int k, float *tmp, float *out, void *stream);
 /* out = a*x + b*y elementwise (0.9*smooth + 0.1*prev, :643; prev = 0.9*prev + 0.1*cur, :695). */
 VSTAB_API int vstab_axpby(const float *x, float a, const float *y, float b, float *out, long long n, void *stream);
+/* scipy.signal.medfilt(np.squeeze(of), k) (evaluate_medianNma, main_flownetS_pyramid.py:809): order filter over a
+ * kh x kw x kc window of each [h,w,2] field -- kc spans the channel axis; the reference's scalar 5 means 5x5x5 --
+ * zero padded on all axes, output = element n/2 of the sorted window.  Odd sizes, kh,kw <= 31, kc <= 5; out != flow. */
+VSTAB_API int vstab_flow_medfilt(const float *flow, int B, int h, int w, int kh, int kw, int kc, float *out, void *stream);
 /* out[b,:,:,c] = mean over the image of flow[b,:,:,c] (main_flownetS_pyramid_highTV_noBBloss.py:629). */
 VSTAB_API int vstab_flow_mean_fill(const float *flow, int B, int h, int w, float *out, void *stream);
 

@@ -501,8 +501,11 @@ def cv_resize_u8(src: np.ndarray, dh: int, dw: int) -> np.ndarray:
     return np.clip(v, 0, 255).astype(np.uint8)
 
 
-def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32):
-    """The loop of evaluate_originalSize (main:540-630) on a clip [T,H,W,3] uint8 BGR -> stabilised uint8 clip."""
+def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32, teacher=None):
+    """The loop of evaluate_originalSize (main:540-630) on a clip [T,H,W,3] uint8 BGR -> stabilised uint8 clip.
+    `teacher` ([T,H,W,3] uint8, another implementation's outputs): if given, frame i is still computed here but the
+    HISTORY later frames read is the teacher's frame i -- a per-frame check that cannot drift (the free-running loop
+    amplifies a one-LSB difference through the warp's out-of-range mask within a few frames)."""
     T, H, W, _ = frames_bgr_u8.shape
     nh, nw = net_hw
     lags = (31, 23, 15, 7, 4, 3, 2, 1)                                             # main:553
@@ -522,6 +525,8 @@ def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32):
         _, _, warped = stabilise_originalsize(cur, frame_f, weights, dtype)        # main:569
         total[i] = (warped[0].numpy().astype(np.float64) * 255.0)[..., ::-1]       # main:625
         outs.append(np.clip(np.trunc(total[i]), 0, 255).astype(np.uint8))          # main:630
+        if teacher is not None:
+            total[i] = teacher[i].astype(np.float64)
     return np.stack(outs)
 
 
@@ -531,6 +536,19 @@ def box_blur_flow(flow, k: int = 75, dtype=torch.float64):
     f = _t(flow, dtype).permute(0, 3, 1, 2)
     w = torch.full((2, 1, k, k), 1.0 / (k * k), dtype=dtype)
     return F.conv2d(f, w, padding=(k - 1) // 2, groups=2).permute(0, 2, 3, 1)
+
+
+def medfilt_flow(flow, kernel_size=5):
+    """scipy.signal.medfilt(np.squeeze(of), kernel_size) per sample (main_flownetS_pyramid.py:809), restated without
+    scipy: zero-pad every axis of the [h,w,2] field (channels too: a scalar size applies to all three axes), sort
+    each kh*kw*kc window, take element n//2.  tests/test_oracle_kat.py pins this against scipy itself."""
+    f = _t(flow, torch.float64)
+    ks = (int(kernel_size),) * 3 if isinstance(kernel_size, int) else tuple(int(k) for k in kernel_size)
+    kh, kw, kc = ks
+    B, h, w, C = f.shape
+    p = F.pad(f, (kc // 2, kc // 2, kw // 2, kw // 2, kh // 2, kh // 2))          # pads last dim first: c, w, h
+    win = p.unfold(1, kh, 1).unfold(2, kw, 1).unfold(3, kc, 1).reshape(B, h, w, C, kh * kw * kc)
+    return win.sort(dim=-1).values[..., (kh * kw * kc) // 2]
 
 
 def mean_flow(flow, dtype=torch.float64):

@@ -36,3 +36,31 @@ def test_mean_flow_and_axpby_and_ema():
         assert float((got.double().cpu() - ref).abs().max()) <= 1e-5
     with pytest.raises(ValueError):
         pf.box_blur_flow(torch.zeros(1, 4, 4, 2, device="cuda"), 4)         # even k
+
+
+@pytest.mark.parametrize("B,h,w,ks", [(1, 382, 510, 5), (2, 45, 37, (5, 5, 1)), (1, 20, 33, (3, 7, 3)), (1, 17, 16, (1, 1, 1)),
+                                      (1, 3, 4, (5, 5, 1)), (1, 40, 40, (9, 3, 1))])
+def test_medfilt_is_bit_exact(B, h, w, ks):
+    torch.manual_seed(5)
+    f = (torch.randn(B, h, w, 2) * 6).round() / 2            # many ties
+    out = pf.medfilt_flow(f.cuda(), ks)
+    ref = vo.medfilt_flow(f, ks).float()
+    assert torch.equal(out.cpu(), ref)
+    if ks == 5:
+        assert float(out.abs().max()) == 0.0                  # the reference's 5x5x5 call: always zero
+
+
+def test_median_ema_filter_and_argument_checks():
+    filt = pf.MedianEmaFilter(kernel_size=(5, 5, 1))
+    prev = torch.zeros(1, 30, 40, 2, dtype=torch.float64)
+    for _ in range(3):
+        cur = torch.randn(1, 30, 40, 2)
+        got = filt(cur.cuda())
+        med = vo.medfilt_flow(cur, (5, 5, 1))
+        ref = (0.9 * med.float() + 0.1 * prev.float())
+        prev = (0.9 * prev.float() + 0.1 * med.float()).double()
+        assert float((got.cpu() - ref).abs().max()) <= 1e-6
+    with pytest.raises(ValueError):
+        pf.medfilt_flow(torch.zeros(1, 4, 4, 2, device="cuda"), 4)
+    with pytest.raises(ValueError):
+        pf.medfilt_flow(torch.zeros(1, 4, 4, 2, device="cuda"), (3, 3))

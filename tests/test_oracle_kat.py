@@ -177,3 +177,20 @@ def test_transform_image_identity_and_outside():
     Mhalf = M.clone(); Mhalf[0, 0, 2] = 2.0                          # half a pixel to the left
     o = vo.warp_transform_image(torch.ones(1, 4, 6, 1, dtype=F64), Mhalf, 4, 6, F64)[0, :, :, 0]
     assert torch.allclose(o[:, 0], torch.full((4,), 0.5, dtype=F64), atol=1e-5) and torch.allclose(o[:, 1:], torch.ones(4, 5, dtype=F64), atol=1e-5)
+
+
+def test_medfilt_is_pinned_by_scipy():
+    # third-party anchor that IS installed here: the restated order filter must equal scipy.signal.medfilt bit for bit,
+    # and the reference's own call (scalar 5 on an [h,w,2] field, main_flownetS_pyramid.py:809) is identically zero
+    # because 75 of the 125 taps are channel-axis padding
+    import warnings
+    import scipy.signal
+    rng = np.random.default_rng(3)
+    f = rng.normal(size=(2, 13, 17, 2)).astype(np.float32) * 4
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for ks in (5, (5, 5, 1), (3, 7, 3), (1, 1, 1), (1, 9, 1)):
+            got = vo.medfilt_flow(f, ks).numpy().astype(np.float32)
+            ref = np.stack([scipy.signal.medfilt(f[b], ks if isinstance(ks, int) else list(ks)) for b in range(2)])
+            assert np.array_equal(got, ref), ks
+    assert np.abs(vo.medfilt_flow(f, 5).numpy()).max() == 0
