@@ -71,7 +71,9 @@ def _build_locked(verbose: bool) -> str:
         subprocess.check_call(cmd)
         objs.append(o)
     tmp = LIB + ".tmp"
-    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp])
+    # -z defs: an unresolved symbol fails the link here, not the dlopen on the GPU box (hipcc can silently drop the host
+    # stub of a kernel template whose body it could not digest in the host pass)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs"] + objs + ["-o", tmp])
     os.replace(tmp, LIB)
     with open(STAMP + ".tmp", "w") as f:
         f.write(source_hash())

@@ -194,7 +194,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     // staging registers, no ds_write.  One wave instruction lands 64 x 16 B contiguously (8 rows x 128 B) at
     // a wave-uniform base, so the XOR swizzle moves to the SOURCE: the lane that fills LDS chunk c' of a row
     // fetches global chunk c' ^ ((row>>1)&7).  Out-of-range lanes (offset 0xC0000000) land as zeros.
+    //
+    // Address arithmetic is the one thing this path still spends VALU issue slots on (measured: the fetch's address
+    // math costs ~3.5 % of the kernel, its memory traffic nothing), so everything that does not change from tile to
+    // tile is folded into per-thread constants up front: the lane's byte offset inside the input (relative to a
+    // descriptor whose base is moved back by the padding, so it is never negative), the three comparison limits of
+    // its validity test.  The tile's own displacement (ky, segment, chunk) is wave
+    // uniform and rides in the instruction's scalar offset.
     const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    int4 RA[VEC ? A_ROWS_V : 1];                  // {byte offset, x-range low, x-range high, segment limit} per gathered row
+    const int bias_el = ((ph.off_y < 0 ? -ph.off_y : 0) * p.Wi + (ph.off_x < 0 ? -ph.off_x : 0)) * p.Cs_in;      // elements the base moves back
+    const __amdgpu_buffer_rsrc_t rin_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in) - bias_el, 0, p.in_bytes + 4u * (unsigned)bias_el, 0x00020000);
+    if constexpr (DMA) {
+#pragma unroll
+        for (int j = 0; j < A_ROWS_V; ++j) {
+            const int row = (tid >> 3) + 32 * j;
+            const int c4 = ((tid & 7) ^ ((row >> 1) & 7)) * 4;            // source chunk (floats) for this LDS slot
+            RA[j] = make_int4((R[j].x + c4 + bias_el) * 4, R[j].z - c4, R[j].w - c4, p.SEG - c4);
+        }
+    }
     auto dma_tile = [&](int kt, int buf) {
         const int ky = c_ky;
         const int qseg = c_kc * 32;
@@ -209,24 +228,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
             c_ky += wrap_sg ? 1 : 0;
         }
         if constexpr (VEC) {
+            const unsigned soff = (unsigned)(ky * row_pitch + qabs0) * 4u;       // wave uniform
 #pragma unroll
             for (int j = 0; j < A_ROWS_V; ++j) {
-                const int row = (tid >> 3) + 32 * j;
-                const int c = (tid & 7) ^ ((row >> 1) & 7);              // source chunk for this LDS slot
-                const int qs = qseg + c * 4, qa = qabs0 + c * 4;
-                const bool ok = (qs < p.SEG) & ((unsigned)(R[j].y + ky) < (unsigned)p.Hi) & (qa >= R[j].z) & (qa < R[j].w);
-                const unsigned off = ok ? (unsigned)(R[j].x + ky * row_pitch + qa) * 4u : OOB;
+                const bool ok = (qseg < RA[j].w) & ((unsigned)(R[j].y + ky) < (unsigned)p.Hi) & (qabs0 >= RA[j].y) & (qabs0 < RA[j].z);
+                const unsigned off = ok ? (unsigned)RA[j].x : OOB;
                 __attribute__((address_space(3))) void *dst =
                     (__attribute__((address_space(3))) void *)(sA + buf * (BM * 32) + (32 * j + 8 * wave_u) * 32);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, dst, 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin_b, dst, 16, off, soff, 0, 0);
             }
         }
-        const unsigned woff = wvoff0 + (unsigned)kt * (unsigned)(p.Npad * 128);
+        const unsigned soffw = (unsigned)kt * (unsigned)(p.Npad * 128);          // wave uniform, like the 4 KB pass stride
 #pragma unroll
         for (int jb = 0; jb < B_PASS; ++jb) {
             __attribute__((address_space(3))) void *dst =
                 (__attribute__((address_space(3))) void *)(sB + buf * (BN * 32) + jb * 1024 + wave_u * 256);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, dst, 16, woff + jb * 4096, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, dst, 16, wvoff0, soffw + jb * 4096, 0, 0);
         }
     };
 

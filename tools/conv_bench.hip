@@ -35,7 +35,12 @@ int main(int argc, char **argv)
     const size_t in_n = (size_t)p.B * p.Hi * p.Wi * p.Cs_in, out_n = (size_t)p.B * p.Ho * p.Wo * p.Cs_out;
     const size_t w_n = (size_t)p.nphase * KT * p.Npad * 32, part_n = (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad;
     std::vector<float> h(std::max(in_n, w_n));
-    for (auto &x : h) x = (float)rand() / RAND_MAX - 0.5f;
+    const char *fill = getenv("VSTAB_BENCH_FILL");             // rand (default) | zero | const | sparse: operand toggling moves the clocks
+    const int fmode = !fill ? 0 : (fill[0] == 'z' ? 1 : (fill[0] == 'c' ? 2 : (fill[0] == 's' ? 3 : 0)));
+    for (auto &x : h) {
+        const float r = (float)rand() / RAND_MAX - 0.5f;
+        x = fmode == 0 ? r : (fmode == 1 ? 0.f : (fmode == 2 ? 0.25f : (r > 0.f ? r : 0.f)));
+    }
     float *din, *dw, *db, *dout, *dpart;
     CK(hipMalloc(&din, in_n * 4)); CK(hipMalloc(&dw, w_n * 4)); CK(hipMalloc(&db, p.Npad * 4)); CK(hipMalloc(&dout, out_n * 4));
     CK(hipMalloc(&dpart, (part_n + 4) * 4));
