@@ -1057,6 +1057,18 @@ extern "C" int vstab_axpby(const float *x, float a, const float *y, float b, flo
     return VSTAB_OK;
 }
 
+extern "C" int vstab_loss_level(const float *pf, const float *gt, const float *unstab, int B, int h, int w, double *sums,
+                                float scale_mse, float scale_tv, float *grad_pf, void *stream)
+{
+    if (!pf || !gt || !unstab || !sums) return fail(nullptr, VSTAB_E_STATE, "loss_level: NULL buffer");
+    if (B < 1 || h < 1 || w < 1 || (long long)h * w > (1LL << 30)) return fail(nullptr, VSTAB_E_SHAPE, "loss_level: bad shape");
+    if ((reinterpret_cast<uintptr_t>(pf) & 7) || (grad_pf && (reinterpret_cast<uintptr_t>(grad_pf) & 7)) ||
+        (reinterpret_cast<uintptr_t>(sums) & 7))
+        return fail(nullptr, VSTAB_E_ALIGN, "loss_level: flow / gradient / sums must be 8-byte aligned");
+    HIP_TRY(nullptr, launch_loss_level(pf, gt, unstab, B, h, w, sums, scale_mse, scale_tv, grad_pf, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_flow_medfilt(const float *flow, int B, int h, int w, int kh, int kw, int kc, float *out, void *stream)
 {
     if (!flow || !out) return fail(nullptr, VSTAB_E_STATE, "flow_medfilt: NULL buffer");

@@ -145,6 +145,9 @@ hipError_t launch_quantise_output(const float *warped, long long npix, unsigned 
 hipError_t launch_flow_box_blur(const float *flow, int B, int h, int w, int k, float *tmp, float *out, hipStream_t stream);
 hipError_t launch_axpby(const float *x, float a, const float *y, float b, float *out, long long n, hipStream_t stream);
 hipError_t launch_flow_mean_fill(const float *flow, int B, int h, int w, float *out, hipStream_t stream);
+// lossterm / masked_MSE / total_variation of one pyramid level and their gradient w.r.t. the flow (train_ops.hip)
+hipError_t launch_loss_level(const float *pf, const float *G, const float *U, int B, int h, int w, double *sums, float scale_mse,
+                             float scale_tv, float *grad, hipStream_t stream);
 hipError_t launch_flow_medfilt(const float *flow, int B, int h, int w, int kh, int kw, int kc, float *out, hipStream_t stream);
 
 // NLDF head helpers (nldf_ops.hip)

@@ -1,0 +1,55 @@
+"""Training objective of the reference, first slice of SURVEY.md 8f rank 4: `lossterm` / `masked_MSE` (main:188-210,
+"main" = main_flownetS_pyramid_noprevloss_dataloader.py), the total-variation terms and `loss_main` (main:213-275) --
+forward value AND the gradient with respect to every predicted flow, i.e. what the network's backward pass starts
+from.  The backward pass through the network itself and the Adam step (main:333-335) are not built yet.
+
+Everything runs in the HIP library (csrc/train_ops.hip); there is no CPU path."""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+
+from . import _lib, runtime
+from .warp_flow import resize_images
+
+LOSS_LEVELS = ("predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3", "predict_flow2")
+TV_WEIGHTS = (2e-8 * 3, 2e-8 * 3, 2e-8 * 3, 4e-8 * 1.5, 4e-8 * 1.5)          # main:269-273
+
+
+def _f32(t, name, c):
+    if not torch.is_tensor(t) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4 or t.shape[3] != c:
+        raise ValueError(f"{name} must be a float32 CUDA tensor [B,h,w,{c}]")
+    return t.contiguous()
+
+
+def lossterm(predict_flow, stab_image, unstab_image, tv_weight: float = 0.0, need_grad: bool = True):
+    """main:200-210 (+ the level's TV term when tv_weight != 0).  Returns (loss [0-dim float64 CUDA tensor],
+    d loss / d predict_flow [B,h,w,2] or None)."""
+    pf = _f32(predict_flow, "predict_flow", 2)
+    B, h, w, _ = pf.shape
+    stab, unstab = _f32(stab_image, "stab_image", 3), _f32(unstab_image, "unstab_image", 3)
+    if stab.shape[0] != B or unstab.shape != stab.shape:
+        raise ValueError("stab_image / unstab_image must be [B,H,W,3] with the flow's batch size")
+    gt = resize_images(stab, (h, w))                                   # tf.image.resize_images, main:202-203
+    un = resize_images(unstab, (h, w))
+    sums = torch.empty(3 * B, dtype=torch.float64, device=pf.device)
+    grad = torch.empty_like(pf) if need_grad else None
+    with torch.cuda.device(pf.device):
+        _lib.check(_lib.lib().vstab_loss_level(pf.data_ptr(), gt.data_ptr(), un.data_ptr(), B, h, w, sums.data_ptr(), 1.0,
+                                               float(tv_weight), grad.data_ptr() if need_grad else None, runtime.stream_ptr()))
+    s = sums.view(B, 3)
+    loss = (s[:, 0] / s[:, 1]).mean() + tv_weight * s[:, 2].sum()
+    return loss, grad
+
+
+def loss_main(outputs: Dict[str, torch.Tensor], gtstab_image, unstab_image, need_grad: bool = True
+              ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    """loss6+...+loss2 + var6+...+var2 (main:275) and its gradient w.r.t. each of the five flows."""
+    total, grads = None, {}
+    for name, tvw in zip(LOSS_LEVELS, TV_WEIGHTS):
+        l, g = lossterm(outputs[name], gtstab_image, unstab_image, tvw, need_grad)
+        total = l if total is None else total + l
+        if need_grad:
+            grads[name] = g
+    return total, grads

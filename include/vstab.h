@@ -206,6 +206,17 @@ VSTAB_API int vstab_quantise_output(const float *warped, long long npix, uint8_t
 VSTAB_API int vstab_flow_box_blur(const float *flow, int B, int h, int w, int k, float *tmp, float *out, void *stream);
 /* out = a*x + b*y elementwise (0.9*smooth + 0.1*prev, :643; prev = 0.9*prev + 0.1*cur, :695). */
 VSTAB_API int vstab_axpby(const float *x, float a, const float *y, float b, float *out, long long n, void *stream);
+/* ---- training objective, first slice of SURVEY.md 8f rank 4 -------------------------------------------
+ * One pyramid level of the reference's loss (main:188-210, 269-273) and its gradient w.r.t. the flow:
+ *   P = tf_warp(unstab, pf), M = tf_warp(ones, pf); masked_MSE = mean_b[ sum (P*M - gt*M)^2 / sum safe(M) ];
+ *   TV = sum_b tf.image.total_variation(pf[b]).
+ * gt / unstab: [B,h,w,3] already resized to the flow's size (vstab_resize_bilinear = tf.image.resize_images).
+ * sums: device double[3*B], overwritten with {sum sq, sum safe(M), TV} per sample -- the level's loss is
+ *   scale_mse * mean_b(sums[3b]/sums[3b+1]) + scale_tv * sum_b sums[3b+2]   (the caller adds the levels up).
+ * grad_pf (may be NULL): [B,h,w,2] d(that loss)/d(pf), overwritten. */
+VSTAB_API int vstab_loss_level(const float *pf, const float *gt, const float *unstab, int B, int h, int w, double *sums,
+                               float scale_mse, float scale_tv, float *grad_pf, void *stream);
+
 /* scipy.signal.medfilt(np.squeeze(of), k) (evaluate_medianNma, main_flownetS_pyramid.py:809): order filter over a
  * kh x kw x kc window of each [h,w,2] field -- kc spans the channel axis; the reference's scalar 5 means 5x5x5 --
  * zero padded on all axes, output = element n/2 of the sorted window.  Odd sizes, kh,kw <= 31, kc <= 5; out != flow. */

@@ -530,6 +530,45 @@ def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32, t
     return np.stack(outs)
 
 
+# --------------------------------------------------------------------------- training objective
+LOSS_LEVELS = ("predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3", "predict_flow2")
+TV_WEIGHTS = (2e-8 * 3, 2e-8 * 3, 2e-8 * 3, 4e-8 * 1.5, 4e-8 * 1.5)          # main:269-273
+
+
+def masked_mse(pred, gt, mask):
+    """main:188-198."""
+    mse = ((pred * mask - gt * mask) ** 2).sum(dim=(1, 2, 3))
+    safe = torch.where(mask == 0, mask + 1e-8, mask)
+    return (mse / safe.sum(dim=(1, 2, 3))).mean()
+
+
+def lossterm(predict_flow, stab_image, unstab_image, dtype=torch.float64):
+    """main:200-210: both images resized to the flow's size (tf.image.resize_images), the unstable one warped by the
+    flow, compared with the stable one under the mask tf_warp(ones)."""
+    h, w = predict_flow.shape[1], predict_flow.shape[2]
+    ds = resize_bilinear_legacy(_t(stab_image, dtype), h, w)
+    du = resize_bilinear_legacy(_t(unstab_image, dtype), h, w)
+    warped = tf_warp(du, predict_flow, h, w, dtype)
+    mask = tf_warp(torch.ones_like(du), predict_flow, h, w, dtype)
+    return masked_mse(warped, ds, mask), warped
+
+
+def total_variation(flow):
+    """tf.image.total_variation summed over the batch (main:269)."""
+    f = flow.double()
+    return (f[:, 1:] - f[:, :-1]).abs().sum() + (f[:, :, 1:] - f[:, :, :-1]).abs().sum()
+
+
+def loss_main(flows, gtstab, unstab, dtype=torch.float64):
+    """loss_main of the training graph (main:213-217, 269-275): five lossterms against the ground-truth stable frame
+    plus the weighted total variation of every flow.  `flows`: dict of float32 tensors (requires_grad for a backward)."""
+    total = 0.0
+    for name, tvw in zip(LOSS_LEVELS, TV_WEIGHTS):
+        l, _ = lossterm(flows[name], gtstab, unstab, dtype)
+        total = total + l + tvw * total_variation(flows[name])
+    return total
+
+
 # --------------------------------------------------------------------------- flow post-filters
 def box_blur_flow(flow, k: int = 75, dtype=torch.float64):
     """tf.nn.conv2d(of_c, constant(1/(k*k), [k,k,1,1]), SAME) per channel (main_flownetS_pyramid.py:634-641)."""

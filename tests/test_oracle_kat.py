@@ -194,3 +194,39 @@ def test_medfilt_is_pinned_by_scipy():
             ref = np.stack([scipy.signal.medfilt(f[b], ks if isinstance(ks, int) else list(ks)) for b in range(2)])
             assert np.array_equal(got, ref), ks
     assert np.abs(vo.medfilt_flow(f, 5).numpy()).max() == 0
+
+
+def test_training_loss_known_answers():
+    # zero flow: tf_warp's clipped corners give weight 0 on the last row and column (x1 == x0 there), so the mask is
+    # 1 on the (h-1)x(w-1) interior and 0 on the border; masked_MSE = sum_interior (U-G)^2 / (3*interior + 3*border*1e-8)
+    torch.manual_seed(1)
+    B, h, w = 2, 5, 7
+    G, U = torch.rand(B, h, w, 3, dtype=F64), torch.rand(B, h, w, 3, dtype=F64)
+    l, warped = vo.lossterm(torch.zeros(B, h, w, 2), G, U)
+    num = ((U - G)[:, :-1, :-1] ** 2).sum(dim=(1, 2, 3))
+    den = 3 * (h - 1) * (w - 1) + 3 * (h + w - 1) * 1e-8
+    assert abs(float(l) - float((num / den).mean())) < 1e-12
+    assert torch.equal(warped[:, :-1, :-1], U[:, :-1, :-1])
+    # total variation of a ramp: |d/dy| = 2 on (h-1)*w edges, |d/dx| = 3 on h*(w-1) edges, second channel constant
+    f = torch.zeros(1, h, w, 2)
+    f[0, :, :, 0] = 2 * torch.arange(h).view(h, 1) + 3 * torch.arange(w).view(1, w)
+    assert float(vo.total_variation(f)) == 2 * (h - 1) * w + 3 * h * (w - 1)
+
+
+def test_training_loss_gradient_matches_finite_differences():
+    # autograd through the restated graph (what TF's autodiff computes: no gradient through the integer casts) against
+    # central differences at points away from the truncation discontinuities
+    torch.manual_seed(2)
+    B, h, w = 1, 6, 8
+    G, U = torch.rand(B, h, w, 3, dtype=F64), torch.rand(B, h, w, 3, dtype=F64)
+    f0 = (torch.rand(B, h, w, 2) * 0.6 + 0.2)                     # sample positions strictly inside a cell
+    f = f0.clone().requires_grad_(True)
+    l, _ = vo.lossterm(f, G, U)
+    l.backward()
+    eps = 1e-3
+    for (y, x, c) in [(2, 3, 0), (2, 3, 1), (0, 0, 0), (4, 6, 1)]:
+        fp, fm = f0.clone(), f0.clone()
+        fp[0, y, x, c] += eps
+        fm[0, y, x, c] -= eps
+        num = (float(vo.lossterm(fp, G, U)[0]) - float(vo.lossterm(fm, G, U)[0])) / (2 * eps)
+        assert abs(num - float(f.grad[0, y, x, c])) < 2e-4 * max(1.0, abs(num)), (y, x, c, num, float(f.grad[0, y, x, c]))
