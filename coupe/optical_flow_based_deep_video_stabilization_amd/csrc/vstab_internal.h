@@ -145,6 +145,29 @@ hipError_t launch_quantise_output(const float *warped, long long npix, unsigned 
 hipError_t launch_flow_box_blur(const float *flow, int B, int h, int w, int k, float *tmp, float *out, hipStream_t stream);
 hipError_t launch_axpby(const float *x, float a, const float *y, float b, float *out, long long n, hipStream_t stream);
 hipError_t launch_flow_mean_fill(const float *flow, int B, int h, int w, float *out, hipStream_t stream);
+// ---------------------------------------------------------------------------------
+// Convolution weight gradient on the MFMA (wgrad_mfma.hip): dW[(ky,kx,ci)][co] = sum over output pixels of
+// x[n, s*oy+ky-p, s*ox+kx-p, ci] * g[n,oy,ox,co]; reduction index = output pixel.
+// ---------------------------------------------------------------------------------
+struct WgradParams {
+    const float *x;         // [B,Hi,Wi,Cs_x], channels cx_off .. cx_off+Cin
+    const float *g;         // [B,Ho,Wo,Cs_g] = [K][Cs_g], channels cg_off .. cg_off+Cout
+    const int4 *ptab;       // [K] pixel table (launch_wgrad_pixel_table)
+    float *dW;              // [KH*KW*Cin][Cout] (HWIO row-major)
+    float *partial;         // split-K slabs [ksplit][M][Cout]
+    unsigned x_bytes, g_bytes;
+    int Hi, Wi, Cs_x, cx_off, Cin;
+    int KH, KW;
+    int Cs_g, cg_off, Cout;
+    int M, K;               // KH*KW*Cin, B*Ho*Wo
+    int ksplit, accumulate; // accumulate: dW += result
+};
+hipError_t launch_wgrad_pixel_table(int B, int Hi, int Wi, int Cs, int Ho, int Wo, int s, int pad, int4 *ptab, hipStream_t stream);
+int wgrad_choose_split(const WgradParams &p);
+hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream);
+// out[c] (+)= sum over rows of g[row*Cs + c_off + c]
+hipError_t launch_column_sum(const float *g, long long rows, int Cs, int c_off, int C, float *out, int accumulate, hipStream_t stream);
+
 // lossterm / masked_MSE / total_variation of one pyramid level and their gradient w.r.t. the flow (train_ops.hip)
 hipError_t launch_loss_level(const float *pf, const float *G, const float *U, int B, int h, int w, double *sums, float scale_mse,
                              float scale_tv, float *grad, hipStream_t stream);

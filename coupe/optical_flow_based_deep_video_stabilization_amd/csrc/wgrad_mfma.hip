@@ -1,0 +1,224 @@
+// Weight gradient of a convolution on the fp32 MFMA (backward of F1/F4 in model.py:786-893).
+//
+//   y[n,oy,ox,co] = b[co] + sum_{ky,kx,ci} x[n, s*oy+ky-p, s*ox+kx-p, ci] * W[ky,kx,ci,co]
+//   dW[ky,kx,ci,co] = sum_{n,oy,ox} x[n, s*oy+ky-p, s*ox+kx-p, ci] * g[n,oy,ox,co]
+//
+// GEMM view: rows m = (ky, kx, ci) -- exactly the HWIO row-major order of dW -- columns = co, and the REDUCTION runs over
+// the output pixels k = (n, oy, ox).  Unlike the forward kernel both operands have their reduction index as the SLOW memory
+// index (a pixel's channels are contiguous in NHWC), which is what the MFMA wants here: lane (i, h) of
+// v_mfma_f32_32x32x2_f32 needs A[m = i][k = h], i.e. 32 consecutive channels of ONE pixel per half-wave -- a conflict-free
+// ds_read_b32 from a k-major LDS tile that LDS-DMA can fill with 16-byte loads.  No transposes, no im2col.
+//
+//   * workgroup tile 128 (m) x 128 (co), K-tile = 32 output pixels, 4 waves with 64x64 register tiles (AGPRs)
+//   * LDS [2 stages][32 pixels][128 floats] for both operands, filled by `buffer_load_dwordx4 ... lds`; a pixel whose tap
+//     falls outside the image, a pixel past the end of the batch or a channel past Cin/Cout reads as zero through the
+//     descriptor's range check (offset 0xC0000000), so the loop has no branches
+//   * a per-pixel table {element offset of the pixel's window origin, s*oy - p, s*ox - p} (built once per geometry by
+//     wgrad_pixel_table_kernel) replaces the n/oy/ox integer divisions; a lane's tap and channel are per-thread constants
+//   * split-K over blockIdx.z (the reduction is B*Ho*Wo long, the output only k*k*Cin x Cout): fp32 slabs summed in
+//     slab order by wgrad_combine_kernel -- deterministic
+// The same kernel gives the gradient of a 4x4 stride-2 transposed conv's weights (roles of x and g swapped by the caller).
+#include <hip/hip_runtime.h>
+
+#include "vstab_internal.h"
+
+namespace vstab {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ptab[k] = {x element offset of (n, s*oy - p, s*ox - p, 0), s*oy - p, s*ox - p, 0}
+__global__ __launch_bounds__(256) void wgrad_pixel_table_kernel(int B, int Hi, int Wi, int Cs, int Ho, int Wo, int s, int p,
+                                                                int4 *__restrict__ ptab)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= B * Ho * Wo) return;
+    const int n = k / (Ho * Wo), r = k - n * Ho * Wo;
+    const int oy = r / Wo, ox = r - oy * Wo;
+    const int y0 = s * oy - p, x0 = s * ox - p;
+    ptab[k] = make_int4(((n * Hi + y0) * Wi + x0) * Cs, y0, x0, 0);
+}
+
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
+{
+    constexpr int BM = 128, BN = 128, KT = 32;
+    __shared__ __attribute__((aligned(16))) float sA[2][KT * BM];
+    __shared__ __attribute__((aligned(16))) float sB[2][KT * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int ktiles = (p.K + KT - 1) / KT;
+    const int kts = (ktiles + p.ksplit - 1) / p.ksplit;
+    const int kt0 = split * kts, kt1 = min(ktiles, kt0 + kts);
+
+    const unsigned OOB = 0xC0000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.g), 0, p.g_bytes, 0x00020000);
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
+
+    // this thread's column chunk (4 floats) inside the 128-float tile rows: constant over the whole K loop
+    const int cc = (tid & 31) * 4;
+    // A: row m = m0 + cc .. +3 -> tap and input channel (Cin % 4 == 0, so a chunk never straddles a tap)
+    const int m = m0 + cc;
+    const bool m_ok = m < p.M;
+    const int tap = m_ok ? m / p.Cin : 0, ci = m - tap * p.Cin;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int a_delta = (ky * p.Wi + kx) * p.Cs_x + p.cx_off + ci;          // added to the pixel's window origin
+    // B: column co = n0 + cc .. +3
+    const bool n_ok = n0 + cc < p.Cout;
+    const int b_delta = p.cg_off + n0 + cc;
+
+    // one K-tile: 32 pixels x 128 floats per operand = 4 DMA instructions per thread per operand (8 pixel rows per pass)
+    auto dma_tile = [&](int kt, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (tid >> 5) + 8 * j;
+            const int k = kt * KT + r;
+            const bool k_ok = k < p.K;
+            const int4 pt = k_ok ? p.ptab[k] : make_int4(0, -(1 << 28), 0, 0);
+            const bool a_ok = m_ok & ((unsigned)(pt.y + ky) < (unsigned)p.Hi) & ((unsigned)(pt.z + kx) < (unsigned)p.Wi);
+            const unsigned aoff = a_ok ? (unsigned)(pt.x + a_delta) * 4u : OOB;
+            const unsigned boff = (k_ok & n_ok) ? (unsigned)(k * p.Cs_g + b_delta) * 4u : OOB;
+            __attribute__((address_space(3))) void *da =
+                (__attribute__((address_space(3))) void *)(&sA[buf][(8 * j + 2 * wave_u) * BM]);
+            __attribute__((address_space(3))) void *db =
+                (__attribute__((address_space(3))) void *)(&sB[buf][(8 * j + 2 * wave_u) * BN]);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, da, 16, aoff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, db, 16, boff, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_col = wm * 64 + li, b_col = wn * 64 + li;
+
+    if (kt0 < kt1) {
+        dma_tile(kt0, 0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            if (kt + 1 < kt1) dma_tile(kt + 1, buf ^ 1);
+            const float *cA = &sA[buf][lh * BM + a_col];
+            const float *cB = &sB[buf][lh * BN + b_col];
+#pragma unroll
+            for (int ks = 0; ks < KT / 2; ++ks) {                          // MFMA k-step: pixels 2*ks + {0, 1}
+                const float a0 = cA[ks * 2 * BM], a1 = cA[ks * 2 * BM + 32];
+                const float b0 = cB[ks * 2 * BN], b1 = cB[ks * 2 * BN + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();                                               // tile kt+1 landed, tile kt's slot is free
+            buf ^= 1;
+        }
+    }
+
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float *dst = p.ksplit > 1 ? p.partial + (size_t)split * p.M * p.Cout : p.dW;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int col = n0 + wn * 64 + nb * 32 + li;
+        if (col >= p.Cout) continue;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < p.M) {
+                    float v = acc[mb][nb][r];
+                    if (p.ksplit == 1 && p.accumulate) v += dst[(size_t)row * p.Cout + col];
+                    dst[(size_t)row * p.Cout + col] = v;
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_combine_kernel(const float *__restrict__ partial, int ks, long long n,
+                                                            int accumulate, float *__restrict__ dW)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 4 <= ks; k += 4) {
+        const float v0 = partial[(k + 0) * n + i], v1 = partial[(k + 1) * n + i];
+        const float v2 = partial[(k + 2) * n + i], v3 = partial[(k + 3) * n + i];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; k < ks; ++k) s += partial[k * n + i];
+    if (accumulate) s += dW[i];
+    dW[i] = s;
+}
+
+// db[c] = sum over rows of g[row][c_off + c] (bias / beta gradients, BatchNorm sums): one workgroup per 64 channels,
+// 4 waves striding over the rows, coalesced 256-byte row reads, fixed reduction order
+__global__ __launch_bounds__(256) void column_sum_kernel(const float *__restrict__ g, long long rows, int Cs, int c_off, int C,
+                                                         float *__restrict__ out, int accumulate)
+{
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (long long r = wave; r < rows; r += 4) s += g[r * Cs + c_off + c];
+    red[wave][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+int wgrad_choose_split(const WgradParams &p)
+{
+    const long long tiles = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    const int ktiles = (p.K + 31) / 32;
+    int ks = (int)(256 / (tiles > 0 ? tiles : 1));                           // one workgroup per CU
+    if (ks < 1) ks = 1;
+    if (ks > 64) ks = 64;
+    const int cap = ktiles / 4 > 1 ? ktiles / 4 : 1;
+    if (ks > cap) ks = cap;
+    const int kts = (ktiles + ks - 1) / ks;
+    return (ktiles + kts - 1) / kts;
+}
+
+hipError_t launch_wgrad_pixel_table(int B, int Hi, int Wi, int Cs, int Ho, int Wo, int s, int pad, int4 *ptab, hipStream_t stream)
+{
+    const int K = B * Ho * Wo;
+    wgrad_pixel_table_kernel<<<dim3((unsigned)((K + 255) / 256)), dim3(256), 0, stream>>>(B, Hi, Wi, Cs, Ho, Wo, s, pad, ptab);
+    return hipGetLastError();
+}
+
+hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream)
+{
+    if ((p.Cin & 3) || (p.Cs_x & 3) || (p.cx_off & 3) || (p.Cs_g & 3) || (p.cg_off & 3) || p.ksplit < 1) return hipErrorInvalidValue;
+    if (p.x_bytes >= 0x80000000u || p.g_bytes >= 0x80000000u) return hipErrorInvalidValue;
+    if (p.ksplit > 1 && !p.partial) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)((p.Cout + 127) / 128), (unsigned)p.ksplit);
+    wgrad_mfma_kernel<<<grid, dim3(256), 0, stream>>>(p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (p.ksplit > 1) {
+        const long long n = (long long)p.M * p.Cout;
+        wgrad_combine_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(p.partial, p.ksplit, n, p.accumulate, p.dW);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+hipError_t launch_column_sum(const float *g, long long rows, int Cs, int c_off, int C, float *out, int accumulate, hipStream_t stream)
+{
+    column_sum_kernel<<<dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream>>>(g, rows, Cs, c_off, C, out, accumulate);
+    return hipGetLastError();
+}
+
+}  // namespace vstab

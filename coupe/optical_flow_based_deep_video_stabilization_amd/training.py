@@ -53,3 +53,34 @@ def loss_main(outputs: Dict[str, torch.Tensor], gtstab_image, unstab_image, need
         if need_grad:
             grads[name] = g
     return total, grads
+
+
+# ----------------------------------------------------------------------------- backward building blocks
+def conv_wgrad(x, gout, k: int, stride: int, pad: int, cx_off: int = 0, cin: int = None, cg_off: int = 0, cout: int = None,
+               dW=None, db=None, accumulate: bool = False, want_db: bool = True):
+    """Filter and bias gradient of PadLayer(pad) -> Conv2d(k, stride, VALID) (model.py:807-844): what TF's autodiff
+    returns for tf.nn.conv2d's filter, in the reference's HWIO layout.  x [B,Hi,Wi,Cs_x] (channels cx_off..+cin),
+    gout [B,Ho,Wo,Cs_g] (channels cg_off..+cout).  Returns (dW [k,k,cin,cout], db [cout] or None)."""
+    for t, name in ((x, "x"), (gout, "gout")):
+        if not torch.is_tensor(t) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+            raise ValueError(f"{name} must be a float32 CUDA tensor [B,H,W,C]")
+    x, gout = x.contiguous(), gout.contiguous()
+    B, Hi, Wi, cs_x = x.shape
+    _, Ho, Wo, cs_g = gout.shape
+    cin = cs_x - cx_off if cin is None else int(cin)
+    cout = cs_g - cg_off if cout is None else int(cout)
+    if gout.shape[0] != B:
+        raise ValueError("x and gout must have the same batch size")
+    if dW is None:
+        dW = torch.empty((k, k, cin, cout), dtype=torch.float32, device=x.device)
+        accumulate = False
+    if want_db and db is None:
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    nbytes = L.vstab_conv_wgrad_workspace_bytes(B, Ho, Wo, k, cin, cout)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.vstab_conv_wgrad(x.data_ptr(), B, Hi, Wi, cs_x, cx_off, cin, gout.data_ptr(), Ho, Wo, cs_g, cg_off, cout,
+                                      k, stride, pad, dW.data_ptr(), db.data_ptr() if want_db else None, 1 if accumulate else 0,
+                                      ws.data_ptr(), ws.numel(), runtime.stream_ptr()))
+    return dW, (db if want_db else None)

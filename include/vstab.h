@@ -217,6 +217,17 @@ VSTAB_API int vstab_axpby(const float *x, float a, const float *y, float b, floa
 VSTAB_API int vstab_loss_level(const float *pf, const float *gt, const float *unstab, int B, int h, int w, double *sums,
                                float scale_mse, float scale_tv, float *grad_pf, void *stream);
 
+/* Weight and bias gradient of PadLayer(pad) -> Conv2d(k, stride, VALID) (model.py:807-844; what tf.gradients yields for
+ * the filter of tf.nn.conv2d): dW[ky,kx,ci,co] = sum_{n,oy,ox} x[n, s*oy+ky-pad, s*ox+kx-pad, ci] * gout[n,oy,ox,co] in the
+ * reference's HWIO layout, db[co] = sum gout (db may be NULL).  x: [B,Hi,Wi,cs_x] using channels cx_off..cx_off+cin;
+ * gout: [B,Ho,Wo,cs_g] using channels cg_off..cg_off+cout; all channel counts / strides / offsets multiples of 4.
+ * accumulate != 0 adds to dW / db instead of overwriting.  With x = the output gradient and gout = the input of a
+ * 4x4 stride-2 SAME transposed conv (k 4, stride 2, pad 1) the result is that layer's [4,4,cout,cin] filter gradient. */
+VSTAB_API size_t vstab_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int k, int cin, int cout);
+VSTAB_API int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *gout, int Ho,
+                               int Wo, int cs_g, int cg_off, int cout, int k, int stride, int pad, float *dW, float *db,
+                               int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
 /* scipy.signal.medfilt(np.squeeze(of), k) (evaluate_medianNma, main_flownetS_pyramid.py:809): order filter over a
  * kh x kw x kc window of each [h,w,2] field -- kc spans the channel axis; the reference's scalar 5 means 5x5x5 --
  * zero padded on all axes, output = element n/2 of the sorted window.  Odd sizes, kh,kw <= 31, kc <= 5; out != flow. */

@@ -67,3 +67,72 @@ def test_argument_checks():
         training.lossterm(torch.zeros(1, 4, 4, 3).cuda(), torch.zeros(1, 4, 4, 3).cuda(), torch.zeros(1, 4, 4, 3).cuda())
     with pytest.raises(ValueError):
         training.lossterm(torch.zeros(2, 4, 4, 2).cuda(), torch.zeros(1, 4, 4, 3).cuda(), torch.zeros(1, 4, 4, 3).cuda())
+
+
+# ----------------------------------------------------------------------------- conv weight gradient (MFMA)
+def _torch_wgrad(x, g, k, s, p):
+    """tf.gradients(conv2d(pad(x), W), W) with torch autograd in float64 (cross-correlation, HWIO)."""
+    import torch.nn.functional as F
+    cin, cout = x.shape[3], g.shape[3]
+    W = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), W, stride=s, padding=p)
+    y.backward(g.double().permute(0, 3, 1, 2))
+    return W.grad.permute(2, 3, 1, 0).contiguous(), g.double().sum(dim=(0, 1, 2))      # HWIO
+
+
+@pytest.mark.parametrize("B,Hi,Wi,cin,cout,k,s,p", [
+    (2, 12, 16, 64, 128, 3, 1, 1),        # conv3_1-like
+    (2, 13, 17, 128, 256, 5, 2, 2),       # conv3-like, odd sizes
+    (1, 9, 11, 256, 512, 3, 2, 1),        # conv4-like
+    (3, 6, 7, 8, 20, 3, 1, 1),            # tiny channel counts: one tile, most of it padding
+    (2, 8, 8, 196, 64, 1, 1, 0),          # 1x1
+    (1, 20, 24, 64, 64, 7, 2, 3),         # 7x7
+    (8, 16, 16, 64, 128, 5, 2, 2),        # longer reduction -> split-K
+])
+def test_conv_wgrad_matches_autograd(B, Hi, Wi, cin, cout, k, s, p):
+    g0 = torch.Generator().manual_seed(B * 100 + cin)
+    Ho, Wo = (Hi + 2 * p - k) // s + 1, (Wi + 2 * p - k) // s + 1
+    x = torch.randn(B, Hi, Wi, cin, generator=g0)
+    g = torch.randn(B, Ho, Wo, cout, generator=g0)
+    dW, db = training.conv_wgrad(x.cuda(), g.cuda(), k, s, p)
+    rW, rb = _torch_wgrad(x, g, k, s, p)
+    assert dW.shape == rW.shape
+    scale = float(rW.abs().max())
+    assert float((dW.double().cpu() - rW).abs().max()) <= 2e-5 * scale + 1e-6
+    assert float((db.double().cpu() - rb).abs().max()) <= 2e-5 * float(rb.abs().max()) + 1e-6
+
+
+def test_conv_wgrad_channel_slices_and_accumulate():
+    # operands living inside wider (concat) pixels, and dW += on a second call
+    g0 = torch.Generator().manual_seed(9)
+    B, Hi, Wi, k, s, p = 2, 10, 12, 3, 1, 1
+    xw = torch.randn(B, Hi, Wi, 20, generator=g0)          # use channels 4..12
+    gw = torch.randn(B, Hi, Wi, 24, generator=g0)          # use channels 8..24
+    dW, db = training.conv_wgrad(xw.cuda(), gw.cuda(), k, s, p, cx_off=4, cin=8, cg_off=8, cout=16)
+    rW, rb = _torch_wgrad(xw[..., 4:12], gw[..., 8:24], k, s, p)
+    assert float((dW.double().cpu() - rW).abs().max()) <= 2e-5 * float(rW.abs().max())
+    dW2, db2 = training.conv_wgrad(xw.cuda(), gw.cuda(), k, s, p, cx_off=4, cin=8, cg_off=8, cout=16, dW=dW.clone(), db=db.clone(),
+                                   accumulate=True)
+    assert float((dW2.double().cpu() - 2 * rW).abs().max()) <= 4e-5 * float(rW.abs().max())
+    assert float((db2.double().cpu() - 2 * rb).abs().max()) <= 4e-5 * float(rb.abs().max())
+    with pytest.raises(ValueError):
+        training.conv_wgrad(torch.zeros(1, 8, 8, 6).cuda(), torch.zeros(1, 8, 8, 8).cuda(), 3, 1, 1)     # cin % 4
+    with pytest.raises(ValueError):
+        training.conv_wgrad(torch.zeros(1, 8, 8, 8).cuda(), torch.zeros(1, 7, 8, 8).cuda(), 3, 1, 1)     # wrong output size
+
+
+def test_deconv_filter_gradient_via_swapped_roles():
+    # 4x4 stride-2 SAME transposed conv y = convT(x, W[4,4,cout,cin]): dW = wgrad of the conv that maps y-shaped tensors
+    # to x-shaped ones, with (input, gout) = (dy, x)
+    import torch.nn.functional as F
+    g0 = torch.Generator().manual_seed(4)
+    B, h, w, cin, cout = 2, 5, 6, 16, 8
+    x = torch.randn(B, h, w, cin, generator=g0)
+    dy = torch.randn(B, 2 * h, 2 * w, cout, generator=g0)
+    Wt = torch.zeros(cin, cout, 4, 4, dtype=torch.float64, requires_grad=True)          # torch conv_transpose2d layout
+    y = F.conv_transpose2d(x.double().permute(0, 3, 1, 2), Wt, stride=2, padding=1)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    ref = Wt.grad.permute(2, 3, 1, 0)                                                    # [4,4,cout,cin] = TL's deconv filter
+    dW, _ = training.conv_wgrad(dy.cuda(), x.cuda(), 4, 2, 1, want_db=False)            # [4,4,cin_of_conv=cout, cout_of_conv=cin]
+    assert dW.shape == ref.shape
+    assert float((dW.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
