@@ -15,7 +15,8 @@ extern "C" size_t vstab_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int k,
     p.M = k * k * cin; p.Cout = cout; p.K = B * Ho * Wo;
     const int ks = wgrad_choose_split(p);
     const size_t ptab = ((size_t)p.K * sizeof(int4) + 255) / 256 * 256;
-    return ptab + (ks > 1 ? (size_t)ks * p.M * cout * sizeof(float) : 0) + 256;
+    const size_t slabs = ((ks > 1 ? (size_t)ks * p.M * cout * sizeof(float) : 0) + 255) / 256 * 256;
+    return ptab + slabs + (size_t)column_sum_chunks(p.K) * cout * sizeof(float) + 256;
 }
 
 extern "C" int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *gout, int Ho,
@@ -50,6 +51,10 @@ extern "C" int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x,
     p.partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + ((size_t)p.K * sizeof(int4) + 255) / 256 * 256);
     HIP_TRY(nullptr, launch_wgrad_pixel_table(B, Hi, Wi, cs_x, Ho, Wo, stride, pad, ptab, st));
     HIP_TRY(nullptr, launch_wgrad(p, st));
-    if (db) HIP_TRY(nullptr, launch_column_sum(gout, (long long)p.K, cs_g, cg_off, cout, db, accumulate ? 1 : 0, st));
+    if (db) {
+        const size_t slabs = ((p.ksplit > 1 ? (size_t)p.ksplit * p.M * cout * sizeof(float) : 0) + 255) / 256 * 256;
+        float *scratch = reinterpret_cast<float *>(reinterpret_cast<char *>(p.partial) + slabs);
+        HIP_TRY(nullptr, launch_column_sum(gout, (long long)p.K, cs_g, cg_off, cout, db, accumulate ? 1 : 0, scratch, st));
+    }
     return VSTAB_OK;
 }

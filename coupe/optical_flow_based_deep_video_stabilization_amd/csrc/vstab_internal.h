@@ -166,7 +166,9 @@ hipError_t launch_wgrad_pixel_table(int B, int Hi, int Wi, int Cs, int Ho, int W
 int wgrad_choose_split(const WgradParams &p);
 hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream);
 // out[c] (+)= sum over rows of g[row*Cs + c_off + c]
-hipError_t launch_column_sum(const float *g, long long rows, int Cs, int c_off, int C, float *out, int accumulate, hipStream_t stream);
+int column_sum_chunks(long long rows);        // scratch floats needed = column_sum_chunks(rows) * C
+hipError_t launch_column_sum(const float *g, long long rows, int Cs, int c_off, int C, float *out, int accumulate, float *scratch,
+                             hipStream_t stream);
 
 // lossterm / masked_MSE / total_variation of one pyramid level and their gradient w.r.t. the flow (train_ops.hip)
 hipError_t launch_loss_level(const float *pf, const float *G, const float *U, int B, int h, int w, double *sums, float scale_mse,

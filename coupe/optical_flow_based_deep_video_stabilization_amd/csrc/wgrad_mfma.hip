@@ -20,6 +20,8 @@
 // The same kernel gives the gradient of a 4x4 stride-2 transposed conv's weights (roles of x and g swapped by the caller).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "vstab_internal.h"
 
 namespace vstab {
@@ -42,8 +44,11 @@ __global__ __launch_bounds__(256) void wgrad_pixel_table_kernel(int B, int Hi, i
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
 {
     constexpr int BM = 128, BN = 128, KT = 32;
-    __shared__ __attribute__((aligned(16))) float sA[2][KT * BM];
-    __shared__ __attribute__((aligned(16))) float sB[2][KT * BN];
+    // dynamic LDS like the forward kernel: with static arrays hipcc orders every fragment read after the DMA that was
+    // just issued into the OTHER stage (it sees one object) and the prefetch is lost
+    extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+    float *sA = reinterpret_cast<float *>(wg_smem);                 // [2][KT * BM]
+    float *sB = sA + 2 * KT * BM;                                   // [2][KT * BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -70,21 +75,27 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
     const bool n_ok = n0 + cc < p.Cout;
     const int b_delta = p.cg_off + n0 + cc;
 
-    // one K-tile: 32 pixels x 128 floats per operand = 4 DMA instructions per thread per operand (8 pixel rows per pass)
+    // one K-tile: 32 pixels x 128 floats per operand = 4 DMA instructions per thread per operand (8 pixel rows per pass).
+    // The pixel-table entries of a tile are fetched one tile AHEAD of its DMA (plain loads into registers, issued behind
+    // the previous tile's DMAs): the loop never waits on a table load, and there is no branch in it.
+    int4 pt[4];
+    auto load_pt = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pt[j] = p.ptab[min(kt * KT + (tid >> 5) + 8 * j, p.K - 1)];
+    };
     auto dma_tile = [&](int kt, int buf) {
+        const bool t_ok = kt < kt1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r = (tid >> 5) + 8 * j;
-            const int k = kt * KT + r;
-            const bool k_ok = k < p.K;
-            const int4 pt = k_ok ? p.ptab[k] : make_int4(0, -(1 << 28), 0, 0);
-            const bool a_ok = m_ok & ((unsigned)(pt.y + ky) < (unsigned)p.Hi) & ((unsigned)(pt.z + kx) < (unsigned)p.Wi);
-            const unsigned aoff = a_ok ? (unsigned)(pt.x + a_delta) * 4u : OOB;
+            const int k = kt * KT + (tid >> 5) + 8 * j;
+            const bool k_ok = t_ok & (k < p.K);
+            const bool a_ok = k_ok & m_ok & ((unsigned)(pt[j].y + ky) < (unsigned)p.Hi) & ((unsigned)(pt[j].z + kx) < (unsigned)p.Wi);
+            const unsigned aoff = a_ok ? (unsigned)(pt[j].x + a_delta) * 4u : OOB;
             const unsigned boff = (k_ok & n_ok) ? (unsigned)(k * p.Cs_g + b_delta) * 4u : OOB;
             __attribute__((address_space(3))) void *da =
-                (__attribute__((address_space(3))) void *)(&sA[buf][(8 * j + 2 * wave_u) * BM]);
+                (__attribute__((address_space(3))) void *)(sA + buf * (KT * BM) + (8 * j + 2 * wave_u) * BM);
             __attribute__((address_space(3))) void *db =
-                (__attribute__((address_space(3))) void *)(&sB[buf][(8 * j + 2 * wave_u) * BN]);
+                (__attribute__((address_space(3))) void *)(sB + buf * (KT * BN) + (8 * j + 2 * wave_u) * BN);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, da, 16, aoff, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, db, 16, boff, 0, 0, 0);
         }
@@ -102,21 +113,30 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
     const int a_col = wm * 64 + li, b_col = wn * 64 + li;
 
     if (kt0 < kt1) {
+        load_pt(kt0);
         dma_tile(kt0, 0);
+        load_pt(kt0 + 1);
         __syncthreads();
         int buf = 0;
         for (int kt = kt0; kt < kt1; ++kt) {
-            if (kt + 1 < kt1) dma_tile(kt + 1, buf ^ 1);
-            const float *cA = &sA[buf][lh * BM + a_col];
-            const float *cB = &sB[buf][lh * BN + b_col];
+            dma_tile(kt + 1, buf ^ 1);                                     // past the last tile: every lane out of range
+            load_pt(kt + 2);
+            const float *cA = sA + buf * (KT * BM) + lh * BM + a_col;
+            const float *cB = sB + buf * (KT * BN) + lh * BN + b_col;
+            // MFMA k-step ks covers pixels 2*ks + {0, 1}; the fragments of step ks+1 are read before the MFMAs of step ks
+            float a0 = cA[0], a1 = cA[32], b0 = cB[0], b1 = cB[32];
 #pragma unroll
-            for (int ks = 0; ks < KT / 2; ++ks) {                          // MFMA k-step: pixels 2*ks + {0, 1}
-                const float a0 = cA[ks * 2 * BM], a1 = cA[ks * 2 * BM + 32];
-                const float b0 = cB[ks * 2 * BN], b1 = cB[ks * 2 * BN + 32];
+            for (int ks = 0; ks < KT / 2; ++ks) {
+                float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+                if (ks + 1 < KT / 2) {
+                    na0 = cA[(ks + 1) * 2 * BM]; na1 = cA[(ks + 1) * 2 * BM + 32];
+                    nb0 = cB[(ks + 1) * 2 * BN]; nb1 = cB[(ks + 1) * 2 * BN + 32];
+                }
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
             }
             __syncthreads();                                               // tile kt+1 landed, tile kt's slot is free
             buf ^= 1;
@@ -160,29 +180,42 @@ __global__ __launch_bounds__(256) void wgrad_combine_kernel(const float *__restr
     dW[i] = s;
 }
 
-// db[c] = sum over rows of g[row][c_off + c] (bias / beta gradients, BatchNorm sums): one workgroup per 64 channels,
-// 4 waves striding over the rows, coalesced 256-byte row reads, fixed reduction order
-__global__ __launch_bounds__(256) void column_sum_kernel(const float *__restrict__ g, long long rows, int Cs, int c_off, int C,
-                                                         float *__restrict__ out, int accumulate)
+// out[c] (+)= sum over rows of g[row][c_off + c] (bias / beta gradients, BatchNorm sums).  Two deterministic stages: a
+// (64-channel block) x (row chunk) grid of workgroups -- 4 waves striding over the chunk's rows, coalesced 256-byte row
+// reads -- writes one partial per chunk; the second stage adds the chunks in order.
+__global__ __launch_bounds__(256) void column_sum_kernel(const float *__restrict__ g, long long rows, int rows_per_chunk, int Cs,
+                                                         int c_off, int C, float *__restrict__ part)
 {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c < C)
-        for (long long r = wave; r < rows; r += 4) s += g[r * Cs + c_off + c];
-    red[wave][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (wave == 0 && c < C) {
-        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        out[c] = accumulate ? out[c] + t : t;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        long long r = r0 + wave;
+        for (; r + 4 < r1; r += 8) { s0 += g[r * Cs + c_off + c]; s1 += g[(r + 4) * Cs + c_off + c]; }
+        if (r < r1) s0 += g[r * Cs + c_off + c];
     }
+    red[wave][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && c < C)
+        part[(long long)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void column_sum_final_kernel(const float *__restrict__ part, int chunks, int C, float *__restrict__ out,
+                                                               int accumulate)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(long long)k * C + c];
+    out[c] = accumulate ? out[c] + s : s;
 }
 
 int wgrad_choose_split(const WgradParams &p)
 {
     const long long tiles = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const int ktiles = (p.K + 31) / 32;
-    int ks = (int)(256 / (tiles > 0 ? tiles : 1));                           // one workgroup per CU
+    int ks = (int)(512 / (tiles > 0 ? tiles : 1));                           // two 64 KB workgroups fit a CU
     if (ks < 1) ks = 1;
     if (ks > 64) ks = 64;
     const int cap = ktiles / 4 > 1 ? ktiles / 4 : 1;
@@ -204,7 +237,7 @@ hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream)
     if (p.x_bytes >= 0x80000000u || p.g_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.ksplit > 1 && !p.partial) return hipErrorInvalidValue;
     dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)((p.Cout + 127) / 128), (unsigned)p.ksplit);
-    wgrad_mfma_kernel<<<grid, dim3(256), 0, stream>>>(p);
+    wgrad_mfma_kernel<<<grid, dim3(256), 2 * 32 * (128 + 128) * sizeof(float), stream>>>(p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (p.ksplit > 1) {
@@ -215,9 +248,15 @@ hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream)
     return e;
 }
 
-hipError_t launch_column_sum(const float *g, long long rows, int Cs, int c_off, int C, float *out, int accumulate, hipStream_t stream)
+int column_sum_chunks(long long rows) { return (int)std::min<long long>(1024, std::max<long long>(1, (rows + 255) / 256)); }
+
+hipError_t launch_column_sum(const float *g, long long rows, int Cs, int c_off, int C, float *out, int accumulate, float *scratch,
+                             hipStream_t stream)
 {
-    column_sum_kernel<<<dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream>>>(g, rows, Cs, c_off, C, out, accumulate);
+    const int chunks = column_sum_chunks(rows);                          // scratch: chunks * C floats
+    const int rpc = (int)((rows + chunks - 1) / chunks);
+    column_sum_kernel<<<dim3((unsigned)((C + 63) / 64), (unsigned)chunks), dim3(256), 0, stream>>>(g, rows, rpc, Cs, c_off, C, scratch);
+    column_sum_final_kernel<<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream>>>(scratch, chunks, C, out, accumulate);
     return hipGetLastError();
 }
 
