@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
                     const int oo = ooff[row];
                     if (cok && oo >= 0) {
                         float v = acc[mb][nb][r] + bv;
-                        if (p.act) v = fmaxf(v, (p.act == 1 ? 0.1f : 0.0f) * v);
+                        if (p.act == 3) v += p.out[(long long)oo + col];                 // accumulate (gradient sums)
+                        else if (p.act) v = fmaxf(v, (p.act == 1 ? 0.1f : 0.0f) * v);
                         p.out[(long long)oo + col] = v;
                     }
                 }
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const ConvParams p)
     }
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + c4 * 4);
     s += bv;
-    if (p.act) {
+    if (p.act == 1 || p.act == 2) {
         const float slope = p.act == 1 ? 0.1f : 0.0f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e], slope * s[e]);
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const ConvParams p)
     const int n = m / hw, r2 = m - n * hw;
     const int j = r2 / ph.Wg, i = r2 - j * ph.Wg;
     const long long oo = ((long long)(n * p.Ho + j * p.s_out + ph.o_y) * p.Wo + i * p.s_out + ph.o_x) * p.Cs_out + p.c_off;
+    if (p.act == 3) s += *reinterpret_cast<const f32x4 *>(p.out + oo + c4 * 4);         // accumulate (gradient sums)
     *reinterpret_cast<f32x4 *>(p.out + oo + c4 * 4) = s;
 }
 

@@ -145,4 +145,66 @@ void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wp
                  [&](int, int, int ci, int n) { return W[((size_t)(n >> 1) * cin + ci) * 2 + (n & 1)]; }, wpk);
 }
 
+// ---------------------------------------------------------------------------------
+// Index tables for DEVICE-side packing (training: the weights change every step, so the gather is replayed on the GPU
+// by pack_apply_kernel): tbl[i] = 1 + index into the raw weight tensor of packed element i, 0 = structural zero.
+// ---------------------------------------------------------------------------------
+template <class F>
+static void pack_index_generic(const KLayout &L, int cs_in, int cin, int kw, int cout, int npad, F ifn, int32_t *tbl)
+{
+    const int kps = L.SEGP / 32;
+    std::memset(tbl, 0, sizeof(int32_t) * (size_t)L.ktiles() * npad * 32);
+    for (int t = 0; t < L.KH; ++t)
+        for (int s = 0; s < L.NSEG; ++s)
+            for (int q = 0; q < L.SEG; ++q) {
+                const int qa = s * L.SEG_STRIDE + q;
+                const int kx = qa / cs_in, ci = qa % cs_in;
+                if (kx >= kw || ci >= cin) continue;
+                const size_t kt = (size_t)(t * L.NSEG + s) * kps + q / 32;
+                int32_t *row = tbl + kt * npad * 32;
+                for (int n = 0; n < cout; ++n) {
+                    const long long src = ifn(t, kx, ci, n);
+                    row[(size_t)n * 32 + swz32(n, q & 31)] = src < 0 ? 0 : (int32_t)(src + 1);
+                }
+            }
+}
+
+void pack_index_conv(int kh, int kw, int cin, int cs_in, int cout, int npad, const KLayout &L, int32_t *tbl)
+{
+    (void)kh;
+    pack_index_generic(L, cs_in, cin, kw, cout, npad,
+                       [&](int t, int kx, int ci, int n) { return (long long)(((size_t)t * kw + kx) * cin + ci) * cout + n; }, tbl);
+}
+
+// Input gradient of a stride-1 conv W[k][k][Cin][Cout] (pad p) = conv over the output gradient with pad k-1-p, the kernel
+// flipped and the channel roles swapped: GEMM columns n = ci, reduction channel = co.
+void pack_index_dgrad_s1(int k, int cin, int cout, int cs_g, const KLayout &L, int npad, int32_t *tbl)
+{
+    pack_index_generic(L, cs_g, cout, k, cin, npad,
+                       [&](int t, int kx, int co, int n) {
+                           return (long long)(((size_t)(k - 1 - t) * k + (k - 1 - kx)) * cin + n) * cout + co;
+                       },
+                       tbl);
+}
+
+// Input gradient of a stride-2 conv W[k][k][Cin][Cout] (pad p) = stride-2 transposed conv of the output gradient:
+// dx[i] = sum over taps t = t0 + 2u (t0 = (i+p)&1) of g[(i + p - t) / 2] W[t].  Four phases (parity of the output pixel) of
+// a conv with KT2 = ceil(k/2) row and column taps in run mode; row tap tt <-> u = KT2-1-tt, i.e. increasing input row.
+void pack_index_dgrad_s2(int k, int pad, int cin, int cout, int cs_g, const KLayout &L, int npad, int32_t *tbl)
+{
+    const int kt2 = (k + 1) / 2;
+    const size_t phase_elems = (size_t)L.ktiles() * npad * 32;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const int t0y = (py + pad) & 1, t0x = (px + pad) & 1;
+            pack_index_generic(L, cs_g, cout, kt2, cin, npad,
+                               [&](int tt, int bx, int co, int n) -> long long {
+                                   const int ky = t0y + 2 * (kt2 - 1 - tt), kx = t0x + 2 * (kt2 - 1 - bx);
+                                   if (ky >= k || kx >= k) return -1;
+                                   return (long long)(((size_t)ky * k + kx) * cin + n) * cout + co;
+                               },
+                               tbl + (size_t)(py * 2 + px) * phase_elems);
+        }
+}
+
 }  // namespace vstab

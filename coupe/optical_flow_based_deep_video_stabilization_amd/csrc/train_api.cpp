@@ -1,6 +1,11 @@
 // C ABI of the training-side building blocks: convolution weight / bias gradients.
 // The loss entry point lives in api.cpp next to the other small wrappers.
 #include <cstdint>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 #include "../../../include/vstab.h"
 #include "api_internal.h"
@@ -56,5 +61,139 @@ extern "C" int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x,
         float *scratch = reinterpret_cast<float *>(reinterpret_cast<char *>(p.partial) + slabs);
         HIP_TRY(nullptr, launch_column_sum(gout, (long long)p.K, cs_g, cg_off, cout, db, accumulate ? 1 : 0, scratch, st));
     }
+    return VSTAB_OK;
+}
+
+// ------------------------------------------------------------------------- input gradient of a convolution
+namespace {
+struct DgradPlan {
+    ConvParams p;
+    ConvTile tile;
+    bool vec4;
+    size_t packed_floats;       // all phases
+    int32_t *tbl;               // device index table, owned by the cache
+};
+
+// geometry -> plan + device index table (built once: the host packer's gather, replayed on the GPU every call because the
+// weights of a training run change every step)
+bool dgrad_plan(int B, int Ho, int Wo, int cs_g, int cout, int k, int stride, int pad, int Hi, int Wi, int cs_x, int cx_off, int cin,
+                int accumulate, DgradPlan &out)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int, int>, DgradPlan> cache;
+    const auto key = std::make_tuple(B, Ho, Wo, cs_g, cout, k, stride, pad, Hi, Wi, cs_x, cx_off, cin, accumulate);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) { out = it->second; return true; }
+    DgradPlan d{};
+    ConvParams &p = d.p;
+    std::vector<int32_t> tbl;
+    const int act = accumulate ? 3 : 0;
+    if (stride == 1) {
+        // conv over gout with pad k-1-pad, flipped kernel, channel roles swapped
+        if (!fill_plain_conv(p, d.tile, d.vec4, B, Ho, Wo, cout, cs_g, k, 1, k - 1 - pad, cin, cs_x, cx_off, act)) return false;
+        if (p.Ho != Hi || p.Wo != Wi || !d.vec4) return false;
+        const KLayout L{p.KH, p.NSEG, p.SEG, p.SEGP, p.SEG_STRIDE};
+        d.packed_floats = (size_t)L.ktiles() * p.Npad * 32;
+        tbl.resize(d.packed_floats);
+        pack_index_dgrad_s1(k, cin, cout, cs_g, L, p.Npad, tbl.data());
+    } else {
+        const int kt2 = (k + 1) / 2;
+        std::memset(&p, 0, sizeof p);
+        p.B = B; p.Hi = Ho; p.Wi = Wo; p.Cs_in = cs_g;
+        const KLayout L = cs_g == cout ? klayout_run(kt2, kt2, cs_g) : klayout_tap(kt2, kt2, cout, cs_g);
+        set_layout(p, L);
+        p.s_in = 1; p.s_out = 2; p.Ho = Hi; p.Wo = Wi; p.Cs_out = cs_x; p.c_off = cx_off;
+        p.N = cin;
+        const int BN = cin >= 128 ? 128 : (cin > 32 ? 64 : 32);
+        d.tile = cin >= 128 ? TILE_128x128 : (cin > 32 ? TILE_128x64 : TILE_128x32);
+        p.Npad = (cin + BN - 1) / BN * BN;
+        p.act = act; p.nphase = 4;
+        const size_t phase_floats = (size_t)L.ktiles() * p.Npad * 32;
+        p.Mmax = 0;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                ConvPhase &ph = p.ph[py * 2 + px];
+                const int t0y = (py + pad) & 1, t0x = (px + pad) & 1;
+                ph.Hg = (Hi - py + 1) / 2; ph.Wg = (Wi - px + 1) / 2;
+                ph.M = B * ph.Hg * ph.Wg;
+                ph.off_y = (py + pad - t0y) / 2 - kt2 + 1; ph.off_x = (px + pad - t0x) / 2 - kt2 + 1;
+                ph.o_y = py; ph.o_x = px;
+                ph.w_off = (long long)(py * 2 + px) * phase_floats;
+                p.Mmax = std::max(p.Mmax, ph.M);
+            }
+        d.vec4 = true;
+        if ((cs_g & 3) || (p.SEG & 3)) return false;
+        set_ranges(p);
+        d.tile = choose_tile_split(p, d.tile, true);
+        d.packed_floats = 4 * phase_floats;
+        tbl.resize(d.packed_floats);
+        pack_index_dgrad_s2(k, pad, cin, cout, cs_g, L, p.Npad, tbl.data());
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;
+    if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d.tbl); return false; }
+    cache[key] = d;
+    out = d;
+    return true;
+}
+
+size_t dgrad_ws(const DgradPlan &d, size_t *bias_off, size_t *part_off)
+{
+    const ConvParams &p = d.p;
+    size_t off = (d.packed_floats * sizeof(float) + 255) / 256 * 256;
+    *bias_off = off;
+    off += ((size_t)p.Npad * sizeof(float) + 255) / 256 * 256;
+    *part_off = off;
+    if (p.ksplit > 1) off += ((size_t)p.nphase * p.ksplit * p.Mmax * p.Npad * sizeof(float) + 255) / 256 * 256;
+    return off + 256;
+}
+}  // namespace
+
+extern "C" size_t vstab_conv_dgrad_workspace_bytes(int B, int Ho, int Wo, int cs_g, int cout, int k, int stride, int pad, int Hi, int Wi,
+                                                   int cs_x, int cx_off, int cin, int accumulate)
+{
+    DgradPlan d;
+    if (!dgrad_plan(B, Ho, Wo, cs_g, cout, k, stride, pad, Hi, Wi, cs_x, cx_off, cin, accumulate ? 1 : 0, d)) return 0;
+    size_t a, b;
+    return dgrad_ws(d, &a, &b);
+}
+
+extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs_g, int cg_off, int cout, const float *W, int k, int stride,
+                                int pad, float *dx, int Hi, int Wi, int cs_x, int cx_off, int cin, int accumulate, void *workspace,
+                                size_t workspace_bytes, void *stream)
+{
+    if (!gout || !W || !dx || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv_dgrad: NULL buffer");
+    if (B < 1 || Ho < 1 || Wo < 1 || Hi < 1 || Wi < 1 || k < 1 || k > 7 || (stride != 1 && stride != 2) || pad < 0 || pad > k - 1 ||
+        cin < 1 || cout < 1 || cg_off < 0 || cx_off < 0 || cg_off + cout > cs_g || cx_off + cin > cs_x)
+        return fail(nullptr, VSTAB_E_SHAPE, "conv_dgrad: bad shape (stride must be 1 or 2)");
+    if ((Hi + 2 * pad - k) / stride + 1 != Ho || (Wi + 2 * pad - k) / stride + 1 != Wo)
+        return fail(nullptr, VSTAB_E_SHAPE, "conv_dgrad: %dx%d input, k %d stride %d pad %d does not give a %dx%d output", Hi, Wi, k,
+                    stride, pad, Ho, Wo);
+    if ((cin & 3) || (cout & 3) || (cs_x & 3) || (cx_off & 3) || (cs_g & 3) || (cg_off & 3))
+        return fail(nullptr, VSTAB_E_ALIGN, "conv_dgrad: channel counts, strides and offsets must be multiples of 4");
+    if ((long long)B * Hi * Wi * cs_x * 4 >= 0x80000000LL || (long long)B * Ho * Wo * cs_g * 4 >= 0x80000000LL)
+        return fail(nullptr, VSTAB_E_SHAPE, "conv_dgrad: tensors must stay below 2 GiB");
+    if ((reinterpret_cast<uintptr_t>(gout) & 15) || (reinterpret_cast<uintptr_t>(dx) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 255))
+        return fail(nullptr, VSTAB_E_ALIGN, "conv_dgrad: gout / dx must be 16-byte, workspace 256-byte aligned");
+    DgradPlan d;
+    // the plan reads gout from its first used channel: cs_g stays the pixel stride, the pointer moves by cg_off
+    if (!dgrad_plan(B, Ho, Wo, cs_g, cout, k, stride, pad, Hi, Wi, cs_x, cx_off, cin, accumulate ? 1 : 0, d))
+        return fail(nullptr, VSTAB_E_SHAPE, "conv_dgrad: unsupported geometry");
+    size_t bias_off, part_off;
+    const size_t need = dgrad_ws(d, &bias_off, &part_off);
+    if (workspace_bytes < need) return fail(nullptr, VSTAB_E_NOMEM, "conv_dgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(nullptr, conv_set_attributes());
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *wpk = reinterpret_cast<float *>(ws);
+    float *bias = reinterpret_cast<float *>(ws + bias_off);
+    HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
+    HIP_TRY(nullptr, hipMemsetAsync(bias, 0, (size_t)d.p.Npad * sizeof(float), st));
+    ConvParams p = d.p;
+    p.in = gout + cg_off;
+    p.in_bytes = (unsigned)((long long)B * Ho * Wo * cs_g * 4 - (long long)cg_off * 4);
+    p.wpk = wpk; p.bias = bias; p.out = dx;
+    p.partial = reinterpret_cast<float *>(ws + part_off);
+    HIP_TRY(nullptr, launch_conv(p, d.tile, d.vec4, st));
     return VSTAB_OK;
 }

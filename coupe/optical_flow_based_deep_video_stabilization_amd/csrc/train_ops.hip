@@ -145,4 +145,20 @@ hipError_t launch_loss_level(const float *pf, const float *G, const float *U, in
     return hipGetLastError();
 }
 
+// device-side weight packing: replay the host packer's gather from its index table
+__global__ __launch_bounds__(256) void pack_apply_kernel(const float *__restrict__ W, const int32_t *__restrict__ tbl, long long n,
+                                                         float *__restrict__ wpk)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t t = tbl[i];
+    wpk[i] = t ? W[t - 1] : 0.f;
+}
+
+hipError_t launch_pack_apply(const float *W, const int32_t *tbl, long long n, float *wpk, hipStream_t stream)
+{
+    pack_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(W, tbl, n, wpk);
+    return hipGetLastError();
+}
+
 }  // namespace vstab

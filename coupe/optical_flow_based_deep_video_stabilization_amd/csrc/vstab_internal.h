@@ -47,7 +47,7 @@ struct ConvParams {
     int s_in, s_out;
     int Ho, Wo, Cs_out, c_off;
     int N, Npad;
-    int act;                // 0 = none, 1 = leaky relu 0.1 (max(v, 0.1 v)), 2 = relu
+    int act;                // 0 = none, 1 = leaky relu 0.1 (max(v, 0.1 v)), 2 = relu, 3 = none, ADD to what is in out
     int nphase, ksplit, Mmax;
     ConvPhase ph[4];
 };
@@ -221,5 +221,12 @@ void pack_deconv5(const float *W, const double *scale, int cin, int cs_in, int c
 // predict head W[3][3][Cin][2] -> tap-table weights: 1x1 conv (run mode over cs_in) with 18 (pad npad)
 // output columns, col = tap*2 + o
 void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wpk);
+
+// Index tables for device-side packing (training): tbl[i] = 1 + raw-weight index of packed element i, 0 = zero.
+void pack_index_conv(int kh, int kw, int cin, int cs_in, int cout, int npad, const KLayout &L, int32_t *tbl);
+void pack_index_dgrad_s1(int k, int cin, int cout, int cs_g, const KLayout &L, int npad, int32_t *tbl);
+void pack_index_dgrad_s2(int k, int pad, int cin, int cout, int cs_g, const KLayout &L, int npad, int32_t *tbl);   // 4 phases of ceil(k/2)^2 taps
+// wpk[i] = tbl[i] ? W[tbl[i]-1] : 0
+hipError_t launch_pack_apply(const float *W, const int32_t *tbl, long long n, float *wpk, hipStream_t stream);
 
 }  // namespace vstab

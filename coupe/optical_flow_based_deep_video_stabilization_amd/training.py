@@ -84,3 +84,35 @@ def conv_wgrad(x, gout, k: int, stride: int, pad: int, cx_off: int = 0, cin: int
                                       k, stride, pad, dW.data_ptr(), db.data_ptr() if want_db else None, 1 if accumulate else 0,
                                       ws.data_ptr(), ws.numel(), runtime.stream_ptr()))
     return dW, (db if want_db else None)
+
+
+def conv_dgrad(gout, W, stride: int, pad: int, in_hw, cg_off: int = 0, cout: int = None, dx=None, cx_off: int = 0,
+               accumulate: bool = False):
+    """Input gradient of PadLayer(pad) -> Conv2d(k, stride, VALID) with filter W [k,k,cin,cout] (CUDA tensor, HWIO):
+    what TF's autodiff returns for tf.nn.conv2d's input.  gout [B,Ho,Wo,Cs_g] (channels cg_off..+cout); the result has
+    the input's size in_hw and lands in channels cx_off..+cin of dx (allocated [B,Hi,Wi,cin] when None)."""
+    if not torch.is_tensor(gout) or not gout.is_cuda or gout.dtype != torch.float32 or gout.dim() != 4:
+        raise ValueError("gout must be a float32 CUDA tensor [B,Ho,Wo,C]")
+    if not torch.is_tensor(W) or not W.is_cuda or W.dtype != torch.float32 or W.dim() != 4 or W.shape[0] != W.shape[1]:
+        raise ValueError("W must be a float32 CUDA tensor [k,k,cin,cout]")
+    gout, W = gout.contiguous(), W.contiguous()
+    B, Ho, Wo, cs_g = gout.shape
+    k, _, cin, cout_w = W.shape
+    cout = cout_w if cout is None else int(cout)
+    if cout != cout_w:
+        raise ValueError("cout must match the filter")
+    Hi, Wi = int(in_hw[0]), int(in_hw[1])
+    if dx is None:
+        dx = torch.empty((B, Hi, Wi, cin), dtype=torch.float32, device=gout.device)
+        accumulate, cx_off = False, 0
+    cs_x = dx.shape[3]
+    L = _lib.lib()
+    nbytes = L.vstab_conv_dgrad_workspace_bytes(B, Ho, Wo, cs_g, cout, k, stride, pad, Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0)
+    if nbytes == 0:
+        raise ValueError("conv_dgrad: unsupported geometry (stride 1 or 2, channel counts multiples of 4, matching sizes)")
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=gout.device)
+    with torch.cuda.device(gout.device):
+        _lib.check(L.vstab_conv_dgrad(gout.data_ptr(), B, Ho, Wo, cs_g, cg_off, cout, W.data_ptr(), k, stride, pad, dx.data_ptr(),
+                                      Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0, ws.data_ptr(), ws.numel(),
+                                      runtime.stream_ptr()))
+    return dx

@@ -228,6 +228,18 @@ VSTAB_API int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x, 
                                int Wo, int cs_g, int cg_off, int cout, int k, int stride, int pad, float *dW, float *db,
                                int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Input gradient of the same layer (tf.gradients w.r.t. the conv's input): dx = transposed conv of gout with
+ * W [k,k,cin,cout] (DEVICE pointer, the reference's HWIO layout), stride 1 or 2.  Runs on the forward MFMA kernel:
+ * stride 1 = conv over gout with the kernel flipped, stride 2 = four output-parity phases of ceil(k/2)^2 taps; the
+ * packed operand is gathered on the device every call (index table cached per geometry).  accumulate != 0: dx += result.
+ * With W = a 4x4 stride-2 transposed conv's [4,4,cout,cin] filter, gout = its input and (k,stride,pad) = (4,2,1) the
+ * same call computes that layer's FORWARD output. */
+VSTAB_API size_t vstab_conv_dgrad_workspace_bytes(int B, int Ho, int Wo, int cs_g, int cout, int k, int stride, int pad, int Hi, int Wi,
+                                                  int cs_x, int cx_off, int cin, int accumulate);
+VSTAB_API int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs_g, int cg_off, int cout, const float *W, int k,
+                               int stride, int pad, float *dx, int Hi, int Wi, int cs_x, int cx_off, int cin, int accumulate,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* scipy.signal.medfilt(np.squeeze(of), k) (evaluate_medianNma, main_flownetS_pyramid.py:809): order filter over a
  * kh x kw x kc window of each [h,w,2] field -- kc spans the channel axis; the reference's scalar 5 means 5x5x5 --
  * zero padded on all axes, output = element n/2 of the sorted window.  Odd sizes, kh,kw <= 31, kc <= 5; out != flow. */

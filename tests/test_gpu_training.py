@@ -136,3 +136,56 @@ def test_deconv_filter_gradient_via_swapped_roles():
     dW, _ = training.conv_wgrad(dy.cuda(), x.cuda(), 4, 2, 1, want_db=False)            # [4,4,cin_of_conv=cout, cout_of_conv=cin]
     assert dW.shape == ref.shape
     assert float((dW.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+# ----------------------------------------------------------------------------- conv input gradient (forward MFMA kernel)
+def _torch_dgrad(g, W_hwio, s, p, in_hw):
+    import torch.nn.functional as F
+    B = g.shape[0]
+    cin = W_hwio.shape[2]
+    x = torch.zeros(B, cin, in_hw[0], in_hw[1], dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, W_hwio.double().permute(3, 2, 0, 1), stride=s, padding=p)
+    y.backward(g.double().permute(0, 3, 1, 2))
+    return x.grad.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,Hi,Wi,cin,cout,k,s,p", [
+    (2, 12, 16, 64, 128, 3, 1, 1),        # conv3_1-like
+    (2, 13, 17, 128, 256, 5, 2, 2),       # conv3-like, odd input size
+    (2, 14, 18, 64, 128, 5, 2, 2),        # even input size
+    (1, 9, 11, 256, 512, 3, 2, 1),        # conv4-like, odd
+    (2, 10, 12, 256, 512, 3, 2, 1),       # even
+    (3, 6, 7, 8, 20, 3, 1, 1),            # small channel counts
+    (2, 8, 8, 196, 32, 1, 1, 0),          # 1x1
+    (1, 22, 26, 64, 64, 7, 2, 3),         # 7x7 stride 2
+    (2, 16, 16, 512, 512, 3, 1, 1),       # split-K
+])
+def test_conv_dgrad_matches_autograd(B, Hi, Wi, cin, cout, k, s, p):
+    g0 = torch.Generator().manual_seed(B * 10 + cout + k)
+    Ho, Wo = (Hi + 2 * p - k) // s + 1, (Wi + 2 * p - k) // s + 1
+    g = torch.randn(B, Ho, Wo, cout, generator=g0)
+    W = torch.randn(k, k, cin, cout, generator=g0) / (k * k * cout) ** 0.5
+    dx = training.conv_dgrad(g.cuda(), W.cuda(), s, p, (Hi, Wi))
+    ref = _torch_dgrad(g, W, s, p, (Hi, Wi))
+    assert dx.shape == ref.shape
+    assert float((dx.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+
+
+def test_conv_dgrad_slices_accumulate_and_deconv_forward():
+    import torch.nn.functional as F
+    g0 = torch.Generator().manual_seed(3)
+    B, Hi, Wi, cin, cout, k, s, p = 2, 10, 14, 16, 24, 3, 2, 1
+    Ho, Wo = (Hi + 2 * p - k) // s + 1, (Wi + 2 * p - k) // s + 1
+    gw = torch.randn(B, Ho, Wo, 40, generator=g0)                  # gradient lives in channels 8..32 of a wider pixel
+    W = torch.randn(k, k, cin, cout, generator=g0) * 0.1
+    dxw = torch.randn(B, Hi, Wi, 28, generator=g0)                 # result accumulates into channels 4..20
+    ref = dxw.double().clone()
+    ref[..., 4:20] += _torch_dgrad(gw[..., 8:32], W, s, p, (Hi, Wi))
+    out = training.conv_dgrad(gw.cuda(), W.cuda(), s, p, (Hi, Wi), cg_off=8, dx=dxw.cuda(), cx_off=4, accumulate=True)
+    assert float((out.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # DeConv2dLayer forward (4x4 s2 SAME, filter [4,4,cout,cin]) through the same entry point
+    x = torch.randn(2, 5, 6, 16, generator=g0)
+    Wd = torch.randn(4, 4, 8, 16, generator=g0) * 0.1                # [4,4,out,in]
+    y = training.conv_dgrad(x.cuda(), Wd.cuda(), 2, 1, (10, 12))
+    yref = F.conv_transpose2d(x.double().permute(0, 3, 1, 2), Wd.double().permute(3, 2, 0, 1), stride=2, padding=1).permute(0, 2, 3, 1)
+    assert float((y.double().cpu() - yref).abs().max()) <= 2e-5 * float(yref.abs().max())
