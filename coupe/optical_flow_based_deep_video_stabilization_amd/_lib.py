@@ -63,6 +63,12 @@ EXPORTS = {
     "vstab_conv_dgrad_workspace_bytes": (C.c_size_t, [C.c_int] * 14),
     "vstab_conv_dgrad": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] + [C.c_int] * 6 +
                          [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vstab_bn_scratch_bytes": (C.c_size_t, [C.c_longlong, C.c_int]),
+    "vstab_bn_lrelu_train_forward": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vstab_bn_lrelu_train_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vstab_lrelu_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p]),
     "vstab_flow_medfilt": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "vstab_flow_mean_fill": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
     "vstab_level_sizes": (C.c_int, [C.c_int, C.c_int, c_int32_p]),

@@ -197,3 +197,47 @@ extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs
     HIP_TRY(nullptr, launch_conv(p, d.tile, d.vec4, st));
     return VSTAB_OK;
 }
+
+// ------------------------------------------------------------------------- BatchNorm (training mode) + leaky relu
+extern "C" size_t vstab_bn_scratch_bytes(long long rows, int C)
+{
+    if (rows < 1 || C < 1) return 0;
+    return ((size_t)2 * bn_chunks(rows) + 2) * C * sizeof(float) + 256;
+}
+
+extern "C" int vstab_bn_lrelu_train_forward(float *zy, long long rows, int cs, int c_off, int C, const float *beta, float *moving_mean,
+                                            float *moving_var, float decay, float eps, float *save_mean, float *save_rstd, void *scratch,
+                                            size_t scratch_bytes, void *stream)
+{
+    if (!zy || !beta || !save_mean || !save_rstd || !scratch) return fail(nullptr, VSTAB_E_STATE, "bn_lrelu_train_forward: NULL buffer");
+    if (rows < 1 || C < 1 || c_off < 0 || c_off + C > cs) return fail(nullptr, VSTAB_E_SHAPE, "bn_lrelu_train_forward: bad shape");
+    if ((C & 3) || (cs & 3) || (c_off & 3) || (reinterpret_cast<uintptr_t>(zy) & 15) || (reinterpret_cast<uintptr_t>(beta) & 15) ||
+        (reinterpret_cast<uintptr_t>(save_mean) & 15) || (reinterpret_cast<uintptr_t>(save_rstd) & 15))
+        return fail(nullptr, VSTAB_E_ALIGN, "bn_lrelu_train_forward: channels multiples of 4, 16-byte aligned buffers");
+    if (scratch_bytes < vstab_bn_scratch_bytes(rows, C)) return fail(nullptr, VSTAB_E_NOMEM, "bn_lrelu_train_forward: scratch too small");
+    HIP_TRY(nullptr, launch_bn_lrelu_train_forward(zy, rows, cs, c_off, C, beta, moving_mean, moving_var, decay, eps, save_mean, save_rstd,
+                                                   reinterpret_cast<float *>(scratch), (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_bn_lrelu_train_backward(const float *y, int cs_y, int cy_off, float *dy, int cs_g, int cg_off, int C, long long rows,
+                                             const float *beta, const float *save_rstd, float *dbeta, int accumulate, void *scratch,
+                                             size_t scratch_bytes, void *stream)
+{
+    if (!y || !dy || !beta || !save_rstd || !scratch) return fail(nullptr, VSTAB_E_STATE, "bn_lrelu_train_backward: NULL buffer");
+    if (rows < 1 || C < 1 || cy_off < 0 || cg_off < 0 || cy_off + C > cs_y || cg_off + C > cs_g)
+        return fail(nullptr, VSTAB_E_SHAPE, "bn_lrelu_train_backward: bad shape");
+    if (scratch_bytes < vstab_bn_scratch_bytes(rows, C)) return fail(nullptr, VSTAB_E_NOMEM, "bn_lrelu_train_backward: scratch too small");
+    HIP_TRY(nullptr, launch_bn_lrelu_train_backward(y, cs_y, cy_off, dy, cs_g, cg_off, C, rows, beta, save_rstd, dbeta, accumulate ? 1 : 0,
+                                                    reinterpret_cast<float *>(scratch), (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_lrelu_backward(const float *y, int cs_y, int cy_off, float *dy, int cs_g, int cg_off, int C, long long rows, void *stream)
+{
+    if (!y || !dy) return fail(nullptr, VSTAB_E_STATE, "lrelu_backward: NULL buffer");
+    if (rows < 1 || C < 1 || cy_off < 0 || cg_off < 0 || cy_off + C > cs_y || cg_off + C > cs_g)
+        return fail(nullptr, VSTAB_E_SHAPE, "lrelu_backward: bad shape");
+    HIP_TRY(nullptr, launch_lrelu_backward(y, cs_y, cy_off, dy, cs_g, cg_off, C, rows, (hipStream_t)stream));
+    return VSTAB_OK;
+}

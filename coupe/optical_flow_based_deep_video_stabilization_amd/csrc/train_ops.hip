@@ -21,6 +21,7 @@
 namespace vstab {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 struct Corners {
@@ -142,6 +143,175 @@ hipError_t launch_loss_level(const float *pf, const float *G, const float *U, in
     dim3 grid((unsigned)((h * w + 255) / 256), (unsigned)B);
     loss_sums_kernel<<<grid, dim3(256), 0, stream>>>(pf, G, U, h, w, sums);
     if (grad) loss_grad_kernel<<<grid, dim3(256), 0, stream>>>(pf, G, U, B, h, w, sums, scale_mse, scale_tv, grad);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// BatchNormLayer(act = lrelu 0.1, is_train = True, gamma_init = None) (model.py:809 etc.; TensorLayer 1.x):
+//   mean, var = tf.nn.moments(z, [0,1,2])  (population variance);  y = lrelu((z - mean) * rsqrt(var + eps) + beta);
+//   moving = moving * decay + batch * (1 - decay)   (assign_moving_average, zero_debias = False)
+// and its backward.  Column reductions over the [rows, C] view of an NHWC channel slice run in two deterministic stages
+// (row-chunk partials, then the chunks in order), like column_sum_kernel.  The layer works IN PLACE: the conv's output z
+// is overwritten by y, and the backward recovers what it needs from y (lrelu is invertible: u = y > 0 ? y : y / 0.1,
+// xhat = u - beta), so no second activation copy is kept.
+// ---------------------------------------------------------------------------------
+namespace {
+// MODE 0: sum z | 1: sum (z - m[c])^2 | 2: two sums for the backward: sum g, sum g * xhat  (g = dy * lrelu'(y))
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_colsum_kernel(const float *__restrict__ a, int cs_a, int ca_off, const float *__restrict__ b,
+                                                        int cs_b, int cb_off, const float *__restrict__ vec, long long rows,
+                                                        int rows_per_chunk, int C, float *__restrict__ part)
+{
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        const float v = (MODE == 0) ? 0.f : vec[c];                  // MODE 1: mean, MODE 2: beta
+        for (long long r = r0 + wave; r < r1; r += 4) {
+            const float x = a[r * cs_a + ca_off + c];
+            if (MODE == 0) s0 += x;
+            else if (MODE == 1) { const float d = x - v; s0 += d * d; }
+            else {
+                const float y = x, dy = b[r * cs_b + cb_off + c];
+                const float g = y > 0.f ? dy : 0.1f * dy;
+                const float xhat = (y > 0.f ? y : y / 0.1f) - v;
+                s0 += g;
+                s1 += g * xhat;
+            }
+        }
+    }
+    red[0][wave][threadIdx.x & 63] = s0;
+    red[1][wave][threadIdx.x & 63] = s1;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        const int l = threadIdx.x;
+        part[((long long)blockIdx.y * 2 + 0) * C + c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        if (MODE == 2) part[((long long)blockIdx.y * 2 + 1) * C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    }
+}
+
+// final stage of the forward statistics: STEP 0 -> mean; STEP 1 -> rstd + moving-average update
+template <int STEP>
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__restrict__ part, int chunks, int C, float inv_rows, float eps,
+                                                             float decay, float *__restrict__ mean, float *__restrict__ rstd,
+                                                             float *__restrict__ mov_mean, float *__restrict__ mov_var)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(long long)k * 2 * C + c];
+    if (STEP == 0) mean[c] = s * inv_rows;
+    else {
+        const float var = s * inv_rows;
+        rstd[c] = 1.0f / sqrtf(var + eps);
+        if (mov_mean) mov_mean[c] = mov_mean[c] * decay + mean[c] * (1.f - decay);
+        if (mov_var) mov_var[c] = mov_var[c] * decay + var * (1.f - decay);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(float *__restrict__ zy, int cs, int c_off, int C4, long long rows,
+                                                             const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                             const float *__restrict__ beta)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C4) return;
+    const long long r = idx / C4;
+    const int c = (int)(idx - r * C4) * 4;
+    float *p = zy + r * cs + c_off + c;
+    f32x4v v = *reinterpret_cast<f32x4v *>(p);
+    const f32x4v m = *reinterpret_cast<const f32x4v *>(mean + c), s = *reinterpret_cast<const f32x4v *>(rstd + c);
+    const f32x4v b = *reinterpret_cast<const f32x4v *>(beta + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float u = (v[e] - m[e]) * s[e] + b[e];
+        v[e] = fmaxf(u, 0.1f * u);
+    }
+    *reinterpret_cast<f32x4v *>(p) = v;
+}
+
+// backward sums: sums[c] = sum g, sums[C + c] = sum g * xhat (chunks added in order); dbeta = sum g
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restrict__ part, int chunks, int C, float *__restrict__ sums,
+                                                           float *__restrict__ dbeta, int accumulate)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < chunks; ++k) { a += part[((long long)k * 2 + 0) * C + c]; b += part[((long long)k * 2 + 1) * C + c]; }
+    sums[c] = a;
+    sums[C + c] = b;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;
+}
+
+// dz = rstd * (g - sum_g / R - xhat * sum_gx / R), written over dy
+__global__ __launch_bounds__(256) void bn_lrelu_bwd_apply_kernel(const float *__restrict__ y, int cs_y, int cy_off, float *__restrict__ dy,
+                                                                 int cs_g, int cg_off, int C, long long rows,
+                                                                 const float *__restrict__ sums, const float *__restrict__ beta,
+                                                                 const float *__restrict__ rstd, float inv_rows)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C) return;
+    const long long r = idx / C;
+    const int c = (int)(idx - r * C);
+    const float yy = y[r * cs_y + cy_off + c], d = dy[r * cs_g + cg_off + c];
+    const float g = yy > 0.f ? d : 0.1f * d;
+    const float xhat = (yy > 0.f ? yy : yy / 0.1f) - beta[c];
+    dy[r * cs_g + cg_off + c] = rstd[c] * (g - sums[c] * inv_rows - xhat * (sums[C + c] * inv_rows));
+}
+
+// leaky-relu backward alone (layers without BatchNorm): dy *= (y > 0 ? 1 : 0.1)
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float *__restrict__ y, int cs_y, int cy_off, float *__restrict__ dy, int cs_g,
+                                                        int cg_off, int C, long long rows)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C) return;
+    const long long r = idx / C;
+    const int c = (int)(idx - r * C);
+    if (!(y[r * cs_y + cy_off + c] > 0.f)) dy[r * cs_g + cg_off + c] *= 0.1f;
+}
+}  // namespace
+
+int bn_chunks(long long rows) { return (int)min((long long)1024, max((long long)1, (rows + 255) / 256)); }
+
+hipError_t launch_bn_lrelu_train_forward(float *zy, long long rows, int cs, int c_off, int C, const float *beta, float *mov_mean,
+                                         float *mov_var, float decay, float eps, float *save_mean, float *save_rstd, float *scratch,
+                                         hipStream_t stream)
+{
+    if ((C & 3) || (cs & 3) || (c_off & 3)) return hipErrorInvalidValue;
+    const int chunks = bn_chunks(rows);                                   // scratch: 2 * chunks * C floats
+    const int rpc = (int)((rows + chunks - 1) / chunks);
+    const dim3 g1((unsigned)((C + 63) / 64), (unsigned)chunks), g2((unsigned)((C + 255) / 256));
+    const float inv = 1.0f / (float)rows;
+    bn_colsum_kernel<0><<<g1, dim3(256), 0, stream>>>(zy, cs, c_off, nullptr, 0, 0, nullptr, rows, rpc, C, scratch);
+    bn_stats_final_kernel<0><<<g2, dim3(256), 0, stream>>>(scratch, chunks, C, inv, eps, decay, save_mean, save_rstd, mov_mean, mov_var);
+    bn_colsum_kernel<1><<<g1, dim3(256), 0, stream>>>(zy, cs, c_off, nullptr, 0, 0, save_mean, rows, rpc, C, scratch);
+    bn_stats_final_kernel<1><<<g2, dim3(256), 0, stream>>>(scratch, chunks, C, inv, eps, decay, save_mean, save_rstd, mov_mean, mov_var);
+    const long long n4 = rows * (C / 4);
+    bn_lrelu_apply_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream>>>(zy, cs, c_off, C / 4, rows, save_mean, save_rstd, beta);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_lrelu_train_backward(const float *y, int cs_y, int cy_off, float *dy, int cs_g, int cg_off, int C, long long rows,
+                                          const float *beta, const float *save_rstd, float *dbeta, int accumulate, float *scratch,
+                                          hipStream_t stream)
+{
+    const int chunks = bn_chunks(rows);
+    const int rpc = (int)((rows + chunks - 1) / chunks);
+    bn_colsum_kernel<2><<<dim3((unsigned)((C + 63) / 64), (unsigned)chunks), dim3(256), 0, stream>>>(y, cs_y, cy_off, dy, cs_g, cg_off, beta,
+                                                                                                  rows, rpc, C, scratch);
+    float *sums = scratch + (size_t)2 * chunks * C;                        // scratch: (2 * chunks + 2) * C floats
+    bn_bwd_final_kernel<<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream>>>(scratch, chunks, C, sums, dbeta, accumulate);
+    const long long n = rows * C;
+    bn_lrelu_bwd_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(y, cs_y, cy_off, dy, cs_g, cg_off, C, rows, sums,
+                                                                                         beta, save_rstd, 1.0f / (float)rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_lrelu_backward(const float *y, int cs_y, int cy_off, float *dy, int cs_g, int cg_off, int C, long long rows,
+                                 hipStream_t stream)
+{
+    const long long n = rows * C;
+    lrelu_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(y, cs_y, cy_off, dy, cs_g, cg_off, C, rows);
     return hipGetLastError();
 }
 

@@ -222,6 +222,18 @@ void pack_deconv5(const float *W, const double *scale, int cin, int cs_in, int c
 // output columns, col = tap*2 + o
 void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wpk);
 
+// BatchNormLayer(lrelu 0.1, no gamma) in training mode, in place on an NHWC channel slice, and its backward (train_ops.hip).
+// scratch: 2 * bn_chunks(rows) * C floats.
+int bn_chunks(long long rows);
+hipError_t launch_bn_lrelu_train_forward(float *zy, long long rows, int cs, int c_off, int C, const float *beta, float *mov_mean,
+                                         float *mov_var, float decay, float eps, float *save_mean, float *save_rstd, float *scratch,
+                                         hipStream_t stream);
+hipError_t launch_bn_lrelu_train_backward(const float *y, int cs_y, int cy_off, float *dy, int cs_g, int cg_off, int C, long long rows,
+                                          const float *beta, const float *save_rstd, float *dbeta, int accumulate, float *scratch,
+                                          hipStream_t stream);
+hipError_t launch_lrelu_backward(const float *y, int cs_y, int cy_off, float *dy, int cs_g, int cg_off, int C, long long rows,
+                                 hipStream_t stream);
+
 // Index tables for device-side packing (training): tbl[i] = 1 + raw-weight index of packed element i, 0 = zero.
 void pack_index_conv(int kh, int kw, int cin, int cs_in, int cout, int npad, const KLayout &L, int32_t *tbl);
 void pack_index_dgrad_s1(int k, int cin, int cout, int cs_g, const KLayout &L, int npad, int32_t *tbl);

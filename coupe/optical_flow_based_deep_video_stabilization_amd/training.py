@@ -116,3 +116,56 @@ def conv_dgrad(gout, W, stride: int, pad: int, in_hw, cg_off: int = 0, cout: int
                                       Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0, ws.data_ptr(), ws.numel(),
                                       runtime.stream_ptr()))
     return dx
+
+
+def _rows_view(t, c_off, C):
+    if not torch.is_tensor(t) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4 or not t.is_contiguous():
+        raise ValueError("expected a contiguous float32 CUDA tensor [B,H,W,C]")
+    cs = t.shape[3]
+    C = cs - c_off if C is None else int(C)
+    return t.shape[0] * t.shape[1] * t.shape[2], cs, C
+
+
+def bn_lrelu_train_forward(z, beta, moving_mean=None, moving_var=None, decay: float = 0.9, eps: float = 1e-5, c_off: int = 0, C: int = None):
+    """BatchNormLayer(act=lrelu 0.1, is_train=True, gamma_init=None) IN PLACE on channels c_off..+C of z (model.py:809 etc.):
+    z is overwritten by y; moving_mean / moving_var (if given) get TensorLayer's moving-average update.
+    Returns (y (= z), save_mean, save_rstd)."""
+    rows, cs, C = _rows_view(z, c_off, C)
+    mean = torch.empty(C, dtype=torch.float32, device=z.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=z.device)
+    L = _lib.lib()
+    sc = torch.empty(int(L.vstab_bn_scratch_bytes(rows, C)), dtype=torch.uint8, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(L.vstab_bn_lrelu_train_forward(z.data_ptr(), rows, cs, c_off, C, beta.data_ptr(),
+                                                  moving_mean.data_ptr() if moving_mean is not None else None,
+                                                  moving_var.data_ptr() if moving_var is not None else None, float(decay), float(eps),
+                                                  mean.data_ptr(), rstd.data_ptr(), sc.data_ptr(), sc.numel(), runtime.stream_ptr()))
+    return z, mean, rstd
+
+
+def bn_lrelu_train_backward(y, dy, beta, save_rstd, cy_off: int = 0, cg_off: int = 0, C: int = None, dbeta=None, accumulate: bool = False):
+    """Backward of the layer above: dy (gradient w.r.t. y) is overwritten IN PLACE by the gradient w.r.t. the layer's input;
+    returns (dz (= dy), dbeta)."""
+    rows, cs_y, Cy = _rows_view(y, cy_off, C)
+    rows_g, cs_g, Cg = _rows_view(dy, cg_off, C)
+    if rows != rows_g or Cy != Cg:
+        raise ValueError("y and dy must cover the same rows and channel count")
+    if dbeta is None:
+        dbeta = torch.empty(Cy, dtype=torch.float32, device=y.device)
+        accumulate = False
+    L = _lib.lib()
+    sc = torch.empty(int(L.vstab_bn_scratch_bytes(rows, Cy)), dtype=torch.uint8, device=y.device)
+    with torch.cuda.device(y.device):
+        _lib.check(L.vstab_bn_lrelu_train_backward(y.data_ptr(), cs_y, cy_off, dy.data_ptr(), cs_g, cg_off, Cy, rows, beta.data_ptr(),
+                                                   save_rstd.data_ptr(), dbeta.data_ptr(), 1 if accumulate else 0, sc.data_ptr(),
+                                                   sc.numel(), runtime.stream_ptr()))
+    return dy, dbeta
+
+
+def lrelu_backward(y, dy, cy_off: int = 0, cg_off: int = 0, C: int = None):
+    """dy *= (y > 0 ? 1 : 0.1) in place."""
+    rows, cs_y, Cy = _rows_view(y, cy_off, C)
+    _, cs_g, _ = _rows_view(dy, cg_off, C)
+    with torch.cuda.device(y.device):
+        _lib.check(_lib.lib().vstab_lrelu_backward(y.data_ptr(), cs_y, cy_off, dy.data_ptr(), cs_g, cg_off, Cy, rows, runtime.stream_ptr()))
+    return dy

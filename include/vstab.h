@@ -240,6 +240,21 @@ VSTAB_API int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs_
                                int stride, int pad, float *dx, int Hi, int Wi, int cs_x, int cx_off, int cin, int accumulate,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* BatchNormLayer(act=lrelu 0.1, is_train=True, gamma_init=None) (model.py:809...) IN PLACE on channels c_off..c_off+C of
+ * an NHWC tensor viewed as [rows, cs]: batch mean / population variance (tf.nn.moments), y = lrelu((z-mean)*rsqrt(var+eps)
+ * + beta), moving = moving*decay + batch*(1-decay) (moving_* may be NULL).  save_mean / save_rstd [C] feed the backward. */
+VSTAB_API size_t vstab_bn_scratch_bytes(long long rows, int C);
+VSTAB_API int vstab_bn_lrelu_train_forward(float *zy, long long rows, int cs, int c_off, int C, const float *beta, float *moving_mean,
+                                           float *moving_var, float decay, float eps, float *save_mean, float *save_rstd, void *scratch,
+                                           size_t scratch_bytes, void *stream);
+/* Its backward: dy (gradient w.r.t. y, channels cg_off..+C of a [rows, cs_g] tensor) is overwritten by the gradient w.r.t.
+ * the layer's input z; dbeta [C] = sum dy*lrelu'(y) (may be NULL).  y: the forward's output (xhat is recovered from it). */
+VSTAB_API int vstab_bn_lrelu_train_backward(const float *y, int cs_y, int cy_off, float *dy, int cs_g, int cg_off, int C, long long rows,
+                                            const float *beta, const float *save_rstd, float *dbeta, int accumulate, void *scratch,
+                                            size_t scratch_bytes, void *stream);
+/* dy *= (y > 0 ? 1 : 0.1): leaky-relu backward for layers without BatchNorm. */
+VSTAB_API int vstab_lrelu_backward(const float *y, int cs_y, int cy_off, float *dy, int cs_g, int cg_off, int C, long long rows, void *stream);
+
 /* scipy.signal.medfilt(np.squeeze(of), k) (evaluate_medianNma, main_flownetS_pyramid.py:809): order filter over a
  * kh x kw x kc window of each [h,w,2] field -- kc spans the channel axis; the reference's scalar 5 means 5x5x5 --
  * zero padded on all axes, output = element n/2 of the sorted window.  Odd sizes, kh,kw <= 31, kc <= 5; out != flow. */

@@ -189,3 +189,49 @@ def test_conv_dgrad_slices_accumulate_and_deconv_forward():
     y = training.conv_dgrad(x.cuda(), Wd.cuda(), 2, 1, (10, 12))
     yref = F.conv_transpose2d(x.double().permute(0, 3, 1, 2), Wd.double().permute(3, 2, 0, 1), stride=2, padding=1).permute(0, 2, 3, 1)
     assert float((y.double().cpu() - yref).abs().max()) <= 2e-5 * float(yref.abs().max())
+
+
+# ----------------------------------------------------------------------------- BatchNorm (training mode) + leaky relu
+def _bn_ref(z, beta, eps=1e-5):
+    z = z.double().clone().requires_grad_(True)
+    mean = z.mean(dim=(0, 1, 2))
+    var = ((z - mean) ** 2).mean(dim=(0, 1, 2))
+    u = (z - mean) / torch.sqrt(var + eps) + beta.double()
+    y = torch.maximum(u, 0.1 * u)
+    return z, y, mean, var
+
+
+@pytest.mark.parametrize("B,H,W,cs,c_off,C", [(2, 9, 11, 64, 0, 64), (3, 16, 16, 40, 8, 24), (1, 33, 47, 128, 0, 128), (8, 32, 32, 68, 4, 64)])
+def test_bn_lrelu_train_forward_backward(B, H, W, cs, c_off, C):
+    g0 = torch.Generator().manual_seed(C + H)
+    zfull = torch.randn(B, H, W, cs, generator=g0) * 2 + 0.5
+    beta = torch.randn(C, generator=g0) * 0.3
+    mm, mv = torch.randn(C, generator=g0), torch.rand(C, generator=g0) + 0.5
+    dyfull = torch.randn(B, H, W, cs, generator=g0)
+    zr, yr, mean, var = _bn_ref(zfull[..., c_off:c_off + C], beta)
+    yr.backward(dyfull[..., c_off:c_off + C].double())
+    zg, mmg, mvg = zfull.clone().cuda(), mm.clone().cuda(), mv.clone().cuda()
+    y, smean, srstd = training.bn_lrelu_train_forward(zg, beta.cuda(), mmg, mvg, decay=0.9, c_off=c_off, C=C)
+    yc = y.cpu()
+    assert float((yc[..., c_off:c_off + C].double() - yr.detach()).abs().max()) <= 2e-5
+    if c_off:
+        assert torch.equal(yc[..., :c_off], zfull[..., :c_off])                      # channels outside the slice untouched
+    assert float((smean.double().cpu() - mean.detach()).abs().max()) <= 1e-5
+    assert float((srstd.double().cpu() - 1 / torch.sqrt(var.detach() + 1e-5)).abs().max()) <= 1e-4
+    assert float((mmg.double().cpu() - (mm.double() * 0.9 + mean.detach() * 0.1)).abs().max()) <= 1e-5
+    assert float((mvg.double().cpu() - (mv.double() * 0.9 + var.detach() * 0.1)).abs().max()) <= 1e-5
+    dg = dyfull.clone().cuda()
+    dz, dbeta = training.bn_lrelu_train_backward(y, dg, beta.cuda(), srstd, cy_off=c_off, cg_off=c_off, C=C)
+    ref = zr.grad
+    assert float((dz.cpu()[..., c_off:c_off + C].double() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max()))
+    gl = dyfull[..., c_off:c_off + C].double() * torch.where(yr.detach() > 0, 1.0, 0.1)
+    assert float((dbeta.double().cpu() - gl.sum(dim=(0, 1, 2))).abs().max()) <= 1e-4 * max(1.0, float(gl.sum(dim=(0, 1, 2)).abs().max()))
+
+
+def test_lrelu_backward():
+    y = torch.randn(2, 5, 6, 12)
+    dy = torch.randn(2, 5, 6, 12)
+    out = training.lrelu_backward(y.cuda(), dy.clone().cuda(), cy_off=4, cg_off=4, C=8).cpu()
+    ref = dy.clone()
+    ref[..., 4:] = dy[..., 4:] * torch.where(y[..., 4:] > 0, 1.0, 0.1)
+    assert torch.allclose(out, ref, atol=0, rtol=1e-7)
