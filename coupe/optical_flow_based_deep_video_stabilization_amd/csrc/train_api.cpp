@@ -32,9 +32,12 @@ extern "C" int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x,
     if (B < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || k < 1 || k > 7 || stride < 1 || pad < 0 || cin < 1 || cout < 1 ||
         cx_off < 0 || cg_off < 0 || cx_off + cin > cs_x || cg_off + cout > cs_g)
         return fail(nullptr, VSTAB_E_SHAPE, "conv_wgrad: bad shape");
-    if ((Hi + 2 * pad - k) / stride + 1 != Ho || (Wi + 2 * pad - k) / stride + 1 != Wo)
-        return fail(nullptr, VSTAB_E_SHAPE, "conv_wgrad: %dx%d input, k %d stride %d pad %d does not give a %dx%d output", Hi, Wi, k,
-                    stride, pad, Ho, Wo);
+    {   // one extra output row/col is allowed (TF SAME on odd sizes / cropped transposed conv); its out-of-image taps read zero
+        const int Ho_min = (Hi + 2 * pad - k) / stride + 1, Wo_min = (Wi + 2 * pad - k) / stride + 1;
+        if (Ho < Ho_min || Wo < Wo_min || Ho > Ho_min + 1 || Wo > Wo_min + 1)
+            return fail(nullptr, VSTAB_E_SHAPE, "conv_wgrad: %dx%d input, k %d stride %d pad %d does not match a %dx%d output", Hi, Wi, k,
+                        stride, pad, Ho, Wo);
+    }
     if ((cin & 3) || (cs_x & 3) || (cx_off & 3) || (cs_g & 3) || (cg_off & 3))
         return fail(nullptr, VSTAB_E_ALIGN, "conv_wgrad: channel counts, strides and offsets must be multiples of 4");
     if ((long long)B * Hi * Wi * cs_x * 4 >= 0x80000000LL || (long long)B * Ho * Wo * cs_g * 4 >= 0x80000000LL)
@@ -158,16 +161,20 @@ extern "C" size_t vstab_conv_dgrad_workspace_bytes(int B, int Ho, int Wo, int cs
     return dgrad_ws(d, &a, &b);
 }
 
-extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs_g, int cg_off, int cout, const float *W, int k, int stride,
-                                int pad, float *dx, int Hi, int Wi, int cs_x, int cx_off, int cin, int accumulate, void *workspace,
-                                size_t workspace_bytes, void *stream)
+extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs_g, int cg_off, int cout, const float *W, const float *bias_in,
+                                int k, int stride, int pad, float *dx, int Hi, int Wi, int cs_x, int cx_off, int cin, int accumulate,
+                                void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!gout || !W || !dx || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv_dgrad: NULL buffer");
     if (B < 1 || Ho < 1 || Wo < 1 || Hi < 1 || Wi < 1 || k < 1 || k > 7 || (stride != 1 && stride != 2) || pad < 0 || pad > k - 1 ||
         cin < 1 || cout < 1 || cg_off < 0 || cx_off < 0 || cg_off + cout > cs_g || cx_off + cin > cs_x)
         return fail(nullptr, VSTAB_E_SHAPE, "conv_dgrad: bad shape (stride must be 1 or 2)");
-    if ((Hi + 2 * pad - k) / stride + 1 != Ho || (Wi + 2 * pad - k) / stride + 1 != Wo)
-        return fail(nullptr, VSTAB_E_SHAPE, "conv_dgrad: %dx%d input, k %d stride %d pad %d does not give a %dx%d output", Hi, Wi, k,
+    // gout may have MORE rows/cols than a symmetric-pad conv of dx's size would give: TF's SAME conv of an odd size pads one more
+    // at the end, and a transposed conv with a cropped output_shape (model.py:850: 23 <- 12) is exactly that case.  Windows that
+    // stick out past dx simply lose those taps (range checks).
+    const int Ho_min = (Hi + 2 * pad - k) / stride + 1, Wo_min = (Wi + 2 * pad - k) / stride + 1;
+    if (Ho < Ho_min || Wo < Wo_min || Ho > Ho_min + 1 || Wo > Wo_min + 1 || (stride == 1 && (Ho != Ho_min || Wo != Wo_min)))
+        return fail(nullptr, VSTAB_E_SHAPE, "conv_dgrad: %dx%d input, k %d stride %d pad %d does not match a %dx%d output", Hi, Wi, k,
                     stride, pad, Ho, Wo);
     if ((cin & 3) || (cout & 3) || (cs_x & 3) || (cx_off & 3) || (cs_g & 3) || (cg_off & 3))
         return fail(nullptr, VSTAB_E_ALIGN, "conv_dgrad: channel counts, strides and offsets must be multiples of 4");
@@ -189,6 +196,7 @@ extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs
     float *bias = reinterpret_cast<float *>(ws + bias_off);
     HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
     HIP_TRY(nullptr, hipMemsetAsync(bias, 0, (size_t)d.p.Npad * sizeof(float), st));
+    if (bias_in) HIP_TRY(nullptr, hipMemcpyAsync(bias, bias_in, (size_t)cin * sizeof(float), hipMemcpyDeviceToDevice, st));
     ConvParams p = d.p;
     p.in = gout + cg_off;
     p.in_bytes = (unsigned)((long long)B * Ho * Wo * cs_g * 4 - (long long)cg_off * 4);
@@ -239,5 +247,132 @@ extern "C" int vstab_lrelu_backward(const float *y, int cs_y, int cy_off, float 
     if (rows < 1 || C < 1 || cy_off < 0 || cg_off < 0 || cy_off + C > cs_y || cg_off + C > cs_g)
         return fail(nullptr, VSTAB_E_SHAPE, "lrelu_backward: bad shape");
     HIP_TRY(nullptr, launch_lrelu_backward(y, cs_y, cy_off, dy, cs_g, cg_off, C, rows, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+// ------------------------------------------------------------------------- forward conv with device-resident raw weights
+namespace {
+bool fwd_plan(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int pad, int cout, int cs_y, int cy_off, int act, int Ho, int Wo,
+              DgradPlan &out)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int, int>, DgradPlan> cache;
+    const auto key = std::make_tuple(B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) { out = it->second; return true; }
+    DgradPlan d{};
+    if (!fill_plain_conv(d.p, d.tile, d.vec4, B, Hi, Wi, cin, cs_x, k, stride, pad, cout, cs_y, cy_off, act)) return false;
+    if (Ho > 0 && Wo > 0 && (Ho != d.p.Ho || Wo != d.p.Wo)) {
+        // one more output row / column than the symmetric-pad formula gives (TF SAME on an odd size): its window sticks out
+        // of the image and the range checks zero those taps
+        if (Ho < d.p.Ho || Wo < d.p.Wo || Ho > d.p.Ho + 1 || Wo > d.p.Wo + 1) return false;
+        if ((long long)B * Ho * Wo * cs_y * 4 >= 0x80000000LL) return false;
+        d.p.Ho = Ho; d.p.Wo = Wo;
+        d.p.ph[0].Hg = Ho; d.p.ph[0].Wg = Wo; d.p.ph[0].M = B * Ho * Wo; d.p.Mmax = d.p.ph[0].M;
+        const ConvTile base = cout >= 128 ? TILE_128x128 : (cout > 32 ? TILE_128x64 : TILE_128x32);
+        d.tile = choose_tile_split(d.p, base, d.vec4);
+    }
+    const KLayout L{d.p.KH, d.p.NSEG, d.p.SEG, d.p.SEGP, d.p.SEG_STRIDE};
+    d.packed_floats = (size_t)L.ktiles() * d.p.Npad * 32;
+    std::vector<int32_t> tbl(d.packed_floats);
+    pack_index_conv(k, k, cin, cs_x, cout, d.p.Npad, L, tbl.data());
+    if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;
+    if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d.tbl); return false; }
+    cache[key] = d;
+    out = d;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t vstab_conv_forward_workspace_bytes(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int pad, int cout, int cs_y,
+                                                     int cy_off, int act, int Ho, int Wo)
+{
+    DgradPlan d;
+    if (!fwd_plan(B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo, d)) return 0;
+    size_t a, b;
+    return dgrad_ws(d, &a, &b);
+}
+
+extern "C" int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *W, const float *bias_in,
+                                  int k, int stride, int pad, float *y, int Ho, int Wo, int cs_y, int cy_off, int cout, int act,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!x || !W || !y || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv_forward: NULL buffer");
+    if (B < 1 || Hi < 1 || Wi < 1 || k < 1 || k > 7 || stride < 1 || pad < 0 || cin < 1 || cout < 1 || cx_off < 0 || cy_off < 0 ||
+        cx_off + cin > cs_x || cy_off + cout > cs_y || act < 0 || act > 3)
+        return fail(nullptr, VSTAB_E_SHAPE, "conv_forward: bad shape");
+    if ((cx_off & 3) || (cy_off & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 255))
+        return fail(nullptr, VSTAB_E_ALIGN, "conv_forward: channel offsets multiples of 4, x 16-byte, workspace 256-byte aligned");
+    DgradPlan d;
+    if (!fwd_plan(B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo, d))
+        return fail(nullptr, VSTAB_E_SHAPE, "conv_forward: unsupported geometry");
+    size_t bias_off, part_off;
+    const size_t need = dgrad_ws(d, &bias_off, &part_off);
+    if (workspace_bytes < need) return fail(nullptr, VSTAB_E_NOMEM, "conv_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(nullptr, conv_set_attributes());
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *wpk = reinterpret_cast<float *>(ws);
+    float *bias = reinterpret_cast<float *>(ws + bias_off);
+    HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
+    HIP_TRY(nullptr, hipMemsetAsync(bias, 0, (size_t)d.p.Npad * sizeof(float), st));
+    if (bias_in) HIP_TRY(nullptr, hipMemcpyAsync(bias, bias_in, (size_t)cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ConvParams p = d.p;
+    p.in = x + cx_off;
+    p.in_bytes = (unsigned)((long long)B * Hi * Wi * cs_x * 4 - (long long)cx_off * 4);
+    p.wpk = wpk; p.bias = bias; p.out = y;
+    p.partial = reinterpret_cast<float *>(ws + part_off);
+    HIP_TRY(nullptr, launch_conv(p, d.tile, d.vec4, st));
+    return VSTAB_OK;
+}
+
+// ------------------------------------------------------------------------- resampler adjoints, full-res upsampler, Adam
+extern "C" int vstab_resize_bilinear_backward(const float *dout, int B, int oh, int ow, int C, float *din, int h, int w, float gain,
+                                              int accumulate, void *stream)
+{
+    if (!dout || !din) return fail(nullptr, VSTAB_E_STATE, "resize_bilinear_backward: NULL buffer");
+    if (B < 1 || oh < 1 || ow < 1 || h < 1 || w < 1 || C < 1) return fail(nullptr, VSTAB_E_SHAPE, "resize_bilinear_backward: bad shape");
+    HIP_TRY(nullptr, launch_resize_bilinear_backward(dout, B, oh, ow, C, din, h, w, gain, accumulate ? 1 : 0, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_pad_nearest_upsample(const float *src, int B, int h2, int w2, int C, float *out, int H, int W, void *stream)
+{
+    if (!src || !out) return fail(nullptr, VSTAB_E_STATE, "pad_nearest_upsample: NULL buffer");
+    if (B < 1 || h2 < 1 || w2 < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return fail(nullptr, VSTAB_E_SHAPE, "pad_nearest_upsample: bad shape");
+    if ((long long)B * H * W * C * 4 >= (1LL << 40)) return fail(nullptr, VSTAB_E_SHAPE, "pad_nearest_upsample: too large");
+    HIP_TRY(nullptr, launch_pad_nearest_up(src, B, h2, w2, C, out, H, W, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_pad_nearest_upsample_backward(const float *dout, int B, int H, int W, int C, float *dsrc, int h2, int w2, int accumulate,
+                                                   void *stream)
+{
+    if (!dout || !dsrc) return fail(nullptr, VSTAB_E_STATE, "pad_nearest_upsample_backward: NULL buffer");
+    if (B < 1 || h2 < 1 || w2 < 1 || H < 1 || W < 1 || C < 4 || (C & 3))
+        return fail(nullptr, VSTAB_E_SHAPE, "pad_nearest_upsample_backward: bad shape");
+    HIP_TRY(nullptr, launch_pad_nearest_up_backward(dout, B, H, W, C, dsrc, h2, w2, accumulate ? 1 : 0, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_adam_step(float *w, const float *g, float *m, float *v, long long n, float lr_t, float beta1, float beta2, float eps,
+                               void *stream)
+{
+    if (!w || !g || !m || !v) return fail(nullptr, VSTAB_E_STATE, "adam_step: NULL buffer");
+    if (n < 1) return fail(nullptr, VSTAB_E_SHAPE, "adam_step: bad size");
+    HIP_TRY(nullptr, launch_adam(w, g, m, v, n, lr_t, beta1, beta2, eps, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" size_t vstab_column_sum_scratch_bytes(long long rows, int C) { return rows < 1 || C < 1 ? 0 : (size_t)column_sum_chunks(rows) * C * sizeof(float) + 256; }
+
+extern "C" int vstab_column_sum(const float *g, long long rows, int cs, int c_off, int C, float *out, int accumulate, void *scratch,
+                                size_t scratch_bytes, void *stream)
+{
+    if (!g || !out || !scratch) return fail(nullptr, VSTAB_E_STATE, "column_sum: NULL buffer");
+    if (rows < 1 || C < 1 || c_off < 0 || c_off + C > cs) return fail(nullptr, VSTAB_E_SHAPE, "column_sum: bad shape");
+    if (scratch_bytes < vstab_column_sum_scratch_bytes(rows, C)) return fail(nullptr, VSTAB_E_NOMEM, "column_sum: scratch too small");
+    HIP_TRY(nullptr, launch_column_sum(g, rows, cs, c_off, C, out, accumulate ? 1 : 0, reinterpret_cast<float *>(scratch), (hipStream_t)stream));
     return VSTAB_OK;
 }

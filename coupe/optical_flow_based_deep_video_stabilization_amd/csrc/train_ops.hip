@@ -315,6 +315,150 @@ hipError_t launch_lrelu_backward(const float *y, int cs_y, int cy_off, float *dy
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------
+// Adjoints of the two resamplers in the decoder, and the full-resolution head's upsampler itself.
+// Both backward kernels GATHER (one thread per input element loops over the few output positions that read it and
+// re-derives the forward's index / weight with the forward's own float arithmetic), so sums have a fixed order.
+// ---------------------------------------------------------------------------------
+namespace {
+struct LerpT { int lo, hi; float t; };
+__device__ __forceinline__ LerpT legacy_coord_t(int o, float scale, int n_in)        // = flow_ops.hip legacy_coord
+{
+    const float f = (float)o * scale;
+    const float fl = floorf(f);
+    LerpT L;
+    L.lo = min((int)fl, n_in - 1);
+    L.hi = min(L.lo + 1, n_in - 1);
+    L.t = f - fl;
+    return L;
+}
+__device__ __forceinline__ int nearest_ac_t(int i, float scale, int n_in) { return min((int)roundf((float)i * scale), n_in - 1); }
+
+// backward of tf.image.resize_images / UpSampling2dLayer (legacy bilinear): out = top + (bot - top) * ty with
+// top = tl + (tr - tl) * tx  =>  d out / d tl = (1-tx)(1-ty), tr: tx(1-ty), bl: (1-tx)ty, br: tx*ty
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const float *__restrict__ dout, int oh, int ow, int C,
+                                                                  float *__restrict__ din, int h, int w, float ry, float rx,
+                                                                  float gain, int accumulate)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)gridDim.y * 0 + (long long)h * w * C;
+    const int n = blockIdx.y;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int pix = (int)(idx / C);
+    const int iy = pix / w, ix = pix - iy * w;
+    const int oy0 = max(0, (int)floorf((float)(iy - 1) / ry) - 1), oy1 = min(oh - 1, (int)ceilf((float)(iy + 1) / ry) + 1);
+    const int ox0 = max(0, (int)floorf((float)(ix - 1) / rx) - 1), ox1 = min(ow - 1, (int)ceilf((float)(ix + 1) / rx) + 1);
+    const float *g = dout + (long long)n * oh * ow * C + c;
+    float s = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        const LerpT Y = legacy_coord_t(oy, ry, h);
+        const float wy = (Y.lo == iy ? 1.f - Y.t : 0.f) + (Y.hi == iy ? Y.t : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const LerpT X = legacy_coord_t(ox, rx, w);
+            const float wx = (X.lo == ix ? 1.f - X.t : 0.f) + (X.hi == ix ? X.t : 0.f);
+            if (wx != 0.f) s += wy * wx * g[((long long)oy * ow + ox) * C];
+        }
+    }
+    float *o = din + ((long long)n * h * w) * C + idx;
+    *o = accumulate ? *o + gain * s : gain * s;
+}
+
+// F7 of the network: PadLayer(1) then nearest-neighbour resize with align_corners=True to H x W (model.py:795-802, 882-884)
+__global__ __launch_bounds__(256) void pad_nearest_up_kernel(const float *__restrict__ src, int h2, int w2, int C4, float *__restrict__ out,
+                                                             int H, int W, float sy, float sx)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)H * W * C4) return;
+    const int n = blockIdx.y;
+    const int c = (int)(idx % C4);
+    const int pix = (int)(idx / C4);
+    const int y = pix / W, x = pix - y * W;
+    const int syi = nearest_ac_t(y, sy, h2 + 2) - 1, sxi = nearest_ac_t(x, sx, w2 + 2) - 1;
+    f32x4v v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)syi < (unsigned)h2 && (unsigned)sxi < (unsigned)w2)
+        v = reinterpret_cast<const f32x4v *>(src)[(((long long)n * h2 + syi) * w2 + sxi) * C4 + c];
+    reinterpret_cast<f32x4v *>(out)[(long long)n * H * W * C4 + idx] = v;
+}
+
+__global__ __launch_bounds__(256) void pad_nearest_up_bwd_kernel(const float *__restrict__ dout, int H, int W, int C4, float *__restrict__ dsrc,
+                                                                 int h2, int w2, float sy, float sx, int accumulate)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)h2 * w2 * C4) return;
+    const int n = blockIdx.y;
+    const int c = (int)(idx % C4);
+    const int pix = (int)(idx / C4);
+    const int syi = pix / w2, sxi = pix - syi * w2;
+    // output rows y with nearest(y) == syi + 1: a contiguous range around (syi + 1) / sy
+    const int yc = sy > 0.f ? (int)((float)(syi + 1) / sy) : 0, xc = sx > 0.f ? (int)((float)(sxi + 1) / sx) : 0;
+    const int span_y = sy > 0.f ? (int)(1.f / sy) + 2 : H, span_x = sx > 0.f ? (int)(1.f / sx) + 2 : W;
+    f32x4v s = {0.f, 0.f, 0.f, 0.f};
+    for (int y = max(0, yc - span_y); y <= min(H - 1, yc + span_y); ++y) {
+        if (nearest_ac_t(y, sy, h2 + 2) != syi + 1) continue;
+        for (int x = max(0, xc - span_x); x <= min(W - 1, xc + span_x); ++x) {
+            if (nearest_ac_t(x, sx, w2 + 2) != sxi + 1) continue;
+            s += reinterpret_cast<const f32x4v *>(dout)[(((long long)n * H + y) * W + x) * C4 + c];
+        }
+    }
+    f32x4v *o = reinterpret_cast<f32x4v *>(dsrc) + (long long)n * h2 * w2 * C4 + idx;
+    if (accumulate) s += *o;
+    *o = s;
+}
+
+// tf.train.AdamOptimizer (main:333-335): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t m / (sqrt(v) + eps),
+// lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) computed by the caller
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, long long n, float lr_t, float b1, float b2, float eps)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+}  // namespace
+
+hipError_t launch_resize_bilinear_backward(const float *dout, int B, int oh, int ow, int C, float *din, int h, int w, float gain,
+                                           int accumulate, hipStream_t stream)
+{
+    const long long per = (long long)h * w * C;
+    resize_bilinear_bwd_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(
+        dout, oh, ow, C, din, h, w, (float)h / (float)oh, (float)w / (float)ow, gain, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_pad_nearest_up(const float *src, int B, int h2, int w2, int C, float *out, int H, int W, hipStream_t stream)
+{
+    if (C & 3) return hipErrorInvalidValue;
+    const float sy = H > 1 ? (float)(h2 + 2 - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w2 + 2 - 1) / (float)(W - 1) : 0.f;
+    const long long per = (long long)H * W * (C / 4);
+    pad_nearest_up_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(src, h2, w2, C / 4, out, H, W, sy, sx);
+    return hipGetLastError();
+}
+
+hipError_t launch_pad_nearest_up_backward(const float *dout, int B, int H, int W, int C, float *dsrc, int h2, int w2, int accumulate,
+                                          hipStream_t stream)
+{
+    if (C & 3) return hipErrorInvalidValue;
+    const float sy = H > 1 ? (float)(h2 + 2 - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w2 + 2 - 1) / (float)(W - 1) : 0.f;
+    const long long per = (long long)h2 * w2 * (C / 4);
+    pad_nearest_up_bwd_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(dout, H, W, C / 4, dsrc, h2, w2, sy,
+                                                                                                      sx, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_adam(float *w, const float *g, float *m, float *v, long long n, float lr_t, float b1, float b2, float eps,
+                       hipStream_t stream)
+{
+    adam_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(w, g, m, v, n, lr_t, b1, b2, eps);
+    return hipGetLastError();
+}
+
 // device-side weight packing: replay the host packer's gather from its index table
 __global__ __launch_bounds__(256) void pack_apply_kernel(const float *__restrict__ W, const int32_t *__restrict__ tbl, long long n,
                                                          float *__restrict__ wpk)

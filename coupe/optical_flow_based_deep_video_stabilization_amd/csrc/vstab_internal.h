@@ -234,6 +234,16 @@ hipError_t launch_bn_lrelu_train_backward(const float *y, int cs_y, int cy_off, 
 hipError_t launch_lrelu_backward(const float *y, int cs_y, int cy_off, float *dy, int cs_g, int cg_off, int C, long long rows,
                                  hipStream_t stream);
 
+// adjoint of the legacy bilinear resize (din (+)= gain * J^T dout), the full-resolution head's pad + nearest upsampler and its
+// adjoint, Adam (train_ops.hip)
+hipError_t launch_resize_bilinear_backward(const float *dout, int B, int oh, int ow, int C, float *din, int h, int w, float gain,
+                                           int accumulate, hipStream_t stream);
+hipError_t launch_pad_nearest_up(const float *src, int B, int h2, int w2, int C, float *out, int H, int W, hipStream_t stream);
+hipError_t launch_pad_nearest_up_backward(const float *dout, int B, int H, int W, int C, float *dsrc, int h2, int w2, int accumulate,
+                                          hipStream_t stream);
+hipError_t launch_adam(float *w, const float *g, float *m, float *v, long long n, float lr_t, float b1, float b2, float eps,
+                       hipStream_t stream);
+
 // Index tables for device-side packing (training): tbl[i] = 1 + raw-weight index of packed element i, 0 = zero.
 void pack_index_conv(int kh, int kw, int cin, int cs_in, int cout, int npad, const KLayout &L, int32_t *tbl);
 void pack_index_dgrad_s1(int k, int cin, int cout, int cs_g, const KLayout &L, int npad, int32_t *tbl);

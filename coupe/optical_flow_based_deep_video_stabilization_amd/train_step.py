@@ -1,0 +1,314 @@
+"""One training step of the reference (`train()`, main:176-335 with "main" = main_flownetS_pyramid_noprevloss_dataloader.py):
+forward of `flownetS_pyramid(..., is_train=True)` (BatchNorm on batch statistics, moving averages updated), `loss_main`
+(five lossterms + total variation), the backward pass through the whole network and `tf.train.AdamOptimizer(lr, beta1)`.
+SURVEY.md 8f rank 4.
+
+Everything numerical runs in the HIP library through the C ABI (`vstab_conv_forward`, `vstab_conv_dgrad`, `vstab_conv_wgrad`,
+`vstab_bn_lrelu_train_*`, `vstab_loss_level`, the resampler adjoints, `vstab_adam_step`, ...); this module only owns the
+buffers and the order of the calls.  torch is used for allocation, zero fills and strided copies (channel padding), never for
+arithmetic.
+
+Layout: NHWC fp32 with every channel count a multiple of four.  The 27-channel input is copied into a 28-channel buffer, the
+2-channel flows live in 4-channel pixels, and the concat buffers carry two zero pad channels after the flow (as in the inference
+path).  Weights are stored padded the same way (zero rows / columns); a pad row only ever multiplies a zero activation and a pad
+column only ever receives a zero gradient, so the padding stays zero under Adam without masking.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, netspec, runtime
+from .training import LOSS_LEVELS, TV_WEIGHTS
+
+ENC = (("1", 7, 2, 3, 64), ("2", 5, 2, 2, 128), ("3", 5, 2, 2, 256), ("3_1", 3, 1, 1, 256), ("4", 3, 2, 1, 512),
+       ("4_1", 3, 1, 1, 512), ("5", 3, 2, 1, 512), ("5_1", 3, 1, 1, 512), ("6", 3, 2, 1, 1024), ("6_1", 3, 1, 1, 1024))   # model.py:807-844
+# output slice (buffer, channel offset) and input slice (buffer, offset, channels) of every encoder stage
+ENC_OUT = {"1": ("conv1", 0), "2": ("concat2", 0), "3": ("conv3", 0), "3_1": ("concat3", 0), "4": ("conv4", 0), "4_1": ("concat4", 0),
+           "5": ("conv5", 0), "5_1": ("concat5", 0), "6": ("conv6", 0), "6_1": ("conv6_1", 0)}
+ENC_IN = {"1": ("x0", 0, 28), "2": ("conv1", 0, 64), "3": ("concat2", 0, 128), "3_1": ("conv3", 0, 256), "4": ("concat3", 0, 256),
+          "4_1": ("conv4", 0, 512), "5": ("concat4", 0, 512), "5_1": ("conv5", 0, 512), "6": ("concat5", 0, 512), "6_1": ("conv6", 0, 1024)}
+BUF_C = {"x0": 28, "conv1": 64, "concat2": 196, "conv3": 256, "concat3": 388, "conv4": 512, "concat4": 772, "conv5": 512,
+         "concat5": 1028, "conv6": 1024, "conv6_1": 1024}
+# decoder levels, coarse to fine: (deconv, its input buffer, real cin, output buffer, offset, cout, predict, upsample, flow offset)
+DEC = (("deconv5", "conv6_1", 1024, "concat5", 512, 512, "predict6", "upsample6_5", 1024),
+       ("deconv4", "concat5", 1026, "concat4", 512, 256, "predict5", "upsample5_4", 768),
+       ("deconv3", "concat4", 770, "concat3", 256, 128, "predict4", "upsample4_3", 384),
+       ("deconv2", "concat3", 386, "concat2", 128, 64, "predict3", "upsample3_2", 192))
+PRED_IN = {"predict6": ("conv6_1", 1024), "predict5": ("concat5", 1026), "predict4": ("concat4", 770), "predict3": ("concat3", 386),
+           "predict2": ("concat2", 194)}
+BN_DECAY, BN_EPS = 0.9, 1e-5        # TensorLayer BatchNormLayer defaults
+
+
+def _pad_to(t: torch.Tensor, shape) -> torch.Tensor:
+    out = torch.zeros(shape, dtype=torch.float32, device=t.device)
+    out[tuple(slice(0, s) for s in t.shape)].copy_(t)
+    return out
+
+
+class Trainer:
+    """Holds the (padded, device-resident) parameters, BatchNorm moving statistics and Adam state; `step()` = one
+    `sess.run(optim_main)` of the reference."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], batch: int, height: int, width: int, device=None):
+        runtime._require_gpu()
+        self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.B, self.H, self.W = int(batch), int(height), int(width)
+        self.sizes = list(netspec.sizes_for(self.H, self.W).enc)              # spatial size after every encoder stage
+        self.L = _lib.lib()
+        self.p: Dict[str, torch.Tensor] = {}
+        self.shape_real: Dict[str, Tuple[int, ...]] = {}
+        for name, v in weights.items():
+            t = torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.dev)
+            self.shape_real[name] = tuple(t.shape)
+            self.p[name] = _pad_to(t, self._padded_shape(name, tuple(t.shape))).contiguous()
+        self.trainable = [k for k in self.p if "moving_" not in k]
+        self.m = {k: torch.zeros_like(self.p[k]) for k in self.trainable}
+        self.v = {k: torch.zeros_like(self.p[k]) for k in self.trainable}
+        self.g = {k: torch.zeros_like(self.p[k]) for k in self.trainable}
+        self.t = 0
+        self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.dev)
+        self._alloc_buffers()
+
+    # ------------------------------------------------------------------ parameters
+    @staticmethod
+    def _r4(n):
+        return (n + 3) // 4 * 4
+
+    def _padded_shape(self, name, s):
+        if name.endswith("W_conv2d"):                       # [k,k,cin,cout]
+            return (s[0], s[1], self._r4(s[2]), self._r4(s[3]))
+        if name.endswith("W_deconv2d"):                     # [4,4,cout,cin]
+            return (s[0], s[1], self._r4(s[2]), self._r4(s[3]))
+        return (self._r4(s[0]),)
+
+    def export(self, tensors: Dict[str, torch.Tensor] = None) -> Dict[str, np.ndarray]:
+        """Unpadded copies (host) of the parameters, or of a dict shaped like them (gradients, Adam moments)."""
+        src = self.p if tensors is None else tensors
+        return {k: t[tuple(slice(0, s) for s in self.shape_real[k])].contiguous().cpu().numpy() for k, t in src.items()}
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc_buffers(self):
+        B, H, W = self.B, self.H, self.W
+        hw = {"x0": (H, W), "conv1": self.sizes[0], "concat2": self.sizes[1], "conv3": self.sizes[2], "concat3": self.sizes[3],
+              "conv4": self.sizes[4], "concat4": self.sizes[5], "conv5": self.sizes[6], "concat5": self.sizes[7],
+              "conv6": self.sizes[8], "conv6_1": self.sizes[9]}
+        self.hw = hw
+        z = lambda h, w, c: torch.zeros((B, h, w, c), dtype=torch.float32, device=self.dev)
+        self.a = {k: z(hw[k][0], hw[k][1], BUF_C[k]) for k in BUF_C}                      # activations
+        self.G = {k: z(hw[k][0], hw[k][1], BUF_C[k]) for k in BUF_C if k != "x0"}          # their gradients
+        self.flow_hw = {"predict_flow6": hw["conv6_1"], "predict_flow5": hw["concat5"], "predict_flow4": hw["concat4"],
+                        "predict_flow3": hw["concat3"], "predict_flow2": (H - 2, W - 2)}
+        self.pf = {k: z(s[0], s[1], 4) for k, s in self.flow_hw.items()}                   # flows in 4-channel pixels
+        self.dpf = {k: z(s[0], s[1], 4) for k, s in self.flow_hw.items()}
+        self.pconv = {k: z(s[0], s[1], 4) for k, s in self.flow_hw.items()}                # predict conv outputs before the residual
+        self.U = z(H, W, 196)                                                               # F7's upsampled concat2
+        self.dU = z(H, W, 196)
+        self.save = {}                                                                       # BatchNorm (mean, rstd) per layer
+
+    def _workspace(self, nbytes):
+        if nbytes > self._ws.numel():
+            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.dev)
+        return self._ws
+
+    # ------------------------------------------------------------------ thin wrappers over the C ABI
+    def _check(self, rc):
+        _lib.check(rc)
+
+    def _conv_fwd(self, x, cx_off, cin, W, b, k, s, p, y, cy_off, cout, act=0):
+        B, Hi, Wi, cs_x = x.shape
+        cs_y = y.shape[3]
+        Ho, Wo = y.shape[1], y.shape[2]
+        n = self.L.vstab_conv_forward_workspace_bytes(B, Hi, Wi, cs_x, cin, k, s, p, cout, cs_y, cy_off, act, Ho, Wo)
+        if n == 0:
+            raise ValueError("conv_forward: unsupported geometry")
+        ws = self._workspace(n)
+        self._check(self.L.vstab_conv_forward(x.data_ptr(), B, Hi, Wi, cs_x, cx_off, cin, W.data_ptr(), b.data_ptr() if b is not None else None,
+                                              k, s, p, y.data_ptr(), Ho, Wo, cs_y, cy_off, cout, act, ws.data_ptr(), ws.numel(), self.st))
+
+    def _convT(self, g, cg_off, cout, W, b, k, s, p, dx, cx_off, cin, accumulate):
+        """dx (+)= transposed conv of g with W [k,k,cin,cout] (conv input gradient; also DeConv2dLayer's forward)."""
+        B, Ho, Wo, cs_g = g.shape
+        _, Hi, Wi, cs_x = dx.shape
+        n = self.L.vstab_conv_dgrad_workspace_bytes(B, Ho, Wo, cs_g, cout, k, s, p, Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0)
+        if n == 0:
+            raise ValueError("conv_dgrad: unsupported geometry")
+        ws = self._workspace(n)
+        self._check(self.L.vstab_conv_dgrad(g.data_ptr(), B, Ho, Wo, cs_g, cg_off, cout, W.data_ptr(), b.data_ptr() if b is not None else None,
+                                            k, s, p, dx.data_ptr(), Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0, ws.data_ptr(),
+                                            ws.numel(), self.st))
+
+    def _wgrad(self, x, cx_off, cin, g, cg_off, cout, k, s, p, dW, db):
+        B, Hi, Wi, cs_x = x.shape
+        _, Ho, Wo, cs_g = g.shape
+        n = self.L.vstab_conv_wgrad_workspace_bytes(B, Ho, Wo, k, cin, cout)
+        ws = self._workspace(n)
+        self._check(self.L.vstab_conv_wgrad(x.data_ptr(), B, Hi, Wi, cs_x, cx_off, cin, g.data_ptr(), Ho, Wo, cs_g, cg_off, cout, k, s, p,
+                                            dW.data_ptr(), db.data_ptr() if db is not None else None, 0, ws.data_ptr(), ws.numel(), self.st))
+
+    def _colsum(self, g, c_off, C, out):
+        rows = g.shape[0] * g.shape[1] * g.shape[2]
+        ws = self._workspace(self.L.vstab_column_sum_scratch_bytes(rows, C))
+        self._check(self.L.vstab_column_sum(g.data_ptr(), rows, g.shape[3], c_off, C, out.data_ptr(), 0, ws.data_ptr(), ws.numel(), self.st))
+
+    def _bn_fwd(self, name, buf, c_off, C):
+        rows = buf.shape[0] * buf.shape[1] * buf.shape[2]
+        mean = torch.empty(C, dtype=torch.float32, device=self.dev)
+        rstd = torch.empty(C, dtype=torch.float32, device=self.dev)
+        ws = self._workspace(self.L.vstab_bn_scratch_bytes(rows, C))
+        self._check(self.L.vstab_bn_lrelu_train_forward(buf.data_ptr(), rows, buf.shape[3], c_off, C, self.p[f"{name}/beta"].data_ptr(),
+                                                        self.p[f"{name}/moving_mean"].data_ptr(), self.p[f"{name}/moving_variance"].data_ptr(),
+                                                        BN_DECAY, BN_EPS, mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel(), self.st))
+        self.save[name] = (mean, rstd)
+
+    def _bn_bwd(self, name, y, G, c_off, C):
+        rows = y.shape[0] * y.shape[1] * y.shape[2]
+        ws = self._workspace(self.L.vstab_bn_scratch_bytes(rows, C))
+        self._check(self.L.vstab_bn_lrelu_train_backward(y.data_ptr(), y.shape[3], c_off, G.data_ptr(), G.shape[3], c_off, C, rows,
+                                                         self.p[f"{name}/beta"].data_ptr(), self.save[name][1].data_ptr(),
+                                                         self.g[f"{name}/beta"].data_ptr(), 0, ws.data_ptr(), ws.numel(), self.st))
+
+    def _resize(self, x, out):
+        B, h, w, C = x.shape
+        self._check(self.L.vstab_resize_bilinear(x.data_ptr(), B, h, w, C, out.data_ptr(), out.shape[1], out.shape[2], self.st))
+
+    def _resize_bwd(self, dout, din, gain):
+        B, oh, ow, C = dout.shape
+        self._check(self.L.vstab_resize_bilinear_backward(dout.data_ptr(), B, oh, ow, C, din.data_ptr(), din.shape[1], din.shape[2],
+                                                          float(gain), 1, self.st))
+
+    def _axpby(self, a, x, b, y, out):
+        self._check(self.L.vstab_axpby(x.data_ptr(), float(a), y.data_ptr(), float(b), out.data_ptr(), x.numel(), self.st))
+
+    # ------------------------------------------------------------------ forward (is_train=True)
+    def forward(self, feats: torch.Tensor) -> Dict[str, torch.Tensor]:
+        if tuple(feats.shape) != (self.B, self.H, self.W, 27) or feats.dtype != torch.float32 or not feats.is_cuda:
+            raise ValueError(f"feats must be a float32 CUDA tensor {(self.B, self.H, self.W, 27)}")
+        self.st = runtime.stream_ptr()
+        a, p = self.a, self.p
+        a["x0"][..., :27].copy_(feats)
+        for name, k, s, pad, cout in ENC:                                                # model.py:807-844
+            ib, ioff, cin = ENC_IN[name]
+            ob, ooff = ENC_OUT[name]
+            self._conv_fwd(a[ib], ioff, cin, p[f"{name}/W_conv2d"], p[f"{name}/b_conv2d"], k, s, pad, a[ob], ooff, cout)
+            self._bn_fwd(name, a[ob], ooff, cout)
+        prev = None
+        for dname, ib, _cin, ob, ooff, cout, pname, uname, foff in DEC:                   # model.py:847-880
+            level = "predict_flow" + pname[-1]
+            pin, _ = PRED_IN[pname]
+            cs_in = a[pin].shape[3]
+            self._conv_fwd(a[pin], 0, cs_in, p[f"{pname}/W_conv2d"], p[f"{pname}/b_conv2d"], 3, 1, 1, self.pconv[level], 0, 4)
+            if prev is None:
+                self.pf[level].copy_(self.pconv[level])
+            else:                                                                         # (conv + up) + up, model.py:857
+                up = torch.empty_like(self.pf[level])
+                self._resize(self.pf[prev], up)
+                self._axpby(1.0, self.pconv[level], 2.0, up, self.pf[level])
+            # upsample_flowN into the next concat's flow channels, deconvN + BatchNorm into its middle slice
+            self._convT(self.pf[level], 0, 4, p[f"{uname}/W_deconv2d"], p[f"{uname}/b_deconv2d"], 4, 2, 1, a[ob], foff, 4, False)
+            self._convT(a[ib], 0, a[ib].shape[3], p[f"{dname}/W_deconv2d"], p[f"{dname}/b_deconv2d"], 4, 2, 1, a[ob], ooff, cout, False)
+            self._bn_fwd(f"{dname}_bn", a[ob], ooff, cout)
+            prev = level
+        # full-resolution head (model.py:882-887)
+        self._check(self.L.vstab_pad_nearest_upsample(a["concat2"].data_ptr(), self.B, a["concat2"].shape[1], a["concat2"].shape[2], 196,
+                                                      self.U.data_ptr(), self.H, self.W, self.st))
+        self._conv_fwd(self.U, 0, 196, p["predict2/W_conv2d"], p["predict2/b_conv2d"], 3, 1, 0, self.pconv["predict_flow2"], 0, 4)
+        up = torch.empty_like(self.pf["predict_flow2"])
+        self._resize(self.pf["predict_flow3"], up)
+        self._axpby(1.0, self.pconv["predict_flow2"], 8.0, up, self.pf["predict_flow2"])
+        return {k: v[..., :2] for k, v in self.pf.items()}
+
+    def lrelu_masks(self) -> Dict[str, torch.Tensor]:
+        """{BatchNorm layer: y > 0} of the last forward (host bool tensors): which side of the leaky relu every element is on."""
+        out = {}
+        for name, _k, _s, _p, cout in ENC:
+            ob, ooff = ENC_OUT[name]
+            out[name] = (self.a[ob][..., ooff:ooff + cout] > 0).cpu()
+        for dname, _ib, _cin, ob, ooff, cout, _p, _u, _f in DEC:
+            out[f"{dname}_bn"] = (self.a[ob][..., ooff:ooff + cout] > 0).cpu()
+        return out
+
+    # ------------------------------------------------------------------ loss + backward
+    def loss_and_backward(self, gtstab: torch.Tensor, unstab: torch.Tensor) -> torch.Tensor:
+        """loss_main (main:213-217, 269-275) and d loss_main / d every trainable tensor (into self.g)."""
+        from .training import lossterm
+        self._zero_grads()
+        total = None
+        for level, tvw in zip(LOSS_LEVELS, TV_WEIGHTS):
+            l, grad = lossterm(self.pf[level][..., :2].contiguous(), gtstab, unstab, tvw, True)
+            total = l if total is None else total + l
+            self.dpf[level][..., :2].copy_(grad)
+        self._backward()
+        return total
+
+    def backward_from_flow_grads(self, dflows: Dict[str, torch.Tensor]):
+        """Vector-Jacobian product of the network alone: given d L / d predict_flowN [B,h,w,2] for the five flows, fills
+        self.g with d L / d every trainable tensor (what tf.gradients(flows, vars, grad_ys=dflows) returns)."""
+        self._zero_grads()
+        for level in LOSS_LEVELS:
+            self.dpf[level][..., :2].copy_(dflows[level])
+        self._backward()
+
+    def _zero_grads(self):
+        for G in self.G.values():
+            G.zero_()
+        for d in self.dpf.values():
+            d.zero_()
+
+    def _backward(self):
+        a, p, g, G = self.a, self.p, self.g, self.G
+        # full-resolution head
+        d2 = self.dpf["predict_flow2"]
+        self._resize_bwd(d2, self.dpf["predict_flow3"], 8.0)
+        self._wgrad(self.U, 0, 196, d2, 0, 4, 3, 1, 0, g["predict2/W_conv2d"], g["predict2/b_conv2d"])
+        self._convT(d2, 0, 4, p["predict2/W_conv2d"], None, 3, 1, 0, self.dU, 0, 196, False)
+        self._check(self.L.vstab_pad_nearest_upsample_backward(self.dU.data_ptr(), self.B, self.H, self.W, 196, G["concat2"].data_ptr(),
+                                                               a["concat2"].shape[1], a["concat2"].shape[2], 1, self.st))
+        # decoder levels, fine to coarse
+        levels = ["predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3"]
+        for i in range(3, -1, -1):
+            dname, ib, _cin, ob, ooff, cout, pname, uname, foff = DEC[i]
+            level = levels[i]
+            cs_in = a[ib].shape[3]
+            # deconvN: BatchNorm backward in place on its slice of the concat gradient, then filter / bias / input gradients
+            self._bn_bwd(f"{dname}_bn", a[ob], G[ob], ooff, cout)
+            self._wgrad(G[ob], ooff, cout, a[ib], 0, cs_in, 4, 2, 1, g[f"{dname}/W_deconv2d"], None)
+            self._colsum(G[ob], ooff, cout, g[f"{dname}/b_deconv2d"])
+            self._conv_fwd(G[ob], ooff, cout, p[f"{dname}/W_deconv2d"], None, 4, 2, 1, G[ib], 0, cs_in, act=3)
+            # upsample_flowN: its input is this level's flow
+            self._wgrad(G[ob], foff, 4, self.pf[level], 0, 4, 4, 2, 1, g[f"{uname}/W_deconv2d"], None)
+            self._colsum(G[ob], foff, 4, g[f"{uname}/b_deconv2d"])
+            self._conv_fwd(G[ob], foff, 4, p[f"{uname}/W_deconv2d"], None, 4, 2, 1, self.dpf[level], 0, 4, act=3)
+            # the flow's gradient is complete: residual add, then predict_flowN
+            if i > 0:
+                self._resize_bwd(self.dpf[level], self.dpf[levels[i - 1]], 2.0)
+            pin, _ = PRED_IN[pname]
+            self._wgrad(a[pin], 0, a[pin].shape[3], self.dpf[level], 0, 4, 3, 1, 1, g[f"{pname}/W_conv2d"], g[f"{pname}/b_conv2d"])
+            self._convT(self.dpf[level], 0, 4, p[f"{pname}/W_conv2d"], None, 3, 1, 1, G[pin], 0, a[pin].shape[3], True)
+        # encoder, last stage first
+        for name, k, s, pad, cout in reversed(ENC):
+            ib, ioff, cin = ENC_IN[name]
+            ob, ooff = ENC_OUT[name]
+            self._bn_bwd(name, a[ob], G[ob], ooff, cout)
+            self._wgrad(a[ib], ioff, cin, G[ob], ooff, cout, k, s, pad, g[f"{name}/W_conv2d"], g[f"{name}/b_conv2d"])
+            if ib != "x0":
+                self._convT(G[ob], ooff, cout, p[f"{name}/W_conv2d"], None, k, s, pad, G[ib], ioff, cin, True)
+
+    # ------------------------------------------------------------------ Adam (main:333-335)
+    def adam(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
+        self.t += 1
+        lr_t = lr * math.sqrt(1.0 - beta2 ** self.t) / (1.0 - beta1 ** self.t)
+        for k in self.trainable:
+            self._check(self.L.vstab_adam_step(self.p[k].data_ptr(), self.g[k].data_ptr(), self.m[k].data_ptr(), self.v[k].data_ptr(),
+                                               self.p[k].numel(), lr_t, beta1, beta2, eps, self.st))
+
+    def step(self, feats, gtstab, unstab, lr: float, beta1: float = 0.9):
+        """One optimiser step; returns loss_main evaluated before the update (what `sess.run([loss_main, optim_main])` prints)."""
+        with torch.cuda.device(self.dev):
+            self.forward(feats)
+            loss = self.loss_and_backward(gtstab, unstab)
+            self.adam(lr, beta1)
+        return loss

@@ -87,7 +87,7 @@ def conv_wgrad(x, gout, k: int, stride: int, pad: int, cx_off: int = 0, cin: int
 
 
 def conv_dgrad(gout, W, stride: int, pad: int, in_hw, cg_off: int = 0, cout: int = None, dx=None, cx_off: int = 0,
-               accumulate: bool = False):
+               accumulate: bool = False, bias=None):
     """Input gradient of PadLayer(pad) -> Conv2d(k, stride, VALID) with filter W [k,k,cin,cout] (CUDA tensor, HWIO):
     what TF's autodiff returns for tf.nn.conv2d's input.  gout [B,Ho,Wo,Cs_g] (channels cg_off..+cout); the result has
     the input's size in_hw and lands in channels cx_off..+cin of dx (allocated [B,Hi,Wi,cin] when None)."""
@@ -112,7 +112,8 @@ def conv_dgrad(gout, W, stride: int, pad: int, in_hw, cg_off: int = 0, cout: int
         raise ValueError("conv_dgrad: unsupported geometry (stride 1 or 2, channel counts multiples of 4, matching sizes)")
     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=gout.device)
     with torch.cuda.device(gout.device):
-        _lib.check(L.vstab_conv_dgrad(gout.data_ptr(), B, Ho, Wo, cs_g, cg_off, cout, W.data_ptr(), k, stride, pad, dx.data_ptr(),
+        _lib.check(L.vstab_conv_dgrad(gout.data_ptr(), B, Ho, Wo, cs_g, cg_off, cout, W.data_ptr(),
+                                      bias.data_ptr() if bias is not None else None, k, stride, pad, dx.data_ptr(),
                                       Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0, ws.data_ptr(), ws.numel(),
                                       runtime.stream_ptr()))
     return dx
@@ -169,3 +170,38 @@ def lrelu_backward(y, dy, cy_off: int = 0, cg_off: int = 0, C: int = None):
     with torch.cuda.device(y.device):
         _lib.check(_lib.lib().vstab_lrelu_backward(y.data_ptr(), cs_y, cy_off, dy.data_ptr(), cs_g, cg_off, Cy, rows, runtime.stream_ptr()))
     return dy
+
+
+def resize_bilinear_backward(dout, in_hw, gain: float = 1.0, din=None):
+    """din (+)= gain * adjoint of tf.image.resize_images(., dout's size) applied to dout [B,oh,ow,C]."""
+    dout = dout.contiguous()
+    B, oh, ow, C = dout.shape
+    acc = din is not None
+    if din is None:
+        din = torch.empty((B, int(in_hw[0]), int(in_hw[1]), C), dtype=torch.float32, device=dout.device)
+    with torch.cuda.device(dout.device):
+        _lib.check(_lib.lib().vstab_resize_bilinear_backward(dout.data_ptr(), B, oh, ow, C, din.data_ptr(), din.shape[1], din.shape[2],
+                                                             float(gain), 1 if acc else 0, runtime.stream_ptr()))
+    return din
+
+
+def pad_nearest_upsample(src, H: int, W: int):
+    """PadLayer(1) -> nearest resize (align_corners=True) to HxW (model.py:795-802, 882-884); C % 4 == 0."""
+    src = src.contiguous()
+    B, h2, w2, C = src.shape
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.lib().vstab_pad_nearest_upsample(src.data_ptr(), B, h2, w2, C, out.data_ptr(), H, W, runtime.stream_ptr()))
+    return out
+
+
+def pad_nearest_upsample_backward(dout, src_hw, dsrc=None):
+    dout = dout.contiguous()
+    B, H, W, C = dout.shape
+    acc = dsrc is not None
+    if dsrc is None:
+        dsrc = torch.empty((B, int(src_hw[0]), int(src_hw[1]), C), dtype=torch.float32, device=dout.device)
+    with torch.cuda.device(dout.device):
+        _lib.check(_lib.lib().vstab_pad_nearest_upsample_backward(dout.data_ptr(), B, H, W, C, dsrc.data_ptr(), dsrc.shape[1], dsrc.shape[2],
+                                                                  1 if acc else 0, runtime.stream_ptr()))
+    return dsrc

@@ -236,9 +236,34 @@ VSTAB_API int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x, 
  * same call computes that layer's FORWARD output. */
 VSTAB_API size_t vstab_conv_dgrad_workspace_bytes(int B, int Ho, int Wo, int cs_g, int cout, int k, int stride, int pad, int Hi, int Wi,
                                                   int cs_x, int cx_off, int cin, int accumulate);
-VSTAB_API int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs_g, int cg_off, int cout, const float *W, int k,
-                               int stride, int pad, float *dx, int Hi, int Wi, int cs_x, int cx_off, int cin, int accumulate,
-                               void *workspace, size_t workspace_bytes, void *stream);
+VSTAB_API int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs_g, int cg_off, int cout, const float *W,
+                               const float *bias /* device [cin] added to every output pixel, or NULL */, int k, int stride, int pad,
+                               float *dx, int Hi, int Wi, int cs_x, int cx_off, int cin, int accumulate, void *workspace,
+                               size_t workspace_bytes, void *stream);
+/* PadLayer(pad) -> Conv2d(k, stride, VALID) + bias with DEVICE-resident raw weights W [k,k,cin,cout] (training: the weights
+ * change every step, so the MFMA operand is gathered on the device from an index table cached per geometry).
+ * act: 0 none, 1 leaky relu 0.1, 2 relu, 3 none and ADD to what is in y. */
+/* Ho, Wo: the output size; 0, 0 = floor((Hi + 2 pad - k)/stride) + 1, or that + 1 (TF SAME on an odd size: the last window
+ * sticks out of the image and reads zeros there). */
+VSTAB_API size_t vstab_conv_forward_workspace_bytes(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int pad, int cout, int cs_y,
+                                                    int cy_off, int act, int Ho, int Wo);
+VSTAB_API int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *W, const float *bias,
+                                 int k, int stride, int pad, float *y, int Ho, int Wo, int cs_y, int cy_off, int cout, int act,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+/* din (+)= gain * (adjoint of tf.image.resize_images(., [oh,ow]))(dout): backward of the legacy bilinear resize. */
+VSTAB_API int vstab_resize_bilinear_backward(const float *dout, int B, int oh, int ow, int C, float *din, int h, int w, float gain,
+                                             int accumulate, void *stream);
+/* PadLayer(1) -> nearest-neighbour resize (align_corners=True) to H x W (model.py:795-802, 882-884), and its adjoint. C % 4 == 0. */
+VSTAB_API int vstab_pad_nearest_upsample(const float *src, int B, int h2, int w2, int C, float *out, int H, int W, void *stream);
+VSTAB_API int vstab_pad_nearest_upsample_backward(const float *dout, int B, int H, int W, int C, float *dsrc, int h2, int w2, int accumulate,
+                                                  void *stream);
+/* out[c] (+)= sum over the rows of g[row*cs + c_off + c] (bias gradients), deterministic two-stage reduction. */
+VSTAB_API size_t vstab_column_sum_scratch_bytes(long long rows, int C);
+VSTAB_API int vstab_column_sum(const float *g, long long rows, int cs, int c_off, int C, float *out, int accumulate, void *scratch,
+                               size_t scratch_bytes, void *stream);
+/* tf.train.AdamOptimizer update (main:333-335) on a flat tensor; lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) is the caller's. */
+VSTAB_API int vstab_adam_step(float *w, const float *g, float *m, float *v, long long n, float lr_t, float beta1, float beta2, float eps,
+                              void *stream);
 
 /* BatchNormLayer(act=lrelu 0.1, is_train=True, gamma_init=None) (model.py:809...) IN PLACE on channels c_off..c_off+C of
  * an NHWC tensor viewed as [rows, cs]: batch mean / population variance (tf.nn.moments), y = lrelu((z-mean)*rsqrt(var+eps)

@@ -53,6 +53,20 @@ def bn_lrelu(x, beta, mean, var):
     return torch.maximum(y, 0.1 * y)      # tl.act.lrelu(x, 0.1) = max(x, 0.1 x), model.py:788
 
 
+def bn_lrelu_train(x, beta, mask=None):
+    """BatchNormLayer(act=lrelu(0.1), is_train=True, gamma_init=None): batch mean / population variance over (N,H,W)
+    (tf.nn.moments), no gamma.  Returns (y, mean, var) -- the moving averages are the caller's business.
+    `mask` (bool, optional) fixes which side of the leaky relu every element is on: the gradient is discontinuous at the
+    kink, so a parity check of a BACKWARD pass hands the checked implementation's own activation pattern in (a pre-activation
+    within rounding distance of zero would otherwise flip a whole 0.9*dy between an fp32 and an fp64 forward)."""
+    mean = x.mean(dim=(0, 1, 2))
+    var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
+    y = (x - mean) * torch.rsqrt(var + BN_EPS) + beta
+    if mask is not None:
+        return y * torch.where(mask, 1.0, 0.1).to(y.dtype), mean, var
+    return torch.maximum(y, 0.1 * y), mean, var
+
+
 def deconv4x4s2(x, W_hwoi, b, out_hw: Tuple[int, int]):
     """DeConv2dLayer(shape=(4,4,Cout,Cin), output_shape=(B,h,w,Cout), strides 2, SAME) + bias
     (model.py:850): y[oy,ox,co] = b + sum x[iy,ix,ci] W[ky,kx,co,ci] over oy = 2 iy + ky - 1
@@ -132,8 +146,11 @@ def level_sizes(H: int, W: int):
 
 
 def flownetS_pyramid(feats, weights: Dict[str, np.ndarray], dtype=torch.float64,
-                     return_internals: bool = False):
-    """The inference graph of model.py:786-893 (is_train=False).  `weights` uses short
+                     return_internals: bool = False, is_train: bool = False, batch_stats: dict = None,
+                     lrelu_masks: dict = None):
+    """The graph of model.py:786-893; `is_train` selects BatchNorm's batch statistics (the training graph, main:184) --
+    then `batch_stats` (if a dict) receives {layer: (mean, var)} for the moving-average update and `lrelu_masks`
+    ({layer: bool tensor}) pins the leaky-relu side of every element (see bn_lrelu_train).  `weights` uses short
     names ('1/W_conv2d', 'deconv5_bn/beta', ... SURVEY.md A.7)."""
     x = _t(feats, dtype)
     Wt = {k: _t(v, dtype) for k, v in weights.items()}
@@ -142,7 +159,12 @@ def flownetS_pyramid(feats, weights: Dict[str, np.ndarray], dtype=torch.float64,
 
     def enc(name, inp, k, s, p):
         y = pad_conv(inp, Wt[f"{name}/W_conv2d"], Wt[f"{name}/b_conv2d"], p, s)
-        y = bn_lrelu(y, Wt[f"{name}/beta"], Wt[f"{name}/moving_mean"], Wt[f"{name}/moving_variance"])
+        if is_train:
+            y, m, v = bn_lrelu_train(y, Wt[f"{name}/beta"], None if lrelu_masks is None else lrelu_masks[name])
+            if batch_stats is not None:
+                batch_stats[name] = (m.detach(), v.detach())
+        else:
+            y = bn_lrelu(y, Wt[f"{name}/beta"], Wt[f"{name}/moving_mean"], Wt[f"{name}/moving_variance"])
         internals[f"conv{name}"] = y
         return y
 
@@ -162,6 +184,11 @@ def flownetS_pyramid(feats, weights: Dict[str, np.ndarray], dtype=torch.float64,
 
     def dec(dname, inp, out_hw):                       # :850-851 etc.
         y = deconv4x4s2(inp, Wt[f"{dname}/W_deconv2d"], Wt[f"{dname}/b_deconv2d"], out_hw)
+        if is_train:
+            y, m, v = bn_lrelu_train(y, Wt[f"{dname}_bn/beta"], None if lrelu_masks is None else lrelu_masks[f"{dname}_bn"])
+            if batch_stats is not None:
+                batch_stats[f"{dname}_bn"] = (m.detach(), v.detach())
+            return y
         return bn_lrelu(y, Wt[f"{dname}_bn/beta"], Wt[f"{dname}_bn/moving_mean"],
                         Wt[f"{dname}_bn/moving_variance"])
 

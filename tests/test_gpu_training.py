@@ -235,3 +235,35 @@ def test_lrelu_backward():
     ref = dy.clone()
     ref[..., 4:] = dy[..., 4:] * torch.where(y[..., 4:] > 0, 1.0, 0.1)
     assert torch.allclose(out, ref, atol=0, rtol=1e-7)
+
+
+# ----------------------------------------------------------------------------- resampler adjoints
+@pytest.mark.parametrize("h,w,oh,ow,C", [(6, 8, 12, 16, 4), (12, 16, 24, 32, 2), (48, 64, 382, 510, 2), (5, 7, 9, 13, 4), (24, 32, 6, 8, 3),
+                                         (7, 7, 7, 7, 4)])
+def test_resize_bilinear_backward_is_the_adjoint(h, w, oh, ow, C):
+    g0 = torch.Generator().manual_seed(h + oh)
+    x = torch.randn(2, h, w, C, generator=g0, dtype=torch.float64, requires_grad=True)
+    y = vo.resize_bilinear_legacy(x, oh, ow)
+    dy = torch.randn(2, oh, ow, C, generator=g0)
+    y.backward(dy.double())
+    got = training.resize_bilinear_backward(dy.cuda(), (h, w), gain=1.0)
+    assert float((got.double().cpu() - x.grad).abs().max()) <= 1e-5 * max(1.0, float(x.grad.abs().max()))
+    acc = training.resize_bilinear_backward(dy.cuda(), (h, w), gain=2.0, din=got.clone())
+    assert float((acc.double().cpu() - 3 * x.grad).abs().max()) <= 3e-5 * max(1.0, float(x.grad.abs().max()))
+
+
+@pytest.mark.parametrize("h2,w2,H,W", [(12, 16, 48, 64), (96, 128, 384, 512), (13, 17, 50, 70), (3, 4, 9, 9), (24, 32, 96, 128)])
+def test_pad_nearest_upsample_forward_and_adjoint(h2, w2, H, W):
+    g0 = torch.Generator().manual_seed(h2)
+    src = torch.randn(2, h2, w2, 8, generator=g0)
+    iy = torch.from_numpy(vo.nearest_align_corners_index(h2 + 2, H))
+    ix = torch.from_numpy(vo.nearest_align_corners_index(w2 + 2, W))
+    p = torch.nn.functional.pad(src.double().requires_grad_(True), (0, 0, 1, 1, 1, 1))
+    srcd = src.double().requires_grad_(True)
+    ref = torch.nn.functional.pad(srcd, (0, 0, 1, 1, 1, 1))[:, iy][:, :, ix]
+    out = training.pad_nearest_upsample(src.cuda(), H, W)
+    assert torch.equal(out.cpu().double(), ref.detach())
+    dy = torch.randn(2, H, W, 8, generator=g0)
+    ref.backward(dy.double())
+    got = training.pad_nearest_upsample_backward(dy.cuda(), (h2, w2))
+    assert float((got.double().cpu() - srcd.grad).abs().max()) <= 1e-5 * max(1.0, float(srcd.grad.abs().max()))
