@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Training-step throughput: one `sess.run(optim_main)` of the reference = train-mode forward + loss_main
++ backward through the network + Adam, on synthetic data.  One JSON line.
+
+    python bench_train.py [--batch 8 --height 512 --width 512 --steps 10 --warmup 3]
+
+FLOP accounting: forward = netspec's 2*MACs; backward = input gradient + weight gradient of every conv-like layer ~ 2x forward
+(the first layer has no input gradient; the full-resolution head runs literally here, on the materialised upsampled tensor)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--phases", action="store_true", help="also time forward / loss+backward / Adam separately (adds syncs)")
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_train.py needs a GPU")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    from coupe.optical_flow_based_deep_video_stabilization_amd import netspec, train_step, weights as wts
+
+    B, H, W = args.batch, args.height, args.width
+    w = wts.synthetic_weights(seed=1, cin=27, random_bn=False, flow_gain=0.2)
+    tr = train_step.Trainer(w, B, H, W)
+    g = torch.Generator().manual_seed(0)
+    feats = torch.rand(B, H, W, 27, generator=g).cuda()
+    gt, un = torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda()
+    for _ in range(args.warmup):
+        loss = tr.step(feats, gt, un, lr=1e-4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(feats, gt, un, lr=1e-4)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    phases = None
+    if args.phases:
+        tf = tb = ta = 0.0
+        for _ in range(args.steps):
+            torch.cuda.synchronize(); a = time.perf_counter()
+            tr.forward(feats); torch.cuda.synchronize(); b = time.perf_counter()
+            tr.loss_and_backward(gt, un); torch.cuda.synchronize(); c = time.perf_counter()
+            tr.adam(1e-4); torch.cuda.synchronize(); d = time.perf_counter()
+            tf += b - a; tb += c - b; ta += d - c
+        phases = {"forward_ms": round(tf / args.steps * 1e3, 3), "loss_backward_ms": round(tb / args.steps * 1e3, 3),
+                  "adam_ms": round(ta / args.steps * 1e3, 3)}
+    gf = netspec.gflop_per_sample(H, W, 27)
+    print(json.dumps({
+        "metric": f"training samples/sec @{H}x{W}", "value": round(B / dt, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": "f32",
+        "data": "synthetic (uniform [0,1) frames, seeded He-normal weights)", "final_loss": float(loss),
+        "approx_tflops": round(3.0 * gf * B / dt / 1e3, 2), "phases": phases,
+        "config": {"workload": f"batch={B} {H}x{W}x27: train-mode forward + loss_main + backward + Adam (38.7 M parameters)"}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

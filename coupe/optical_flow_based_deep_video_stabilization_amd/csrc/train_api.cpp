@@ -376,3 +376,21 @@ extern "C" int vstab_column_sum(const float *g, long long rows, int cs, int c_of
     HIP_TRY(nullptr, launch_column_sum(g, rows, cs, c_off, C, out, accumulate ? 1 : 0, reinterpret_cast<float *>(scratch), (hipStream_t)stream));
     return VSTAB_OK;
 }
+
+// ------------------------------------------------------------------------- full-resolution head through its tap table
+extern "C" int vstab_pf2_from_taps(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2,
+                                   int H, int W, void *stream)
+{
+    if (!T || !bias2 || !pf3 || !pf2) return fail(nullptr, VSTAB_E_STATE, "pf2_from_taps: NULL buffer");
+    if (B < 1 || h2 < 1 || w2 < 1 || h3 < 1 || w3 < 1 || H < 3 || W < 3) return fail(nullptr, VSTAB_E_SHAPE, "pf2_from_taps: bad shape");
+    HIP_TRY(nullptr, launch_pf2(T, B, h2, w2, bias2, pf3, h3, w3, pf2, H, W, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_pf2_taps_backward(const float *g, int cs_g, int B, int H, int W, float *dT, int h2, int w2, void *stream)
+{
+    if (!g || !dT) return fail(nullptr, VSTAB_E_STATE, "pf2_taps_backward: NULL buffer");
+    if (B < 1 || h2 < 1 || w2 < 1 || H < 3 || W < 3 || cs_g < 2) return fail(nullptr, VSTAB_E_SHAPE, "pf2_taps_backward: bad shape");
+    HIP_TRY(nullptr, launch_pf2_taps_backward(g, cs_g, B, H, W, dT, h2, w2, (hipStream_t)stream));
+    return VSTAB_OK;
+}

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float *__restrict_
 }
 }  // namespace
 
-int bn_chunks(long long rows) { return (int)min((long long)1024, max((long long)1, (rows + 255) / 256)); }
+int bn_chunks(long long rows) { return (int)min((long long)96, max((long long)1, (rows + 255) / 256)); }
 
 hipError_t launch_bn_lrelu_train_forward(float *zy, long long rows, int cs, int c_off, int C, const float *beta, float *mov_mean,
                                          float *mov_var, float decay, float eps, float *save_mean, float *save_rstd, float *scratch,
@@ -407,6 +407,41 @@ __global__ __launch_bounds__(256) void pad_nearest_up_bwd_kernel(const float *__
     *o = s;
 }
 
+// Adjoint of pf2_kernel's gather (flow_ops.hip): the full-resolution head reads, for output pixel (y,x) and tap (dy,dx), the
+// tap-table entry of source pixel s = (nearest(y+dy) - 1, nearest(x+dx) - 1) of the UNPADDED concat2, so
+//   dT[n, s, tap*2 + o] = sum over the output pixels whose tap (dy,dx) maps to s of g[n, y, x, o].
+// One thread per (source pixel, tap); the output rows / columns that map to a source index form a contiguous range
+// (found by re-evaluating the forward's index function), so the sum has a fixed order.  Columns 18..31 are zeroed.
+__global__ __launch_bounds__(256) void pf2_taps_bwd_kernel(const float *__restrict__ g, int cs_g, int H, int W, float *__restrict__ dT,
+                                                           int h2, int w2, float sy, float sx)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= h2 * w2 * 16) return;
+    const int n = blockIdx.y;
+    const int tap = idx & 15;
+    const int pix = idx >> 4;
+    f32x2 *out = reinterpret_cast<f32x2 *>(dT + ((long long)n * h2 * w2 + pix) * 32) + tap;
+    if (tap >= 9) { f32x2 z = {0.f, 0.f}; *out = z; return; }
+    const int syi = pix / w2, sxi = pix - syi * w2;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int oh = H - 2, ow = W - 2;
+    const int rc = sy > 0.f ? (int)((float)(syi + 1) / sy) : 0, cc = sx > 0.f ? (int)((float)(sxi + 1) / sx) : 0;
+    const int span_y = sy > 0.f ? (int)(1.f / sy) + 2 : H, span_x = sx > 0.f ? (int)(1.f / sx) + 2 : W;
+    float a0 = 0.f, a1 = 0.f;
+    for (int r = max(dy, rc - span_y); r <= min(oh - 1 + dy, rc + span_y); ++r) {          // r = y + dy: row of the padded grid
+        if (nearest_ac_t(r, sy, h2 + 2) != syi + 1) continue;
+        const int y = r - dy;
+        for (int c = max(dx, cc - span_x); c <= min(ow - 1 + dx, cc + span_x); ++c) {
+            if (nearest_ac_t(c, sx, w2 + 2) != sxi + 1) continue;
+            const float *p = g + (((long long)n * oh + y) * ow + (c - dx)) * cs_g;
+            a0 += p[0];
+            a1 += p[1];
+        }
+    }
+    f32x2 o; o.x = a0; o.y = a1;
+    *out = o;
+}
+
 // tf.train.AdamOptimizer (main:333-335): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t m / (sqrt(v) + eps),
 // lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) computed by the caller
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
@@ -449,6 +484,14 @@ hipError_t launch_pad_nearest_up_backward(const float *dout, int B, int H, int W
     const long long per = (long long)h2 * w2 * (C / 4);
     pad_nearest_up_bwd_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(dout, H, W, C / 4, dsrc, h2, w2, sy,
                                                                                                       sx, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf2_taps_backward(const float *g, int cs_g, int B, int H, int W, float *dT, int h2, int w2, hipStream_t stream)
+{
+    const float sy = H > 1 ? (float)(h2 + 2 - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w2 + 2 - 1) / (float)(W - 1) : 0.f;
+    const int per = h2 * w2 * 16;
+    pf2_taps_bwd_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(g, cs_g, H, W, dT, h2, w2, sy, sx);
     return hipGetLastError();
 }
 

@@ -241,6 +241,8 @@ hipError_t launch_resize_bilinear_backward(const float *dout, int B, int oh, int
 hipError_t launch_pad_nearest_up(const float *src, int B, int h2, int w2, int C, float *out, int H, int W, hipStream_t stream);
 hipError_t launch_pad_nearest_up_backward(const float *dout, int B, int H, int W, int C, float *dsrc, int h2, int w2, int accumulate,
                                           hipStream_t stream);
+// adjoint of pf2_kernel's tap gather: dT [B,h2,w2,32] (col = tap*2+o) from the flow gradient g [B,H-2,W-2,cs_g]
+hipError_t launch_pf2_taps_backward(const float *g, int cs_g, int B, int H, int W, float *dT, int h2, int w2, hipStream_t stream);
 hipError_t launch_adam(float *w, const float *g, float *m, float *v, long long n, float lr_t, float b1, float b2, float eps,
                        hipStream_t stream);
 

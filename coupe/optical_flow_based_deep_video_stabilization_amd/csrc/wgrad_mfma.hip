@@ -248,7 +248,7 @@ hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream)
     return e;
 }
 
-int column_sum_chunks(long long rows) { return (int)std::min<long long>(1024, std::max<long long>(1, (rows + 255) / 256)); }
+int column_sum_chunks(long long rows) { return (int)std::min<long long>(96, std::max<long long>(1, (rows + 255) / 256)); }
 
 hipError_t launch_column_sum(const float *g, long long rows, int Cs, int c_off, int C, float *out, int accumulate, float *scratch,
                              hipStream_t stream)

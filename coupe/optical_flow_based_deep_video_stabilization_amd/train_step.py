@@ -105,8 +105,10 @@ class Trainer:
         self.pf = {k: z(s[0], s[1], 4) for k, s in self.flow_hw.items()}                   # flows in 4-channel pixels
         self.dpf = {k: z(s[0], s[1], 4) for k, s in self.flow_hw.items()}
         self.pconv = {k: z(s[0], s[1], 4) for k, s in self.flow_hw.items()}                # predict conv outputs before the residual
-        self.U = z(H, W, 196)                                                               # F7's upsampled concat2
-        self.dU = z(H, W, 196)
+        h2, w2 = hw["concat2"]
+        self.T = z(h2, w2, 32)                                                              # F7's tap table and its gradient
+        self.dT = z(h2, w2, 32)
+        self.pf2c = torch.zeros((B, H - 2, W - 2, 2), dtype=torch.float32, device=self.dev)
         self.save = {}                                                                       # BatchNorm (mean, rstd) per layer
 
     def _workspace(self, nbytes):
@@ -212,13 +214,18 @@ class Trainer:
             self._convT(a[ib], 0, a[ib].shape[3], p[f"{dname}/W_deconv2d"], p[f"{dname}/b_deconv2d"], 4, 2, 1, a[ob], ooff, cout, False)
             self._bn_fwd(f"{dname}_bn", a[ob], ooff, cout)
             prev = level
-        # full-resolution head (model.py:882-887)
-        self._check(self.L.vstab_pad_nearest_upsample(a["concat2"].data_ptr(), self.B, a["concat2"].shape[1], a["concat2"].shape[2], 196,
-                                                      self.U.data_ptr(), self.H, self.W, self.st))
-        self._conv_fwd(self.U, 0, 196, p["predict2/W_conv2d"], p["predict2/b_conv2d"], 3, 1, 0, self.pconv["predict_flow2"], 0, 4)
-        up = torch.empty_like(self.pf["predict_flow2"])
-        self._resize(self.pf["predict_flow3"], up)
-        self._axpby(1.0, self.pconv["predict_flow2"], 8.0, up, self.pf["predict_flow2"])
+        # full-resolution head (model.py:882-887) through its tap table, as in the inference path: the padded, nearest-upsampled
+        # concat2 (1.6 GB at B=8 512x512) never exists.  T[s][tap*2+o] = sum_c concat2[s][c] W[tap][c][o] is a 1x1 conv.
+        c2 = a["concat2"]
+        w2 = p["predict2/W_conv2d"]                                                       # [3,3,196,4], columns 2,3 zero
+        self.WT = torch.zeros((1, 1, 196, 32), dtype=torch.float32, device=self.dev)
+        self.WT[0, 0, :, :18].copy_(w2[..., :2].permute(2, 0, 1, 3).reshape(196, 18))
+        self._conv_fwd(c2, 0, 196, self.WT, None, 1, 1, 0, self.T, 0, 32)
+        pf3c = self.pf["predict_flow3"][..., :2].contiguous()
+        h3, w3 = pf3c.shape[1], pf3c.shape[2]
+        self._check(self.L.vstab_pf2_from_taps(self.T.data_ptr(), self.B, c2.shape[1], c2.shape[2], p["predict2/b_conv2d"].data_ptr(),
+                                               pf3c.data_ptr(), h3, w3, self.pf2c.data_ptr(), self.H, self.W, self.st))
+        self.pf["predict_flow2"][..., :2].copy_(self.pf2c)
         return {k: v[..., :2] for k, v in self.pf.items()}
 
     def lrelu_masks(self) -> Dict[str, torch.Tensor]:
@@ -260,13 +267,19 @@ class Trainer:
 
     def _backward(self):
         a, p, g, G = self.a, self.p, self.g, self.G
-        # full-resolution head
+        # full-resolution head: residual, then the adjoint of the tap gather and the 1x1 tap-table conv
         d2 = self.dpf["predict_flow2"]
+        c2 = a["concat2"]
         self._resize_bwd(d2, self.dpf["predict_flow3"], 8.0)
-        self._wgrad(self.U, 0, 196, d2, 0, 4, 3, 1, 0, g["predict2/W_conv2d"], g["predict2/b_conv2d"])
-        self._convT(d2, 0, 4, p["predict2/W_conv2d"], None, 3, 1, 0, self.dU, 0, 196, False)
-        self._check(self.L.vstab_pad_nearest_upsample_backward(self.dU.data_ptr(), self.B, self.H, self.W, 196, G["concat2"].data_ptr(),
-                                                               a["concat2"].shape[1], a["concat2"].shape[2], 1, self.st))
+        self._colsum(d2, 0, 4, g["predict2/b_conv2d"])
+        self._check(self.L.vstab_pf2_taps_backward(d2.data_ptr(), 4, self.B, self.H, self.W, self.dT.data_ptr(), c2.shape[1], c2.shape[2],
+                                                   self.st))
+        dWT = torch.empty((1, 1, 196, 32), dtype=torch.float32, device=self.dev)
+        self._wgrad(c2, 0, 196, self.dT, 0, 32, 1, 1, 0, dWT, None)
+        g["predict2/W_conv2d"].zero_()
+        g["predict2/W_conv2d"][..., :2].copy_(dWT[0, 0, :, :18].reshape(196, 3, 3, 2).permute(1, 2, 0, 3))
+        WTt = self.WT[0, 0].t().contiguous().view(1, 1, 32, 196)
+        self._conv_fwd(self.dT, 0, 32, WTt, None, 1, 1, 0, G["concat2"], 0, 196, act=3)
         # decoder levels, fine to coarse
         levels = ["predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3"]
         for i in range(3, -1, -1):

@@ -257,6 +257,13 @@ VSTAB_API int vstab_resize_bilinear_backward(const float *dout, int B, int oh, i
 VSTAB_API int vstab_pad_nearest_upsample(const float *src, int B, int h2, int w2, int C, float *out, int H, int W, void *stream);
 VSTAB_API int vstab_pad_nearest_upsample_backward(const float *dout, int B, int H, int W, int C, float *dsrc, int h2, int w2, int accumulate,
                                                   void *stream);
+/* The full-resolution head (model.py:882-887) through its tap table, as the inference path computes it: T [B,h2,w2,32] with
+ * T[s][tap*2+o] = sum_c concat2[s][c] W[tap][c][o] (a 1x1 conv, vstab_conv_forward); pf2 [B,H-2,W-2,2] = bias + the nine
+ * gathered taps + eight adds of the upsampled pf3 [B,h3,w3,2].  The backward of the gather: dT from the flow gradient
+ * g [B,H-2,W-2,cs_g] (channels 0,1), columns 18..31 zeroed. */
+VSTAB_API int vstab_pf2_from_taps(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2,
+                                  int H, int W, void *stream);
+VSTAB_API int vstab_pf2_taps_backward(const float *g, int cs_g, int B, int H, int W, float *dT, int h2, int w2, void *stream);
 /* out[c] (+)= sum over the rows of g[row*cs + c_off + c] (bias gradients), deterministic two-stage reduction. */
 VSTAB_API size_t vstab_column_sum_scratch_bytes(long long rows, int C);
 VSTAB_API int vstab_column_sum(const float *g, long long rows, int cs, int c_off, int C, float *out, int accumulate, void *scratch,
