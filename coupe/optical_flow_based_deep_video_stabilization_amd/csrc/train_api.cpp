@@ -134,7 +134,7 @@ bool dgrad_plan(int B, int Ho, int Wo, int cs_g, int cout, int k, int stride, in
         pack_index_dgrad_s2(k, pad, cin, cout, cs_g, L, p.Npad, tbl.data());
     }
     if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;
-    if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d.tbl); return false; }
+    if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d.tbl); return false; }
     cache[key] = d;
     out = d;
     return true;
@@ -210,7 +210,7 @@ extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs
 extern "C" size_t vstab_bn_scratch_bytes(long long rows, int C)
 {
     if (rows < 1 || C < 1) return 0;
-    return ((size_t)2 * bn_chunks(rows) + 2) * C * sizeof(float) + 256;
+    return ((size_t)4 * bn_chunks(rows) + 2) * C * sizeof(float) + 256;
 }
 
 extern "C" int vstab_bn_lrelu_train_forward(float *zy, long long rows, int cs, int c_off, int C, const float *beta, float *moving_mean,
@@ -278,7 +278,7 @@ bool fwd_plan(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int p
     std::vector<int32_t> tbl(d.packed_floats);
     pack_index_conv(k, k, cin, cs_x, cout, d.p.Npad, L, tbl.data());
     if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;
-    if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d.tbl); return false; }
+    if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d.tbl); return false; }
     cache[key] = d;
     out = d;
     return true;

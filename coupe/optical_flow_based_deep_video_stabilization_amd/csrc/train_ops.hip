@@ -151,34 +151,29 @@ hipError_t launch_loss_level(const float *pf, const float *G, const float *U, in
 //   mean, var = tf.nn.moments(z, [0,1,2])  (population variance);  y = lrelu((z - mean) * rsqrt(var + eps) + beta);
 //   moving = moving * decay + batch * (1 - decay)   (assign_moving_average, zero_debias = False)
 // and its backward.  Column reductions over the [rows, C] view of an NHWC channel slice run in two deterministic stages
-// (row-chunk partials, then the chunks in order), like column_sum_kernel.  The layer works IN PLACE: the conv's output z
+// (row-chunk partials, then the chunks in order), like column_sum_kernel; the forward's mean and variance come from ONE
+// pass (sum and sum of squares in double precision).  The layer works IN PLACE: the conv's output z
 // is overwritten by y, and the backward recovers what it needs from y (lrelu is invertible: u = y > 0 ? y : y / 0.1,
 // xhat = u - beta), so no second activation copy is kept.
 // ---------------------------------------------------------------------------------
 namespace {
-// MODE 0: sum z | 1: sum (z - m[c])^2 | 2: two sums for the backward: sum g, sum g * xhat  (g = dy * lrelu'(y))
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_colsum_kernel(const float *__restrict__ a, int cs_a, int ca_off, const float *__restrict__ b,
-                                                        int cs_b, int cb_off, const float *__restrict__ vec, long long rows,
-                                                        int rows_per_chunk, int C, float *__restrict__ part)
+// the two sums of the backward: sum g and sum g * xhat with g = dy * lrelu'(y), xhat = lrelu^-1(y) - beta; part = [chunk][2][C]
+__global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(const float *__restrict__ y, int cs_y, int cy_off, const float *__restrict__ dyp,
+                                                            int cs_g, int cg_off, const float *__restrict__ beta, long long rows,
+                                                            int rows_per_chunk, int C, float *__restrict__ part)
 {
     __shared__ float red[2][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     float s0 = 0.f, s1 = 0.f;
     if (c < C) {
-        const float v = (MODE == 0) ? 0.f : vec[c];                  // MODE 1: mean, MODE 2: beta
+        const float bt = beta[c];
         for (long long r = r0 + wave; r < r1; r += 4) {
-            const float x = a[r * cs_a + ca_off + c];
-            if (MODE == 0) s0 += x;
-            else if (MODE == 1) { const float d = x - v; s0 += d * d; }
-            else {
-                const float y = x, dy = b[r * cs_b + cb_off + c];
-                const float g = y > 0.f ? dy : 0.1f * dy;
-                const float xhat = (y > 0.f ? y : y / 0.1f) - v;
-                s0 += g;
-                s1 += g * xhat;
-            }
+            const float yy = y[r * cs_y + cy_off + c], dy = dyp[r * cs_g + cg_off + c];
+            const float g = yy > 0.f ? dy : 0.1f * dy;
+            const float xhat = (yy > 0.f ? yy : yy / 0.1f) - bt;
+            s0 += g;
+            s1 += g * xhat;
         }
     }
     red[0][wave][threadIdx.x & 63] = s0;
@@ -187,27 +182,50 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const float *__restrict_
     if (wave == 0 && c < C) {
         const int l = threadIdx.x;
         part[((long long)blockIdx.y * 2 + 0) * C + c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
-        if (MODE == 2) part[((long long)blockIdx.y * 2 + 1) * C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+        part[((long long)blockIdx.y * 2 + 1) * C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
     }
 }
 
-// final stage of the forward statistics: STEP 0 -> mean; STEP 1 -> rstd + moving-average update
-template <int STEP>
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__restrict__ part, int chunks, int C, float inv_rows, float eps,
-                                                             float decay, float *__restrict__ mean, float *__restrict__ rstd,
-                                                             float *__restrict__ mov_mean, float *__restrict__ mov_var)
+// forward statistics in ONE pass over z: per-chunk sum and sum of squares in double precision (full-rate fp64 adds on this
+// chip; E[z^2] - mean^2 in double loses nothing that matters for fp32 data), part = [chunk][2][C] doubles
+__global__ __launch_bounds__(256) void bn_moments_kernel(const float *__restrict__ z, int cs, int c_off, long long rows, int rows_per_chunk,
+                                                         int C, double *__restrict__ part)
+{
+    __shared__ double red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    double s0 = 0.0, s1 = 0.0;
+    if (c < C)
+        for (long long r = r0 + wave; r < r1; r += 4) {
+            const double x = (double)z[r * cs + c_off + c];
+            s0 += x;
+            s1 += x * x;
+        }
+    red[0][wave][threadIdx.x & 63] = s0;
+    red[1][wave][threadIdx.x & 63] = s1;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        const int l = threadIdx.x;
+        part[((long long)blockIdx.y * 2 + 0) * C + c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        part[((long long)blockIdx.y * 2 + 1) * C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_moments_final_kernel(const double *__restrict__ part, int chunks, int C, double inv_rows, float eps,
+                                                               float decay, float *__restrict__ mean, float *__restrict__ rstd,
+                                                               float *__restrict__ mov_mean, float *__restrict__ mov_var)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += part[(long long)k * 2 * C + c];
-    if (STEP == 0) mean[c] = s * inv_rows;
-    else {
-        const float var = s * inv_rows;
-        rstd[c] = 1.0f / sqrtf(var + eps);
-        if (mov_mean) mov_mean[c] = mov_mean[c] * decay + mean[c] * (1.f - decay);
-        if (mov_var) mov_var[c] = mov_var[c] * decay + var * (1.f - decay);
-    }
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < chunks; ++k) { s += part[((long long)k * 2 + 0) * C + c]; q += part[((long long)k * 2 + 1) * C + c]; }
+    const double m = s * inv_rows;
+    double var = q * inv_rows - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (mov_mean) mov_mean[c] = mov_mean[c] * decay + (float)m * (1.f - decay);
+    if (mov_var) mov_var[c] = mov_var[c] * decay + (float)var * (1.f - decay);
 }
 
 __global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(float *__restrict__ zy, int cs, int c_off, int C4, long long rows,
@@ -278,14 +296,12 @@ hipError_t launch_bn_lrelu_train_forward(float *zy, long long rows, int cs, int 
                                          hipStream_t stream)
 {
     if ((C & 3) || (cs & 3) || (c_off & 3)) return hipErrorInvalidValue;
-    const int chunks = bn_chunks(rows);                                   // scratch: 2 * chunks * C floats
+    const int chunks = bn_chunks(rows);                                   // scratch: 2 * chunks * C doubles
     const int rpc = (int)((rows + chunks - 1) / chunks);
-    const dim3 g1((unsigned)((C + 63) / 64), (unsigned)chunks), g2((unsigned)((C + 255) / 256));
-    const float inv = 1.0f / (float)rows;
-    bn_colsum_kernel<0><<<g1, dim3(256), 0, stream>>>(zy, cs, c_off, nullptr, 0, 0, nullptr, rows, rpc, C, scratch);
-    bn_stats_final_kernel<0><<<g2, dim3(256), 0, stream>>>(scratch, chunks, C, inv, eps, decay, save_mean, save_rstd, mov_mean, mov_var);
-    bn_colsum_kernel<1><<<g1, dim3(256), 0, stream>>>(zy, cs, c_off, nullptr, 0, 0, save_mean, rows, rpc, C, scratch);
-    bn_stats_final_kernel<1><<<g2, dim3(256), 0, stream>>>(scratch, chunks, C, inv, eps, decay, save_mean, save_rstd, mov_mean, mov_var);
+    double *part = reinterpret_cast<double *>(scratch);
+    bn_moments_kernel<<<dim3((unsigned)((C + 63) / 64), (unsigned)chunks), dim3(256), 0, stream>>>(zy, cs, c_off, rows, rpc, C, part);
+    bn_moments_final_kernel<<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream>>>(part, chunks, C, 1.0 / (double)rows, eps, decay,
+                                                                                       save_mean, save_rstd, mov_mean, mov_var);
     const long long n4 = rows * (C / 4);
     bn_lrelu_apply_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream>>>(zy, cs, c_off, C / 4, rows, save_mean, save_rstd, beta);
     return hipGetLastError();
@@ -297,8 +313,8 @@ hipError_t launch_bn_lrelu_train_backward(const float *y, int cs_y, int cy_off, 
 {
     const int chunks = bn_chunks(rows);
     const int rpc = (int)((rows + chunks - 1) / chunks);
-    bn_colsum_kernel<2><<<dim3((unsigned)((C + 63) / 64), (unsigned)chunks), dim3(256), 0, stream>>>(y, cs_y, cy_off, dy, cs_g, cg_off, beta,
-                                                                                                  rows, rpc, C, scratch);
+    bn_bwd_colsum_kernel<<<dim3((unsigned)((C + 63) / 64), (unsigned)chunks), dim3(256), 0, stream>>>(y, cs_y, cy_off, dy, cs_g, cg_off, beta,
+                                                                                                   rows, rpc, C, scratch);
     float *sums = scratch + (size_t)2 * chunks * C;                        // scratch: (2 * chunks + 2) * C floats
     bn_bwd_final_kernel<<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream>>>(scratch, chunks, C, sums, dbeta, accumulate);
     const long long n = rows * C;

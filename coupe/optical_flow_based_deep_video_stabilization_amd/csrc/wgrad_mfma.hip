@@ -41,9 +41,15 @@ __global__ __launch_bounds__(256) void wgrad_pixel_table_kernel(int B, int Hi, i
     ptab[k] = make_int4(((n * Hi + y0) * Wi + x0) * Cs, y0, x0, 0);
 }
 
+// BN = 128 (wave tile 64x64) or 64 (wave tile 64x32, for layers with at most 64 output channels)
+template <int BN>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
 {
-    constexpr int BM = 128, BN = 128, KT = 32;
+    constexpr int BM = 128, KT = 32;
+    constexpr int NBW = BN / 64;                 // 32-column MFMA blocks per wave
+    constexpr int BL = BN / 4;                   // lanes per pixel row of the B tile (16-byte chunks)
+    constexpr int BR = 256 / BL;                 // B rows per DMA pass
+    constexpr int BP = KT / BR;                  // DMA passes for B
     // dynamic LDS like the forward kernel: with static arrays hipcc orders every fragment read after the DMA that was
     // just issued into the OTHER stage (it sees one object) and the prefetch is lost
     extern __shared__ __attribute__((aligned(16))) char wg_smem[];
@@ -71,9 +77,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
     const int tap = m_ok ? m / p.Cin : 0, ci = m - tap * p.Cin;
     const int ky = tap / p.KW, kx = tap - ky * p.KW;
     const int a_delta = (ky * p.Wi + kx) * p.Cs_x + p.cx_off + ci;          // added to the pixel's window origin
-    // B: column co = n0 + cc .. +3
-    const bool n_ok = n0 + cc < p.Cout;
-    const int b_delta = p.cg_off + n0 + cc;
+    // B: column co = n0 + ccb .. +3
+    const int ccb = (tid % BL) * 4;
+    const bool n_ok = n0 + ccb < p.Cout;
+    const int b_delta = p.cg_off + n0 + ccb;
 
     // one K-tile: 32 pixels x 128 floats per operand = 4 DMA instructions per thread per operand (8 pixel rows per pass).
     // The pixel-table entries of a tile are fetched one tile AHEAD of its DMA (plain loads into registers, issued behind
@@ -88,29 +95,32 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = kt * KT + (tid >> 5) + 8 * j;
-            const bool k_ok = t_ok & (k < p.K);
-            const bool a_ok = k_ok & m_ok & ((unsigned)(pt[j].y + ky) < (unsigned)p.Hi) & ((unsigned)(pt[j].z + kx) < (unsigned)p.Wi);
+            const bool a_ok = t_ok & (k < p.K) & m_ok & ((unsigned)(pt[j].y + ky) < (unsigned)p.Hi) & ((unsigned)(pt[j].z + kx) < (unsigned)p.Wi);
             const unsigned aoff = a_ok ? (unsigned)(pt[j].x + a_delta) * 4u : OOB;
-            const unsigned boff = (k_ok & n_ok) ? (unsigned)(k * p.Cs_g + b_delta) * 4u : OOB;
             __attribute__((address_space(3))) void *da =
                 (__attribute__((address_space(3))) void *)(sA + buf * (KT * BM) + (8 * j + 2 * wave_u) * BM);
-            __attribute__((address_space(3))) void *db =
-                (__attribute__((address_space(3))) void *)(sB + buf * (KT * BN) + (8 * j + 2 * wave_u) * BN);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, da, 16, aoff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int k = kt * KT + tid / BL + BR * j;
+            const unsigned boff = (t_ok & (k < p.K) & n_ok) ? (unsigned)(k * p.Cs_g + b_delta) * 4u : OOB;
+            __attribute__((address_space(3))) void *db =
+                (__attribute__((address_space(3))) void *)(sB + buf * (KT * BN) + (BR * j + (64 / BL) * wave_u) * BN);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, db, 16, boff, 0, 0, 0);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NBW];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NBW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int li = lane & 31, lh = lane >> 5;
-    const int a_col = wm * 64 + li, b_col = wn * 64 + li;
+    const int a_col = wm * 64 + li, b_col = wn * (BN / 2) + li;
 
     if (kt0 < kt1) {
         load_pt(kt0);
@@ -124,18 +134,19 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
             const float *cA = sA + buf * (KT * BM) + lh * BM + a_col;
             const float *cB = sB + buf * (KT * BN) + lh * BN + b_col;
             // MFMA k-step ks covers pixels 2*ks + {0, 1}; the fragments of step ks+1 are read before the MFMAs of step ks
-            float a0 = cA[0], a1 = cA[32], b0 = cB[0], b1 = cB[32];
+            float a0 = cA[0], a1 = cA[32], b0 = cB[0], b1 = NBW > 1 ? cB[32] : 0.f;
 #pragma unroll
             for (int ks = 0; ks < KT / 2; ++ks) {
                 float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
                 if (ks + 1 < KT / 2) {
                     na0 = cA[(ks + 1) * 2 * BM]; na1 = cA[(ks + 1) * 2 * BM + 32];
-                    nb0 = cB[(ks + 1) * 2 * BN]; nb1 = cB[(ks + 1) * 2 * BN + 32];
+                    nb0 = cB[(ks + 1) * 2 * BN];
+                    if (NBW > 1) nb1 = cB[(ks + 1) * 2 * BN + 32];
                 }
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                if (NBW > 1) acc[0][NBW - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][NBW - 1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                if (NBW > 1) acc[1][NBW - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][NBW - 1], 0, 0, 0);
                 a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
             }
             __syncthreads();                                               // tile kt+1 landed, tile kt's slot is free
@@ -146,8 +157,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
     // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float *dst = p.ksplit > 1 ? p.partial + (size_t)split * p.M * p.Cout : p.dW;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int col = n0 + wn * 64 + nb * 32 + li;
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int col = n0 + wn * (BN / 2) + nb * 32 + li;
         if (col >= p.Cout) continue;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -213,7 +224,8 @@ __global__ __launch_bounds__(256) void column_sum_final_kernel(const float *__re
 
 int wgrad_choose_split(const WgradParams &p)
 {
-    const long long tiles = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    const int bn = p.Cout <= 64 ? 64 : 128;
+    const long long tiles = (long long)((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);
     const int ktiles = (p.K + 31) / 32;
     int ks = (int)(512 / (tiles > 0 ? tiles : 1));                           // two 64 KB workgroups fit a CU
     if (ks < 1) ks = 1;
@@ -236,8 +248,13 @@ hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream)
     if ((p.Cin & 3) || (p.Cs_x & 3) || (p.cx_off & 3) || (p.Cs_g & 3) || (p.cg_off & 3) || p.ksplit < 1) return hipErrorInvalidValue;
     if (p.x_bytes >= 0x80000000u || p.g_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.ksplit > 1 && !p.partial) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)((p.Cout + 127) / 128), (unsigned)p.ksplit);
-    wgrad_mfma_kernel<<<grid, dim3(256), 2 * 32 * (128 + 128) * sizeof(float), stream>>>(p);
+    if (p.Cout <= 64) {
+        dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)((p.Cout + 63) / 64), (unsigned)p.ksplit);
+        wgrad_mfma_kernel<64><<<grid, dim3(256), 2 * 32 * (128 + 64) * sizeof(float), stream>>>(p);
+    } else {
+        dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)((p.Cout + 127) / 128), (unsigned)p.ksplit);
+        wgrad_mfma_kernel<128><<<grid, dim3(256), 2 * 32 * (128 + 128) * sizeof(float), stream>>>(p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (p.ksplit > 1) {

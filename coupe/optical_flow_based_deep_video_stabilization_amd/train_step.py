@@ -289,7 +289,7 @@ class Trainer:
             # deconvN: BatchNorm backward in place on its slice of the concat gradient, then filter / bias / input gradients
             self._bn_bwd(f"{dname}_bn", a[ob], G[ob], ooff, cout)
             self._wgrad(G[ob], ooff, cout, a[ib], 0, cs_in, 4, 2, 1, g[f"{dname}/W_deconv2d"], None)
-            self._colsum(G[ob], ooff, cout, g[f"{dname}/b_deconv2d"])
+            g[f"{dname}/b_deconv2d"].zero_()          # a bias in front of BatchNorm: sum of dz = 0 exactly (sum of xhat = 0)
             self._conv_fwd(G[ob], ooff, cout, p[f"{dname}/W_deconv2d"], None, 4, 2, 1, G[ib], 0, cs_in, act=3)
             # upsample_flowN: its input is this level's flow
             self._wgrad(G[ob], foff, 4, self.pf[level], 0, 4, 4, 2, 1, g[f"{uname}/W_deconv2d"], None)
@@ -306,7 +306,8 @@ class Trainer:
             ib, ioff, cin = ENC_IN[name]
             ob, ooff = ENC_OUT[name]
             self._bn_bwd(name, a[ob], G[ob], ooff, cout)
-            self._wgrad(a[ib], ioff, cin, G[ob], ooff, cout, k, s, pad, g[f"{name}/W_conv2d"], g[f"{name}/b_conv2d"])
+            self._wgrad(a[ib], ioff, cin, G[ob], ooff, cout, k, s, pad, g[f"{name}/W_conv2d"], None)
+            g[f"{name}/b_conv2d"].zero_()               # same: the batch mean removes the bias, its gradient is exactly zero
             if ib != "x0":
                 self._convT(G[ob], ooff, cout, p[f"{name}/W_conv2d"], None, k, s, pad, G[ib], ioff, cin, True)
 
