@@ -29,23 +29,41 @@ def main():
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_train.py needs a GPU")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    use_dist = world > 1 or os.environ.get("VSTAB_FORCE_DIST") == "1"      # data-parallel replicas, gradients averaged over RCCL
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from coupe.optical_flow_based_deep_video_stabilization_amd import netspec, train_step, weights as wts
 
     B, H, W = args.batch, args.height, args.width
     w = wts.synthetic_weights(seed=1, cin=27, random_bn=False, flow_gain=0.2)
     tr = train_step.Trainer(w, B, H, W)
-    g = torch.Generator().manual_seed(0)
+    g = torch.Generator().manual_seed(rank)                # every replica trains on its own shard
     feats = torch.rand(B, H, W, 27, generator=g).cuda()
     gt, un = torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda()
     for _ in range(args.warmup):
         loss = tr.step(feats, gt, un, lr=1e-4)
     torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tr.step(feats, gt, un, lr=1e-4)
     torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    if use_dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax[0])
     phases = None
     if args.phases:
         tf = tb = ta = 0.0
@@ -58,12 +76,20 @@ def main():
         phases = {"forward_ms": round(tf / args.steps * 1e3, 3), "loss_backward_ms": round(tb / args.steps * 1e3, 3),
                   "adam_ms": round(ta / args.steps * 1e3, 3)}
     gf = netspec.gflop_per_sample(H, W, 27)
+    if rank != 0:
+        if use_dist:
+            dist.destroy_process_group()
+        return
     print(json.dumps({
-        "metric": f"training samples/sec @{H}x{W}", "value": round(B / dt, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+        "metric": f"training samples/sec @{H}x{W}", "value": round(B * world / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "scaling": "weak",
         "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": "f32",
         "data": "synthetic (uniform [0,1) frames, seeded He-normal weights)", "final_loss": float(loss),
-        "approx_tflops": round(3.0 * gf * B / dt / 1e3, 2), "phases": phases,
-        "config": {"workload": f"batch={B} {H}x{W}x27: train-mode forward + loss_main + backward + Adam (38.7 M parameters)"}}), flush=True)
+        "approx_tflops": round(3.0 * gf * B * world / dt / 1e3, 2), "phases": phases,
+        "config": {"workload": f"batch={B} per GPU {H}x{W}x27: train-mode forward + loss_main + backward + Adam (38.7 M parameters)"
+                               + ("; gradients averaged with one RCCL all-reduce of a 155 MB bucket" if use_dist else "")}}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

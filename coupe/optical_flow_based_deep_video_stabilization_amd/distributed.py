@@ -2,7 +2,11 @@
 collective -- an all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) that reassembles
 the stabilised sequence.  The reference has no distributed code at all (single tf.Session,
 main:489); samples are independent at inference (BatchNorm uses moving statistics), so there is
-no other exchange step on this path."""
+no other exchange step on this path.
+
+Training is the one place with a real exchange: data-parallel replicas average their gradients --
+`GradBucket` keeps every parameter gradient as a view into ONE flat buffer so that the step needs a single all-reduce
+(155 MB for the 38.7 M parameters; on xGMI's point-to-point links one large collective beats many small ones)."""
 from __future__ import annotations
 
 from typing import List, Optional, Tuple
@@ -86,3 +90,37 @@ class FrameGatherer:
     def drain(self):
         for s in range(self.depth):
             self._wait(s)
+
+
+class GradBucket:
+    """One flat fp32 buffer; `views[name]` are tensors of the given shapes that alias consecutive pieces of it (each piece
+    16-byte aligned).  `allreduce_mean()` averages the whole buffer over the process group in a single collective."""
+
+    def __init__(self, shapes, device):
+        self.offsets, n = {}, 0
+        for name, shape in shapes.items():
+            self.offsets[name] = n
+            numel = 1
+            for s in shape:
+                numel *= int(s)
+            n += (numel + 3) // 4 * 4
+        self.flat = torch.zeros(max(n, 4), dtype=torch.float32, device=device)
+        self.views = {}
+        for name, shape in shapes.items():
+            numel = 1
+            for s in shape:
+                numel *= int(s)
+            self.views[name] = self.flat[self.offsets[name]:self.offsets[name] + numel].view(tuple(shape))
+
+    def allreduce_mean(self, group=None, async_op: bool = False):
+        """flat <- mean over ranks.  No-op without an initialised process group or with a single rank."""
+        if not dist.is_available() or not dist.is_initialized():
+            return None
+        world = dist.get_world_size(group)
+        if world == 1:
+            return None
+        if hasattr(dist.ReduceOp, "AVG") and self.flat.is_cuda:
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=False)
+        self.flat.mul_(1.0 / world)           # gloo has no AVG: a scale on the flat buffer (CPU tests only)
+        return work

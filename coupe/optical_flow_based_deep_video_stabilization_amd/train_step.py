@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib, netspec, runtime
+from .distributed import GradBucket
 from .training import LOSS_LEVELS, TV_WEIGHTS
 
 ENC = (("1", 7, 2, 3, 64), ("2", 5, 2, 2, 128), ("3", 5, 2, 2, 256), ("3_1", 3, 1, 1, 256), ("4", 3, 2, 1, 512),
@@ -68,7 +69,11 @@ class Trainer:
         self.trainable = [k for k in self.p if "moving_" not in k]
         self.m = {k: torch.zeros_like(self.p[k]) for k in self.trainable}
         self.v = {k: torch.zeros_like(self.p[k]) for k in self.trainable}
-        self.g = {k: torch.zeros_like(self.p[k]) for k in self.trainable}
+        # every gradient is a view into one flat buffer: data-parallel replicas average them with a single all-reduce;
+        # the BatchNorm moving statistics get the same treatment so that replicas stay identical
+        self.gbucket = GradBucket({k: tuple(self.p[k].shape) for k in self.trainable}, self.dev)
+        self.g = self.gbucket.views
+        self.sbucket = GradBucket({k: tuple(self.p[k].shape) for k in self.p if "moving_" in k}, self.dev)
         self.t = 0
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.dev)
         self._alloc_buffers()
@@ -319,10 +324,26 @@ class Trainer:
             self._check(self.L.vstab_adam_step(self.p[k].data_ptr(), self.g[k].data_ptr(), self.m[k].data_ptr(), self.v[k].data_ptr(),
                                                self.p[k].numel(), lr_t, beta1, beta2, eps, self.st))
 
-    def step(self, feats, gtstab, unstab, lr: float, beta1: float = 0.9):
-        """One optimiser step; returns loss_main evaluated before the update (what `sess.run([loss_main, optim_main])` prints)."""
+    def sync_replicas(self, group=None):
+        """Data-parallel exchange (no-op on one rank): gradients averaged with ONE all-reduce of the flat bucket, BatchNorm
+        moving statistics averaged the same way (each replica normalises with its own batch statistics, as the reference's
+        single-GPU graph would on that shard)."""
+        import torch.distributed as dist
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        self.gbucket.allreduce_mean(group)
+        for k, v in self.sbucket.views.items():
+            v.copy_(self.p[k])
+        self.sbucket.allreduce_mean(group)
+        for k, v in self.sbucket.views.items():
+            self.p[k].copy_(v)
+
+    def step(self, feats, gtstab, unstab, lr: float, beta1: float = 0.9, group=None):
+        """One optimiser step; returns this rank's loss_main evaluated before the update (what
+        `sess.run([loss_main, optim_main])` prints).  Under torch.distributed the replicas' gradients are averaged first."""
         with torch.cuda.device(self.dev):
             self.forward(feats)
             loss = self.loss_and_backward(gtstab, unstab)
+            self.sync_replicas(group)
             self.adam(lr, beta1)
         return loss

@@ -69,3 +69,42 @@ def test_shard_range_partition():
     assert vd.shard_sizes(1000, 8) == [125] * 8
     with pytest.raises(ValueError):
         vd.shard_range(4, 2, 2)
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes = {"a/W": (3, 3, 4, 8), "a/b": (6,), "c/beta": (5,)}                   # 6 and 5 are padded to 8 inside the bucket
+        b = vd.GradBucket(shapes, "cpu")
+        for i, (k, v) in enumerate(b.views.items()):
+            v.fill_(float(rank + 1) * (i + 1))
+        b.allreduce_mean()
+        mean_rank = sum(r + 1 for r in range(world)) / world
+        ok = all(torch.allclose(v, torch.full_like(v, mean_rank * (i + 1))) for i, (k, v) in enumerate(b.views.items()))
+        ok = ok and b.views["a/W"].shape == (3, 3, 4, 8) and b.offsets["a/b"] % 4 == 0 and b.offsets["c/beta"] % 4 == 0
+        ok = ok and b.views["a/b"].data_ptr() == b.flat.data_ptr() + 4 * b.offsets["a/b"]       # views alias the flat buffer
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_grad_bucket_allreduce_mean(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def test_grad_bucket_without_process_group_is_a_noop():
+    b = vd.GradBucket({"x": (2, 3)}, "cpu")
+    b.views["x"].fill_(2.0)
+    assert b.allreduce_mean() is None and float(b.flat[:6].sum()) == 12.0
