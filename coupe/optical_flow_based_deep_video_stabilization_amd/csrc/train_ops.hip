@@ -168,7 +168,20 @@ __global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(const float *__restr
     float s0 = 0.f, s1 = 0.f;
     if (c < C) {
         const float bt = beta[c];
-        for (long long r = r0 + wave; r < r1; r += 4) {
+        long long r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {                               // four rows in flight per wave (HBM-bound pass)
+            float yy[4], dy[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { yy[u] = y[(r + 4 * u) * cs_y + cy_off + c]; dy[u] = dyp[(r + 4 * u) * cs_g + cg_off + c]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float g = yy[u] > 0.f ? dy[u] : 0.1f * dy[u];
+                const float xhat = (yy[u] > 0.f ? yy[u] : yy[u] / 0.1f) - bt;
+                s0 += g;
+                s1 += g * xhat;
+            }
+        }
+        for (; r < r1; r += 4) {
             const float yy = y[r * cs_y + cy_off + c], dy = dyp[r * cs_g + cg_off + c];
             const float g = yy > 0.f ? dy : 0.1f * dy;
             const float xhat = (yy > 0.f ? yy : yy / 0.1f) - bt;
@@ -196,11 +209,21 @@ __global__ __launch_bounds__(256) void bn_moments_kernel(const float *__restrict
     const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     double s0 = 0.0, s1 = 0.0;
     if (c < C)
-        for (long long r = r0 + wave; r < r1; r += 4) {
+    {
+        long long r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {                               // four rows in flight per wave (HBM-bound pass)
+            float x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = z[(r + 4 * u) * cs + c_off + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s0 += (double)x[u]; s1 += (double)x[u] * (double)x[u]; }
+        }
+        for (; r < r1; r += 4) {
             const double x = (double)z[r * cs + c_off + c];
             s0 += x;
             s1 += x * x;
         }
+    }
     red[0][wave][threadIdx.x & 63] = s0;
     red[1][wave][threadIdx.x & 63] = s1;
     __syncthreads();

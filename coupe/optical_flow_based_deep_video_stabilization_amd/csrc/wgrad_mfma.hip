@@ -203,8 +203,12 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const float *__restrict
     float s0 = 0.f, s1 = 0.f;
     if (c < C) {
         long long r = r0 + wave;
-        for (; r + 4 < r1; r += 8) { s0 += g[r * Cs + c_off + c]; s1 += g[(r + 4) * Cs + c_off + c]; }
-        if (r < r1) s0 += g[r * Cs + c_off + c];
+        for (; r + 12 < r1; r += 16) {                               // four rows in flight per wave
+            const float v0 = g[r * Cs + c_off + c], v1 = g[(r + 4) * Cs + c_off + c];
+            const float v2 = g[(r + 8) * Cs + c_off + c], v3 = g[(r + 12) * Cs + c_off + c];
+            s0 += v0; s1 += v1; s0 += v2; s1 += v3;
+        }
+        for (; r < r1; r += 4) s0 += g[r * Cs + c_off + c];
     }
     red[wave][threadIdx.x & 63] = s0 + s1;
     __syncthreads();
