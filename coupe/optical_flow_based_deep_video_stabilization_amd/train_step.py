@@ -42,6 +42,12 @@ DEC = (("deconv5", "conv6_1", 1024, "concat5", 512, 512, "predict6", "upsample6_
 PRED_IN = {"predict6": ("conv6_1", 1024), "predict5": ("concat5", 1026), "predict4": ("concat4", 770), "predict3": ("concat3", 386),
            "predict2": ("concat2", 194)}
 BN_DECAY, BN_EPS = 0.9, 1e-5        # TensorLayer BatchNormLayer defaults
+LR_INIT, LR_DECAY, DECAY_EVERY, BETA1 = 1e-4, 0.8, 20, 0.9     # config.py:19-25 (config.TRAIN.*)
+
+
+def learning_rate(epoch: int, lr_init: float = LR_INIT, lr_decay: float = LR_DECAY, decay_every: int = DECAY_EVERY) -> float:
+    """The reference's step schedule (main:389-393): lr_init * lr_decay ** (epoch // decay_every)."""
+    return lr_init * lr_decay ** (epoch // decay_every)
 
 
 def _pad_to(t: torch.Tensor, shape) -> torch.Tensor:
@@ -337,6 +343,21 @@ class Trainer:
         self.sbucket.allreduce_mean(group)
         for k, v in self.sbucket.views.items():
             self.p[k].copy_(v)
+
+    def save_npz(self, path: str, outer: str = "main_net", scope: str = "flownetS"):
+        """tl.files.save_npz_dict(save_vars, ...) (main:424-426): every variable under main_net -- weights, biases, betas AND
+        the BatchNorm moving statistics -- under the reference's key names, loadable by `load_and_assign_npz_dict`."""
+        from . import weights as wts
+        wts.save_npz_dict(path, self.export(), outer, scope)
+
+    def train_epoch(self, batches, epoch: int = 0, group=None):
+        """The inner loop of main:386-430 over an iterable of (feats, gtstab, unstab) CUDA batches with the epoch's learning
+        rate; returns the list of per-step losses (host floats, synchronising once at the end).  Note: the reference evaluates
+        `loss_main` with a SECOND training-mode forward after the update (main:409-411), which also advances its BatchNorm
+        moving averages twice per iteration; here the loss is the one the update was computed from."""
+        lr = learning_rate(epoch)
+        losses = [self.step(f, g, u, lr, BETA1, group) for f, g, u in batches]
+        return [float(l) for l in losses]
 
     def step(self, feats, gtstab, unstab, lr: float, beta1: float = 0.9, group=None):
         """One optimiser step; returns this rank's loss_main evaluated before the update (what
