@@ -16,6 +16,8 @@ Prints ONE JSON line on rank 0 (see the keys below); a per-layer table goes to s
 import argparse
 import json
 import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (what RCCL needs on this driver); before any HIP init
 import sys
 import time
 
@@ -114,7 +116,6 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import coupe.optical_flow_based_deep_video_stabilization_amd as vs

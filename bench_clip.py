@@ -13,6 +13,8 @@ the clip is fixed, ranks split it.
 import argparse
 import json
 import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (what RCCL needs on this driver); before any HIP init
 import sys
 import time
 
@@ -40,7 +42,6 @@ def main():
     use_dist = world > 1 or os.environ.get("VSTAB_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 

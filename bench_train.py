@@ -9,6 +9,8 @@ FLOP accounting: forward = netspec's 2*MACs; backward = input gradient + weight 
 import argparse
 import json
 import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (what RCCL needs on this driver); before any HIP init
 import sys
 import time
 
@@ -36,7 +38,6 @@ def main():
     use_dist = world > 1 or os.environ.get("VSTAB_FORCE_DIST") == "1"      # data-parallel replicas, gradients averaged over RCCL
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from coupe.optical_flow_based_deep_video_stabilization_amd import netspec, train_step, weights as wts
