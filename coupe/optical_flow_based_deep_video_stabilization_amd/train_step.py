@@ -271,10 +271,17 @@ class Trainer:
         self._backward()
 
     def _zero_grads(self):
-        for G in self.G.values():
-            G.zero_()
+        # the activation gradients are NOT cleared: the first gradient written into each buffer in _backward covers all of its
+        # channels and overwrites (self._fresh tracks that), later contributions accumulate
+        self._fresh = set(self.G.keys())
         for d in self.dpf.values():
             d.zero_()
+
+    def _acc(self, name) -> bool:
+        """False for the first write into activation gradient `name` of this backward pass (overwrite), True afterwards."""
+        first = name in self._fresh
+        self._fresh.discard(name)
+        return not first
 
     def _backward(self):
         a, p, g, G = self.a, self.p, self.g, self.G
@@ -290,7 +297,7 @@ class Trainer:
         g["predict2/W_conv2d"].zero_()
         g["predict2/W_conv2d"][..., :2].copy_(dWT[0, 0, :, :18].reshape(196, 3, 3, 2).permute(1, 2, 0, 3))
         WTt = self.WT[0, 0].t().contiguous().view(1, 1, 32, 196)
-        self._conv_fwd(self.dT, 0, 32, WTt, None, 1, 1, 0, G["concat2"], 0, 196, act=3)
+        self._conv_fwd(self.dT, 0, 32, WTt, None, 1, 1, 0, G["concat2"], 0, 196, act=3 if self._acc("concat2") else 0)
         # decoder levels, fine to coarse
         levels = ["predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3"]
         for i in range(3, -1, -1):
@@ -301,7 +308,7 @@ class Trainer:
             self._bn_bwd(f"{dname}_bn", a[ob], G[ob], ooff, cout)
             self._wgrad(G[ob], ooff, cout, a[ib], 0, cs_in, 4, 2, 1, g[f"{dname}/W_deconv2d"], None)
             g[f"{dname}/b_deconv2d"].zero_()          # a bias in front of BatchNorm: sum of dz = 0 exactly (sum of xhat = 0)
-            self._conv_fwd(G[ob], ooff, cout, p[f"{dname}/W_deconv2d"], None, 4, 2, 1, G[ib], 0, cs_in, act=3)
+            self._conv_fwd(G[ob], ooff, cout, p[f"{dname}/W_deconv2d"], None, 4, 2, 1, G[ib], 0, cs_in, act=3 if self._acc(ib) else 0)
             # upsample_flowN: its input is this level's flow
             self._wgrad(G[ob], foff, 4, self.pf[level], 0, 4, 4, 2, 1, g[f"{uname}/W_deconv2d"], None)
             self._colsum(G[ob], foff, 4, g[f"{uname}/b_deconv2d"])
@@ -311,7 +318,7 @@ class Trainer:
                 self._resize_bwd(self.dpf[level], self.dpf[levels[i - 1]], 2.0)
             pin, _ = PRED_IN[pname]
             self._wgrad(a[pin], 0, a[pin].shape[3], self.dpf[level], 0, 4, 3, 1, 1, g[f"{pname}/W_conv2d"], g[f"{pname}/b_conv2d"])
-            self._convT(self.dpf[level], 0, 4, p[f"{pname}/W_conv2d"], None, 3, 1, 1, G[pin], 0, a[pin].shape[3], True)
+            self._convT(self.dpf[level], 0, 4, p[f"{pname}/W_conv2d"], None, 3, 1, 1, G[pin], 0, a[pin].shape[3], self._acc(pin))
         # encoder, last stage first
         for name, k, s, pad, cout in reversed(ENC):
             ib, ioff, cin = ENC_IN[name]
@@ -320,7 +327,7 @@ class Trainer:
             self._wgrad(a[ib], ioff, cin, G[ob], ooff, cout, k, s, pad, g[f"{name}/W_conv2d"], None)
             g[f"{name}/b_conv2d"].zero_()               # same: the batch mean removes the bias, its gradient is exactly zero
             if ib != "x0":
-                self._convT(G[ob], ooff, cout, p[f"{name}/W_conv2d"], None, k, s, pad, G[ib], ioff, cin, True)
+                self._convT(G[ob], ooff, cout, p[f"{name}/W_conv2d"], None, k, s, pad, G[ib], ioff, cin, self._acc(ib))
 
     # ------------------------------------------------------------------ Adam (main:333-335)
     def adam(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
