@@ -61,12 +61,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int z = blockIdx.z;
+    unsigned bx_, by_, bz_;
+    xcd_remap(bx_, by_, bz_);                       // each XCD works on a contiguous band of tiles (shared halos stay in its L2)
+    const int z = (int)bz_;
     const int phase = z / p.ksplit, split = z - phase * p.ksplit;
     const ConvPhase ph = p.ph[phase];
-    const int m0 = blockIdx.x * BM;
+    const int m0 = (int)bx_ * BM;
     if (m0 >= ph.M) return;                       // uniform for the whole workgroup
-    const int n0 = blockIdx.y * BN;
+    const int n0 = (int)by_ * BN;
 
     // ---- per-row gather table: {input element offset, iy0, q_lo, q_hi} and output offset
     for (int r = tid; r < BM; r += 256) {

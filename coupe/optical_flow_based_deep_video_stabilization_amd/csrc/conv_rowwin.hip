@@ -42,7 +42,11 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                // 2x2 waves, wave tile 64 (pixels) x 32 (channels)
     const int li = lane & 31, lh = lane >> 5;
-    const int ox0 = blockIdx.x * 128, oy = blockIdx.y, n = blockIdx.z;
+    // XCD-aware order: grid = (row, x tile, sample) so that a remapped XCD range is a band of consecutive output rows, whose
+    // 7-row input windows overlap by five rows
+    unsigned bx_, by_, bz_;
+    xcd_remap(bx_, by_, bz_);
+    const int oy = (int)bx_, ox0 = (int)by_ * 128, n = (int)bz_;
     const int pix_step = p.s_in * p.Cs_in;
     const int row_floats = p.Wi * p.Cs_in;
     const int g0 = pix_step * ox0 + p.e_off - p.w_a;       // window start, floats from the row start (multiple of 4)
@@ -184,7 +188,7 @@ hipError_t rowwin_set_attributes()
 hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (!rowwin_applicable(p)) return hipErrorInvalidValue;
-    dim3 grid((p.Wo + 127) / 128, p.Ho, p.B), block(256);
+    dim3 grid(p.Ho, (p.Wo + 127) / 128, p.B), block(256);       // (row, x tile, sample): see the XCD remap in the kernel
     if (ev_start && ev_stop)      // timestamps of the kernel's own dispatch packet, no marker packets (see conv_mfma.hip)
         hipExtLaunchKernelGGL(conv_rowwin_kernel<7>, grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, p);
     else

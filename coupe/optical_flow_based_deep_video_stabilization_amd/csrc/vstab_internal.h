@@ -9,6 +9,32 @@ namespace vstab {
 inline int round_up_c(int a, int b) { return (a + b - 1) / b * b; }
 
 // ---------------------------------------------------------------------------------
+// XCD-aware workgroup -> tile mapping (device side).  The dispatcher deals workgroups round-robin over the 8 XCDs (each with
+// a private 4 MiB L2), so neighbouring tiles -- which share input halo rows, whole A tiles (column blocks of one row tile) or
+// whole operand panels -- would land on different L2s and every one of them would fetch its operands from HBM again.  The
+// remap hands each XCD a CONTIGUOUS range of a linear tile order (y fastest, then z, then x -- the column blocks and the
+// transposed-conv phases of one row tile stay together, then come its neighbours): linear id l -> label l % 8 (which
+// workgroups share an XCD) -> that label's range.  Bijective for any grid size (cdna_hip_programming.md T1); a speed tool only,
+// nothing depends on the placement being as observed.
+// ---------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ void xcd_remap(unsigned &bx, unsigned &by, unsigned &bz)
+{
+    const unsigned Nx = gridDim.x, Ny = gridDim.y, Nz = gridDim.z;
+    const unsigned T = Nx * Ny * Nz;
+    const unsigned lin = blockIdx.x + Nx * (blockIdx.y + Ny * blockIdx.z);
+    const unsigned q = T >> 3, r = T & 7u, c = lin & 7u, idx = lin >> 3;
+    const unsigned nl = (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + idx;
+    // grid.y and grid.z are almost always 1, 2, 4 or 8 here: shifts instead of the ~40-instruction runtime division
+    unsigned t2;
+    if ((Ny & (Ny - 1)) == 0) { const unsigned s = 31u - (unsigned)__builtin_clz(Ny); by = nl & (Ny - 1); t2 = nl >> s; }
+    else { by = nl % Ny; t2 = nl / Ny; }
+    if ((Nz & (Nz - 1)) == 0) { const unsigned s = 31u - (unsigned)__builtin_clz(Nz); bz = t2 & (Nz - 1); bx = t2 >> s; }
+    else { bz = t2 % Nz; bx = t2 / Nz; }
+}
+#endif
+
+// ---------------------------------------------------------------------------------
 // Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
 //
 // GEMM view: rows m = output pixels of one "phase" grid (n, j, i), columns = output

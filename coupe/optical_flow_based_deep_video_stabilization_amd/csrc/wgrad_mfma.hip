@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int split = blockIdx.z;
+    unsigned bx_, by_, bz_;
+    xcd_remap(bx_, by_, bz_);                       // the tiles of one K split (which all read the same pixels) share an XCD
+    const int m0 = (int)bx_ * BM, n0 = (int)by_ * BN;
+    const int split = (int)bz_;
     const int ktiles = (p.K + KT - 1) / KT;
     const int kts = (ktiles + p.ksplit - 1) / p.ksplit;
     const int kt0 = split * kts, kt1 = min(ktiles, kt0 + kts);
