@@ -82,6 +82,7 @@ EXPORTS = {
     "vstab_lrelu_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p]),
     "vstab_flow_medfilt": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "vstab_flow_mean_fill": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
+    "vstab_host_xcd_remap": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int32)]),
     "vstab_level_sizes": (C.c_int, [C.c_int, C.c_int, c_int32_p]),
     "vstab_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_profile_reset": (C.c_int, [C.c_void_p]),

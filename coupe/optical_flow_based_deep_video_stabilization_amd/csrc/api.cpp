@@ -358,6 +358,16 @@ extern "C" void vstab_destroy(vstab_ctx *ctx)
     delete ctx;
 }
 
+extern "C" int vstab_host_xcd_remap(int gx, int gy, int gz, int lin, int32_t *xyz)
+{
+    if (!xyz || gx < 1 || gy < 1 || gz < 1 || lin < 0 || (long long)gx * gy * gz > 0x7fffffffLL || lin >= gx * gy * gz)
+        return fail(nullptr, VSTAB_E_SHAPE, "host_xcd_remap: bad argument");
+    unsigned bx, by, bz;
+    xcd_remap_calc((unsigned)gx, (unsigned)gy, (unsigned)gz, (unsigned)lin, bx, by, bz);
+    xyz[0] = (int32_t)bx; xyz[1] = (int32_t)by; xyz[2] = (int32_t)bz;
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_level_sizes(int H, int W, int32_t *hw20)
 {
     int eh[10], ew[10];

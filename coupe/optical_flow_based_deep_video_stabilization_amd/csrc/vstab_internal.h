@@ -18,11 +18,15 @@ inline int round_up_c(int a, int b) { return (a + b - 1) / b * b; }
 // nothing depends on the placement being as observed.
 // ---------------------------------------------------------------------------------
 #ifdef __HIPCC__
-__device__ __forceinline__ void xcd_remap(unsigned &bx, unsigned &by, unsigned &bz)
+#define VSTAB_HD __host__ __device__
+#else
+#define VSTAB_HD
+#endif
+// the mapping itself (shared with the host-side test hook vstab_host_xcd_remap): dispatch-order id `lin` of a grid Nx x Ny x Nz
+// -> tile coordinates
+VSTAB_HD inline void xcd_remap_calc(unsigned Nx, unsigned Ny, unsigned Nz, unsigned lin, unsigned &bx, unsigned &by, unsigned &bz)
 {
-    const unsigned Nx = gridDim.x, Ny = gridDim.y, Nz = gridDim.z;
     const unsigned T = Nx * Ny * Nz;
-    const unsigned lin = blockIdx.x + Nx * (blockIdx.y + Ny * blockIdx.z);
     const unsigned q = T >> 3, r = T & 7u, c = lin & 7u, idx = lin >> 3;
     const unsigned nl = (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + idx;
     // grid.y and grid.z are almost always 1, 2, 4 or 8 here: shifts instead of the ~40-instruction runtime division
@@ -31,6 +35,11 @@ __device__ __forceinline__ void xcd_remap(unsigned &bx, unsigned &by, unsigned &
     else { by = nl % Ny; t2 = nl / Ny; }
     if ((Nz & (Nz - 1)) == 0) { const unsigned s = 31u - (unsigned)__builtin_clz(Nz); bz = t2 & (Nz - 1); bx = t2 >> s; }
     else { bz = t2 % Nz; bx = t2 / Nz; }
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ void xcd_remap(unsigned &bx, unsigned &by, unsigned &bz)
+{
+    xcd_remap_calc(gridDim.x, gridDim.y, gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), bx, by, bz);
 }
 #endif
 

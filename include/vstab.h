@@ -297,6 +297,9 @@ VSTAB_API int vstab_flow_mean_fill(const float *flow, int B, int h, int w, float
 /* ---- host-only helpers (no GPU needed; used by the CPU tests) --------------------- */
 /* Level sizes of the encoder for an HxW input: hw[2*i], hw[2*i+1] = (h, w) of stage i
  * (10 stages).  Returns 0 or VSTAB_E_SHAPE. */
+/* host-only: the XCD-aware workgroup -> tile map the MFMA kernels apply (dispatch-order id `lin` of a gx x gy x gz grid ->
+ * tile coordinates xyz[3]); exported so that its bijectivity and banding can be tested without a GPU. */
+VSTAB_API int vstab_host_xcd_remap(int gx, int gy, int gz, int lin, int32_t *xyz);
 VSTAB_API int vstab_level_sizes(int H, int W, int32_t *hw20);
 
 /* Host-side view of one conv-like launch of the forward schedule (layer 0-9 = encoder

@@ -54,3 +54,29 @@ def test_errors_without_context():
     assert L.vstab_warp_flow(None, None, None, 1, 4, 4, 3, None) < 0
     assert L.vstab_flow_box_blur(None, 1, 4, 4, 3, None, None, None) < 0
     assert L.vstab_vec2mtrx(None, 1, 8, 4, None, None) < 0
+
+
+@pytest.mark.parametrize("grid", [(256, 1, 1), (256, 2, 1), (64, 4, 8), (1024, 1, 4), (13, 1, 19), (11, 3, 5), (7, 1, 1), (1, 1, 1),
+                                  (256, 2, 16), (384, 2, 1)])
+def test_xcd_remap_is_a_bijection_and_bands_the_tiles(grid):
+    gx, gy, gz = grid
+    T = gx * gy * gz
+    xyz = (C.c_int32 * 3)()
+    seen, per_label = set(), {c: [] for c in range(8)}
+    for lin in range(T):
+        assert L.vstab_host_xcd_remap(gx, gy, gz, lin, xyz) == 0
+        x, y, z = xyz[0], xyz[1], xyz[2]
+        assert 0 <= x < gx and 0 <= y < gy and 0 <= z < gz
+        seen.add((x, y, z))
+        per_label[lin % 8].append(y + gy * (z + gz * x))             # position in the (y, z, x) tile order
+    assert len(seen) == T                                            # bijective for any grid size
+    # workgroups that share an XCD (same lin % 8) get one CONTIGUOUS, ascending range of that order; the ranges tile [0, T)
+    ranges = []
+    for c in range(8):
+        p = per_label[c]
+        if p:
+            assert p == list(range(p[0], p[0] + len(p)))
+            ranges.append((p[0], p[0] + len(p)))
+    ranges.sort()
+    assert ranges[0][0] == 0 and ranges[-1][1] == T and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    assert L.vstab_host_xcd_remap(4, 4, 4, 64, xyz) != 0                # out of range
