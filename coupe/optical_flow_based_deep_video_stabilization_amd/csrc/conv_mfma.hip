@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     unsigned bx_, by_, bz_;
-    xcd_remap(bx_, by_, bz_);                       // each XCD works on a contiguous band of tiles (shared halos stay in its L2)
+    xcd_remap(bx_, by_, bz_, p.no_remap != 0);      // each XCD works on a contiguous band of tiles (shared halos stay in its L2)
     const int z = (int)bz_;
     const int phase = z / p.ksplit, split = z - phase * p.ksplit;
     const ConvPhase ph = p.ph[phase];
@@ -510,9 +510,12 @@ bool conv_uses_lds_dma(ConvTile tile, bool vec4)
     return vec4 && lds_dma_enabled();
 }
 
-hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
+hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
                        bool combine)
 {
+    static const int no_remap = getenv("VSTAB_NO_XCD_REMAP") != nullptr;      // A/B switch for tuning runs
+    ConvParams p = p_in;
+    p.no_remap = no_remap;
     const int BM = tile == TILE_64x128 ? 64 : 128;
     const int BN = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : (tile == TILE_128x64 ? 64 : 32);
     if (p.in_bytes >= 0x80000000u || p.w_bytes >= 0x80000000u) return hipErrorInvalidValue;

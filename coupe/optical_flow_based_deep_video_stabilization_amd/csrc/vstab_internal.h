@@ -37,8 +37,9 @@ VSTAB_HD inline void xcd_remap_calc(unsigned Nx, unsigned Ny, unsigned Nz, unsig
     else { bz = t2 % Nz; bx = t2 / Nz; }
 }
 #ifdef __HIPCC__
-__device__ __forceinline__ void xcd_remap(unsigned &bx, unsigned &by, unsigned &bz)
+__device__ __forceinline__ void xcd_remap(unsigned &bx, unsigned &by, unsigned &bz, bool identity = false)
 {
+    if (identity) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return; }      // A/B switch for tuning runs (VSTAB_NO_XCD_REMAP)
     xcd_remap_calc(gridDim.x, gridDim.y, gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), bx, by, bz);
 }
 #endif
@@ -84,6 +85,7 @@ struct ConvParams {
     int N, Npad;
     int act;                // 0 = none, 1 = leaky relu 0.1 (max(v, 0.1 v)), 2 = relu, 3 = none, ADD to what is in out
     int nphase, ksplit, Mmax;
+    int no_remap;           // tuning switch: keep the dispatch order (VSTAB_NO_XCD_REMAP)
     ConvPhase ph[4];
 };
 
