@@ -21,16 +21,22 @@ def flownetS_pyramid(feats, batch_size, is_train=False, reuse=False, scope='flow
 
     `batch_size` only sized the deconv output_shapes in the reference (model.py:850);
     it must equal feats.shape[0].  `reuse` is accepted and ignored (no variable scopes
-    here).  `is_train=True` is not supported: this is the inference path (BatchNorm uses
-    the moving statistics, folded into the conv weights)."""
-    if is_train:
-        raise NotImplementedError("flownetS_pyramid: only is_train=False (inference) is implemented")
+    here).  `is_train=False` is the inference path (BatchNorm on the moving statistics,
+    folded into the conv weights); `is_train=True` (main:184) runs the training-mode forward
+    of the scope's `train_step.Trainer` -- BatchNorm on batch statistics, moving averages
+    updated -- whose `loss_and_backward` / `adam` / `step` continue from there."""
     if not torch.is_tensor(feats):
         raise TypeError("feats must be a torch tensor")
     if feats.dim() != 4:
         raise ValueError("feats must be [B,H,W,C]")
     if batch_size is not None and int(batch_size) != feats.shape[0]:
         raise ValueError(f"batch_size={batch_size} but feats has batch {feats.shape[0]}")
+    if is_train:
+        from . import train_step
+        tr = train_step.get_trainer(scope, feats.shape[0], feats.shape[1], feats.shape[2])
+        out = {k: v.contiguous() for k, v in tr.forward(feats).items()}
+        out['flow'] = out['predict_flow2']
+        return out
     ctx = runtime.get_context(scope, feats.device.index if feats.is_cuda else None)
     pf6, pf5, pf4, pf3, pf2 = ctx.forward(feats)
     return {'predict_flow6': pf6, 'predict_flow5': pf5, 'predict_flow4': pf4, 'predict_flow3': pf3,

@@ -168,3 +168,7 @@ def reset():
         ctx.close()
     _contexts.clear()
     _pending_weights.clear()
+    import sys
+    ts = sys.modules.get(__package__ + ".train_step")
+    if ts is not None:
+        ts._trainers.clear()

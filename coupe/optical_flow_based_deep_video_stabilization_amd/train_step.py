@@ -375,3 +375,29 @@ class Trainer:
             self.sync_replicas(group)
             self.adam(lr, beta1)
         return loss
+
+
+# ---------------------------------------------------------------------- the training graph behind model.flownetS_pyramid(is_train=True)
+_trainers: Dict[tuple, Trainer] = {}
+
+
+def get_trainer(scope: str, batch: int, height: int, width: int) -> Trainer:
+    """The scope's Trainer for this input shape (main:183-185 builds one training graph per process), created from the weights
+    last assigned to the scope (initialize_global_variables / load_and_assign_npz_dict)."""
+    key = (scope, int(batch), int(height), int(width))
+    tr = _trainers.get(key)
+    if tr is None:
+        w = runtime._pending_weights.get(scope)
+        if w is None:
+            raise RuntimeError(f"no weights assigned to scope '{scope}': call initialize_global_variables() or "
+                               "load_and_assign_npz_dict() first")
+        if int(np.asarray(w["1/W_conv2d"]).shape[2]) != 27:
+            raise ValueError("training is built for the 27-channel input stack of the reference's training graph (main:176-184)")
+        tr = _trainers[key] = Trainer(w, batch, height, width)
+    return tr
+
+
+def sync_to_inference(trainer: Trainer, scope: str = "flownetS"):
+    """Hand the trained variables (weights, betas, moving statistics) to the inference path of `scope` (what
+    `flownetS_pyramid(..., is_train=False, reuse=True)` shares through TF variable scopes, main:185)."""
+    runtime.assign_weights(trainer.export(), scope)        # re-folds BatchNorm and re-packs in every live context of the scope

@@ -68,7 +68,9 @@ def test_no_cpu_fallback_without_gpu():
 
 def test_is_train_and_batch_size_errors():
     import coupe.optical_flow_based_deep_video_stabilization_amd as vs
-    with pytest.raises(NotImplementedError):
+    from coupe.optical_flow_based_deep_video_stabilization_amd import runtime
+    runtime.reset()
+    with pytest.raises(RuntimeError):                      # the training graph needs variables first (and a GPU: no CPU path)
         vs.flownetS_pyramid(torch.zeros(1, 64, 64, 27), 1, is_train=True)
     with pytest.raises(ValueError):
         vs.flownetS_pyramid(torch.zeros(2, 64, 64, 27), 1)
