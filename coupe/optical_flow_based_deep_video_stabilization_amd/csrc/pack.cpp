@@ -207,4 +207,17 @@ void pack_index_dgrad_s2(int k, int pad, int cin, int cout, int cs_g, const KLay
         }
 }
 
+// One output-parity phase of that transposed conv with EXACTLY its taps: nty x ntx taps, row tap tt <-> ky = t0y + 2 (nty-1-tt),
+// column tap bx <-> kx = t0x + 2 (ntx-1-bx) (increasing input row / column); L = klayout_run/tap(nty, ntx, ...).
+void pack_index_phase(int k, int cin, int cout, int cs_g, const KLayout &L, int npad, int t0y, int nty, int t0x, int ntx, int32_t *tbl)
+{
+    pack_index_generic(L, cs_g, cout, ntx, cin, npad,
+                       [&](int tt, int bx, int co, int n) -> long long {
+                           const int ky = t0y + 2 * (nty - 1 - tt), kx = t0x + 2 * (ntx - 1 - bx);
+                           if (ky >= k || kx >= k) return -1;
+                           return (long long)(((size_t)ky * k + kx) * cin + n) * cout + co;
+                       },
+                       tbl);
+}
+
 }  // namespace vstab

@@ -75,6 +75,14 @@ struct DgradPlan {
     bool vec4;
     size_t packed_floats;       // all phases
     int32_t *tbl;               // device index table, owned by the cache
+    // odd-k stride-2 input gradients: the four output-parity phases have DIFFERENT tap counts ((k+1)/2 or (k-1)/2 per axis), so each
+    // is its own launch with exactly its taps instead of one 4-phase launch padded to ceil(k/2)^2 (44 % / 31 % of the MACs of a
+    // 3x3 / 5x5 layer were zero taps).  nsub == 0: the single launch `p` is the whole plan.
+    int nsub;
+    ConvParams sp[4];
+    ConvTile stile[4];
+    size_t soff[4];             // float offset of each phase's operand inside the packed buffer / the table
+    size_t part_floats;         // split-K slab space (max over the launches)
 };
 
 // geometry -> plan + device index table (built once: the host packer's gather, replayed on the GPU every call because the
@@ -100,6 +108,47 @@ bool dgrad_plan(int B, int Ho, int Wo, int cs_g, int cout, int k, int stride, in
         d.packed_floats = (size_t)L.ktiles() * p.Npad * 32;
         tbl.resize(d.packed_floats);
         pack_index_dgrad_s1(k, cin, cout, cs_g, L, p.Npad, tbl.data());
+    } else if (k & 1) {
+        // one launch per output-parity phase, each with exactly its taps: row taps ky = t0y + 2u (u < nty), input row j + c - u
+        if (cs_g & 3) return false;
+        const int BN = cin >= 128 ? 128 : (cin > 32 ? 64 : 32);
+        const ConvTile base = cin >= 128 ? TILE_128x128 : (cin > 32 ? TILE_128x64 : TILE_128x32);
+        const int npad = (cin + BN - 1) / BN * BN;
+        d.vec4 = true;
+        d.packed_floats = 0;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                const int t0y = (py + pad) & 1, t0x = (px + pad) & 1;
+                const int nty = (k - t0y + 1) / 2, ntx = (k - t0x + 1) / 2;
+                const int Hg = (Hi - py + 1) / 2, Wg = (Wi - px + 1) / 2;
+                if (Hg < 1 || Wg < 1 || nty < 1 || ntx < 1) continue;
+                ConvParams &q = d.sp[d.nsub];
+                std::memset(&q, 0, sizeof q);
+                q.B = B; q.Hi = Ho; q.Wi = Wo; q.Cs_in = cs_g;
+                const KLayout L = cs_g == cout ? klayout_run(nty, ntx, cs_g) : klayout_tap(nty, ntx, cout, cs_g);
+                set_layout(q, L);
+                if (q.SEG & 3) return false;
+                q.s_in = 1; q.s_out = 2; q.Ho = Hi; q.Wo = Wi; q.Cs_out = cs_x; q.c_off = cx_off;
+                q.N = cin; q.Npad = npad; q.act = act; q.nphase = 1;
+                ConvPhase &ph = q.ph[0];
+                ph.Hg = Hg; ph.Wg = Wg; ph.M = B * Hg * Wg;
+                ph.off_y = (py + pad - t0y) / 2 - nty + 1; ph.off_x = (px + pad - t0x) / 2 - ntx + 1;
+                ph.o_y = py; ph.o_x = px; ph.w_off = 0;
+                q.Mmax = ph.M;
+                set_ranges(q);
+                d.stile[d.nsub] = choose_tile_split(q, base, true);
+                d.soff[d.nsub] = d.packed_floats;
+                const size_t pf = (size_t)L.ktiles() * npad * 32;
+                tbl.resize(d.packed_floats + pf);
+                // row tap tt <-> ky = t0y + 2 (nty-1-tt): increasing input row; GEMM columns n = ci, reduction channel = co
+                pack_index_phase(k, cin, cout, cs_g, L, npad, t0y, nty, t0x, ntx, tbl.data() + d.packed_floats);
+                d.packed_floats += pf;
+                if (q.ksplit > 1) d.part_floats = std::max(d.part_floats, (size_t)q.ksplit * q.Mmax * q.Npad);
+                ++d.nsub;
+            }
+        if (d.nsub == 0) return false;
+        d.p = d.sp[0];
+        d.tile = d.stile[0];
     } else {
         const int kt2 = (k + 1) / 2;
         std::memset(&p, 0, sizeof p);
@@ -133,6 +182,7 @@ bool dgrad_plan(int B, int Ho, int Wo, int cs_g, int cout, int k, int stride, in
         tbl.resize(d.packed_floats);
         pack_index_dgrad_s2(k, pad, cin, cout, cs_g, L, p.Npad, tbl.data());
     }
+    if (d.nsub == 0 && d.p.ksplit > 1) d.part_floats = (size_t)d.p.nphase * d.p.ksplit * d.p.Mmax * d.p.Npad;
     if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;
     if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d.tbl); return false; }
     cache[key] = d;
@@ -147,7 +197,7 @@ size_t dgrad_ws(const DgradPlan &d, size_t *bias_off, size_t *part_off)
     *bias_off = off;
     off += ((size_t)p.Npad * sizeof(float) + 255) / 256 * 256;
     *part_off = off;
-    if (p.ksplit > 1) off += ((size_t)p.nphase * p.ksplit * p.Mmax * p.Npad * sizeof(float) + 255) / 256 * 256;
+    off += (d.part_floats * sizeof(float) + 255) / 256 * 256;
     return off + 256;
 }
 }  // namespace
@@ -197,12 +247,15 @@ extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs
     HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
     HIP_TRY(nullptr, hipMemsetAsync(bias, 0, (size_t)d.p.Npad * sizeof(float), st));
     if (bias_in) HIP_TRY(nullptr, hipMemcpyAsync(bias, bias_in, (size_t)cin * sizeof(float), hipMemcpyDeviceToDevice, st));
-    ConvParams p = d.p;
-    p.in = gout + cg_off;
-    p.in_bytes = (unsigned)((long long)B * Ho * Wo * cs_g * 4 - (long long)cg_off * 4);
-    p.wpk = wpk; p.bias = bias; p.out = dx;
-    p.partial = reinterpret_cast<float *>(ws + part_off);
-    HIP_TRY(nullptr, launch_conv(p, d.tile, d.vec4, st));
+    const int nl = d.nsub ? d.nsub : 1;
+    for (int s = 0; s < nl; ++s) {
+        ConvParams p = d.nsub ? d.sp[s] : d.p;
+        p.in = gout + cg_off;
+        p.in_bytes = (unsigned)((long long)B * Ho * Wo * cs_g * 4 - (long long)cg_off * 4);
+        p.wpk = wpk + (d.nsub ? d.soff[s] : 0); p.bias = bias; p.out = dx;
+        p.partial = reinterpret_cast<float *>(ws + part_off);
+        HIP_TRY(nullptr, launch_conv(p, d.nsub ? d.stile[s] : d.tile, d.vec4, st));
+    }
     return VSTAB_OK;
 }
 
@@ -275,6 +328,7 @@ bool fwd_plan(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int p
     }
     const KLayout L{d.p.KH, d.p.NSEG, d.p.SEG, d.p.SEGP, d.p.SEG_STRIDE};
     d.packed_floats = (size_t)L.ktiles() * d.p.Npad * 32;
+    if (d.p.ksplit > 1) d.part_floats = (size_t)d.p.nphase * d.p.ksplit * d.p.Mmax * d.p.Npad;
     std::vector<int32_t> tbl(d.packed_floats);
     pack_index_conv(k, k, cin, cs_x, cout, d.p.Npad, L, tbl.data());
     if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;

@@ -287,6 +287,7 @@ hipError_t launch_adam(float *w, const float *g, float *m, float *v, long long n
 void pack_index_conv(int kh, int kw, int cin, int cs_in, int cout, int npad, const KLayout &L, int32_t *tbl);
 void pack_index_dgrad_s1(int k, int cin, int cout, int cs_g, const KLayout &L, int npad, int32_t *tbl);
 void pack_index_dgrad_s2(int k, int pad, int cin, int cout, int cs_g, const KLayout &L, int npad, int32_t *tbl);   // 4 phases of ceil(k/2)^2 taps
+void pack_index_phase(int k, int cin, int cout, int cs_g, const KLayout &L, int npad, int t0y, int nty, int t0x, int ntx, int32_t *tbl);
 // wpk[i] = tbl[i] ? W[tbl[i]-1] : 0
 hipError_t launch_pack_apply(const float *W, const int32_t *tbl, long long n, float *wpk, hipStream_t stream);
 
