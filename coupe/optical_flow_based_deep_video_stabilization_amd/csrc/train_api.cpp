@@ -69,6 +69,23 @@ extern "C" int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x,
 
 // ------------------------------------------------------------------------- input gradient of a convolution
 namespace {
+// a zero vector every bias-less GEMM can point at (instead of a memset in front of each launch); one per device, never freed
+const float *zero_bias()
+{
+    static std::mutex mu;
+    static std::map<int, float *> buf;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = buf.find(dev);
+    if (it != buf.end()) return it->second;
+    float *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), 8192 * sizeof(float)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 8192 * sizeof(float)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    buf[dev] = p;
+    return p;
+}
+
 struct DgradPlan {
     ConvParams p;
     ConvTile tile;
@@ -245,8 +262,14 @@ extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs
     float *wpk = reinterpret_cast<float *>(ws);
     float *bias = reinterpret_cast<float *>(ws + bias_off);
     HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
-    HIP_TRY(nullptr, hipMemsetAsync(bias, 0, (size_t)d.p.Npad * sizeof(float), st));
-    if (bias_in) HIP_TRY(nullptr, hipMemcpyAsync(bias, bias_in, (size_t)cin * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // the bias vector the kernel reads has Npad entries: a shared zero vector when there is none, the caller's own when it is
+    // already that long, a padded copy otherwise
+    if (!bias_in && d.p.Npad <= 8192 && zero_bias()) bias = const_cast<float *>(zero_bias());
+    else if (bias_in && cin == d.p.Npad) bias = const_cast<float *>(bias_in);
+    else {
+        HIP_TRY(nullptr, hipMemsetAsync(bias, 0, (size_t)d.p.Npad * sizeof(float), st));
+        if (bias_in) HIP_TRY(nullptr, hipMemcpyAsync(bias, bias_in, (size_t)cin * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     const int nl = d.nsub ? d.nsub : 1;
     for (int s = 0; s < nl; ++s) {
         ConvParams p = d.nsub ? d.sp[s] : d.p;
@@ -370,8 +393,12 @@ extern "C" int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_
     float *wpk = reinterpret_cast<float *>(ws);
     float *bias = reinterpret_cast<float *>(ws + bias_off);
     HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
-    HIP_TRY(nullptr, hipMemsetAsync(bias, 0, (size_t)d.p.Npad * sizeof(float), st));
-    if (bias_in) HIP_TRY(nullptr, hipMemcpyAsync(bias, bias_in, (size_t)cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (!bias_in && d.p.Npad <= 8192 && zero_bias()) bias = const_cast<float *>(zero_bias());
+    else if (bias_in && cout == d.p.Npad) bias = const_cast<float *>(bias_in);
+    else {
+        HIP_TRY(nullptr, hipMemsetAsync(bias, 0, (size_t)d.p.Npad * sizeof(float), st));
+        if (bias_in) HIP_TRY(nullptr, hipMemcpyAsync(bias, bias_in, (size_t)cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     ConvParams p = d.p;
     p.in = x + cx_off;
     p.in_bytes = (unsigned)((long long)B * Hi * Wi * cs_x * 4 - (long long)cx_off * 4);
