@@ -87,6 +87,7 @@ EXPORTS = {
     "vstab_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_profile_reset": (C.c_int, [C.c_void_p]),
     "vstab_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "vstab_profile_read_direct": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "vstab_profile_kernel_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "vstab_host_layer_plan": (C.c_int, [C.c_int] * 5 + [c_int32_p, C.c_int]),
     "vstab_host_pack_layer": (C.c_longlong, [C.c_int, C.c_int, c_float_p, C.POINTER(C.c_double), c_float_p,

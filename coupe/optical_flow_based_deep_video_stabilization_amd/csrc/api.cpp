@@ -41,9 +41,9 @@ const int PRED_CIN[4] = {1024, 1026, 770, 386};             // predict6,5,4,3
 const int PRED_CS[4] = {1024, 1028, 772, 388};
 
 enum Buf { B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV4, B_CONCAT4, B_CONV5, B_CONCAT5, B_CONV6, B_CONV6_1, B_T,
-           B_T6, B_T5, B_T4, B_T3, B_PARTIAL, N_BUF };
+           B_T6, B_T5, B_T4, B_T3, B_PARTIAL, B_WINO_V, B_WINO_M, N_BUF };
 const char *BUF_NAME[N_BUF] = {"conv1", "concat2", "conv3", "concat3", "conv4", "concat4", "conv5", "concat5",
-                               "conv6", "conv6_1", "pf2_taps", "pf6_taps", "pf5_taps", "pf4_taps", "pf3_taps", "splitk"};
+                               "conv6", "conv6_1", "pf2_taps", "pf6_taps", "pf5_taps", "pf4_taps", "pf3_taps", "splitk", "winograd_in", "winograd_out"};
 
 // where each encoder stage reads and writes: {in buf (-1 = feats), out buf, out stride, used in channels, in stride}
 struct EncIO { int in_buf, out_buf, cs_out, cs_in; };
@@ -64,6 +64,10 @@ struct Plan {
     ConvParams cp[19];
     ConvTile tile[19];
     bool vec4[19];
+    // Winograd F(2x2,3x3) form of the 3x3 stride-1 encoder stages (cp[i] stays the direct form: host-plan tests, fallback)
+    bool wino[10];
+    ConvParams wcp[10];
+    ConvTile wtile[10];
 };
 
 bool level_sizes(int H, int W, int *eh, int *ew)
@@ -201,6 +205,8 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
     setbuf(B_T4, pl.eh[5], pl.ew[5], 32, 32);
     setbuf(B_T3, pl.eh[3], pl.ew[3], 32, 32);
     setbuf(B_PARTIAL, 0, 0, 0, 0);
+    setbuf(B_WINO_V, 0, 0, 0, 0);
+    setbuf(B_WINO_M, 0, 0, 0, 0);
     for (int b = 0; b < N_BUF; ++b) {
         const long long n = (long long)B * pl.buf_h[b] * pl.buf_w[b] * pl.buf_cs[b];
         if (n > lim) return false;
@@ -232,6 +238,45 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         pl.tile[i] = choose_tile_split(p, pl.tile[i], pl.vec4[i]);
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
     }
+    // ---- Winograd form of the 3x3 stride-1 stages: a 16-phase 1x1 GEMM over the transformed tiles (winograd_ops.hip)
+    static const bool wino_on = getenv("VSTAB_NO_WINOGRAD") == nullptr;
+    size_t wino_v = 0, wino_m = 0;
+    for (int i = 0; i < 10; ++i) {
+        pl.wino[i] = false;
+        const Enc &e = ENC[i];
+        if (!wino_on || e.k != 3 || e.s != 1 || e.p != 1) continue;
+        const int cin_i = ENC[i - 1].cout;
+        if (ENC_IO[i].cs_in != cin_i || (cin_i & 31) || (e.cout & 127)) continue;      // plain input buffer, whole K tiles
+        const int TH = (pl.eh[i] + 1) / 2, TW = (pl.ew[i] + 1) / 2;
+        const long long vfl = (long long)B * 16 * TH * TW * cin_i, mfl = (long long)B * 16 * TH * TW * e.cout;
+        if (vfl * 4 >= 0x80000000LL || mfl * 4 >= 0x80000000LL) continue;
+        // two extra HBM passes and two more launches: pays once the Winograd-domain GEMM issues a few GFLOP (measured: B=8 512x512
+        // every stage gains, 20..96 us; B=1 384x512 (1.6 GFLOP per stage) loses 2..5 %)
+        if (32.0 * B * TH * TW * cin_i * e.cout < 3.0e9) continue;
+        ConvParams &p = pl.wcp[i];
+        std::memset(&p, 0, sizeof p);
+        p.B = B; p.Hi = 16 * TH; p.Wi = TW; p.Cs_in = cin_i;
+        const KLayout L = klayout_run(1, 1, cin_i);
+        set_layout(p, L);
+        p.s_in = 1; p.s_out = 1; p.Ho = 16 * TH; p.Wo = TW; p.Cs_out = e.cout; p.c_off = 0;
+        p.N = e.cout; p.Npad = e.cout; p.act = 0; p.nphase = 16;
+        const size_t phase_floats = (size_t)L.ktiles() * p.Npad * 32;
+        for (int xi = 0; xi < 16; ++xi) {
+            ConvPhase &ph = p.ph[xi];
+            ph.Hg = TH; ph.Wg = TW; ph.M = B * TH * TW;
+            ph.off_y = xi * TH; ph.off_x = 0; ph.o_y = xi * TH; ph.o_x = 0;
+            ph.w_off = (long long)xi * phase_floats;
+        }
+        p.Mmax = B * TH * TW;
+        set_ranges(p);
+        pl.wtile[i] = choose_tile_split(p, TILE_128x128, true);
+        if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad);
+        wino_v = std::max(wino_v, (size_t)vfl);
+        wino_m = std::max(wino_m, (size_t)mfl);
+        pl.wino[i] = true;
+    }
+    pl.bytes[B_WINO_V] = wino_v * 4;
+    pl.bytes[B_WINO_M] = wino_m * 4;
     // ---- decoder transposed convs: 4 phases of a 2x2-tap conv
     const int dec_in[4] = {B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3};
     const int dec_out[4] = {B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2};
@@ -400,7 +445,7 @@ extern "C" int vstab_workspace_layout(int B, int H, int W, int Cin, vstab_ws_ent
         std::snprintf(e.name, sizeof e.name, "%s", BUF_NAME[b]);
         e.offset_bytes = (int64_t)pl.off[b];
         e.n = B; e.h = pl.buf_h[b]; e.w = pl.buf_w[b]; e.c = pl.buf_c[b]; e.c_stride = pl.buf_cs[b];
-        if (b == B_PARTIAL) { e.n = 1; e.h = 1; e.w = (int32_t)std::min<size_t>(pl.bytes[b] / 4, 0x7fffffff); e.c = 1; e.c_stride = 1; }
+        if (b == B_PARTIAL || b == B_WINO_V || b == B_WINO_M) { e.n = 1; e.h = 1; e.w = (int32_t)std::min<size_t>(pl.bytes[b] / 4, 0x7fffffff); e.c = 1; e.c_stride = 1; }
     }
     return n;
 }
@@ -501,6 +546,10 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
         fold_bn(b->data, beta->data, mean->data, var->data, e.cout, npad, scale.data(), host.data() + ctx->enc_b[i]);
         ctx->enc_w[i] = reserve((size_t)L.ktiles() * npad * 32);
         pack_conv(W->data, scale.data(), e.k, e.k, ci, cs_in, e.cout, npad, L, host.data() + ctx->enc_w[i]);
+        if (e.k == 3 && e.s == 1 && (ci & 31) == 0 && (e.cout & 127) == 0) {      // Winograd-domain operands (16 positions)
+            ctx->wino_w[i] = reserve((size_t)16 * (ci / 32) * e.cout * 32);
+            pack_winograd(W->data, scale.data(), ci, e.cout, e.cout, host.data() + ctx->wino_w[i]);
+        }
         if (i == 0) {
             const int lead = rowwin_lead(-e.p, cin), segp = rowwin_segp(-e.p, e.k, cin);
             ctx->enc0_rw = reserve((size_t)e.k * (segp / 32) * npad * 32);
@@ -546,6 +595,7 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
         ctx->tab_w = reserve((size_t)L.ktiles() * 32 * 32);
         pack_predict2_table(W->data, 194, 196, 32, host.data() + ctx->tab_w);
         ctx->tab_b = reserve(32);
+        ctx->zero_b = reserve(1024);             // zero bias for the Winograd-domain GEMMs (bias is added by the inverse transform)
         ctx->pred2_b = reserve(4);
         host[ctx->pred2_b] = b->data[0]; host[ctx->pred2_b + 1] = b->data[1];
     }
@@ -636,10 +686,14 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         for (int i = 0; i < 15; ++i) {
             const ConvParams &p = pl.cp[i];
             double mac = 0;
-            if (i < 10) mac = (double)p.ph[0].M * ENC[i].k * ENC[i].k * (i == 0 ? Cin : ENC[i - 1].cout) * p.N;
+            if (i < 10 && pl.wino[i]) mac = 16.0 * pl.wcp[i].Mmax * ENC[i - 1].cout * p.N;      // MACs the Winograd-domain GEMM issues (4/9 of direct)
+            else if (i < 10) mac = (double)p.ph[0].M * ENC[i].k * ENC[i].k * (i == 0 ? Cin : ENC[i - 1].cout) * p.N;
             else if (i < 14) mac = (double)B * p.Ho * p.Wo * 4.0 * DEC_CIN[i - 10] * p.N;
             else mac = (double)p.ph[0].M * 194.0 * 18.0;
             ctx->prof_flops[i] += 2.0 * mac;
+            double dmac = mac;                           // the same layer as a direct convolution (SURVEY.md 8d's accounting)
+            if (i < 10 && pl.wino[i]) dmac = (double)p.ph[0].M * 9.0 * ENC[i - 1].cout * p.N;
+            ctx->prof_flops_direct[i] += 2.0 * dmac;
         }
     }
 #define EV_A(slot) (ev ? ev[2 * (slot)] : nullptr)
@@ -665,6 +719,18 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
                 ctx->prof_kernel[0] = "conv_rowwin_kernel<7>";
                 continue;
             }
+        }
+        if (pl.wino[i]) {       // transform, 16-position GEMM on the MFMA kernel, inverse transform (+ bias, leaky relu)
+            ConvParams q = pl.wcp[i];
+            const int cin_i = ENC[i - 1].cout;
+            HIP_TRY(ctx, launch_wino_input(buf(ENC_IO[i].in_buf), B, pl.eh[i], pl.ew[i], ENC_IO[i].cs_in, 0, cin_i, buf(B_WINO_V), stream));
+            q.in = buf(B_WINO_V); q.out = buf(B_WINO_M);
+            q.wpk = dw + ctx->wino_w[i]; q.bias = dw + ctx->zero_b; q.partial = buf(B_PARTIAL);
+            HIP_TRY(ctx, launch_conv(q, pl.wtile[i], true, stream, EV_A(i), EV_B(i)));
+            ctx->prof_kernel[i] = conv_kernel_name(pl.wtile[i], true);
+            HIP_TRY(ctx, launch_wino_output(buf(B_WINO_M), B, pl.eh[i], pl.ew[i], ENC[i].cout, dw + ctx->enc_b[i], 1, buf(ENC_IO[i].out_buf),
+                                            ENC_IO[i].cs_out, 0, stream));
+            continue;
         }
         p.in = ENC_IO[i].in_buf < 0 ? feats : buf(ENC_IO[i].in_buf);
         p.out = buf(ENC_IO[i].out_buf);
@@ -748,6 +814,7 @@ extern "C" int vstab_profile_reset(vstab_ctx *ctx)
     if (!ctx) return fail(nullptr, VSTAB_E_STATE, "profile_reset: ctx is NULL");
     ctx->prof_forwards = 0;
     for (double &f : ctx->prof_flops) f = 0;
+    for (double &f : ctx->prof_flops_direct) f = 0;
     return VSTAB_OK;
 }
 
@@ -762,6 +829,13 @@ extern "C" int vstab_profile_read(vstab_ctx *ctx, double *ms_sum15, double *flop
             ms_sum15[i] += ms;
         }
     *n_forwards = ctx->prof_forwards;
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_profile_read_direct(vstab_ctx *ctx, double *flops15)
+{
+    if (!ctx || !flops15) return fail(ctx, VSTAB_E_STATE, "profile_read_direct: NULL argument");
+    for (int i = 0; i < 15; ++i) flops15[i] = ctx->prof_flops_direct[i];
     return VSTAB_OK;
 }
 

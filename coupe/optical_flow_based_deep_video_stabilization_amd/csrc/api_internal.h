@@ -21,6 +21,8 @@ struct vstab_ctx {
     // float offsets into dev_weights
     size_t enc_w[10], enc_b[10];
     size_t enc0_rw = 0;                  // layer-1 weights in the row-window layout (conv_rowwin.hip)
+    size_t zero_b = 0;                   // 1024 zeros
+    size_t wino_w[10] = {0};             // Winograd-domain operands of the 3x3 stride-1 stages (winograd_ops.hip)
     size_t dec_w[4], dec_b[4];
     size_t pred_w[4], pred_b[4];         // predict6,5,4,3
     size_t tab_w, tab_b, pred2_b;        // predict2 tap table (bias of the table = 0)
@@ -29,7 +31,8 @@ struct vstab_ctx {
     bool prof = false;
     std::vector<hipEvent_t> prof_ev;     // [forward][15][2]
     int prof_forwards = 0;
-    double prof_flops[15] = {0};
+    double prof_flops[15] = {0};         // flops the launches ISSUE (Winograd-form stages: 4/9 of the direct convolution)
+    double prof_flops_direct[15] = {0};  // the same layers counted as direct convolutions
     std::string prof_kernel[15];         // kernel instantiation each slot launched last
     // VGG16 trunk (vstab_vgg16_*)
     void *nldf = nullptr;                // NLDF head state (nldf_api.cpp)

@@ -519,7 +519,7 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
     const int BM = tile == TILE_64x128 ? 64 : 128;
     const int BN = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : (tile == TILE_128x64 ? 64 : 32);
     if (p.in_bytes >= 0x80000000u || p.w_bytes >= 0x80000000u) return hipErrorInvalidValue;
-    if (p.Npad % BN != 0 || p.SEGP % 32 != 0 || p.SEGP < p.SEG || p.NSEG < 1 || p.ksplit < 1 || p.nphase < 1 || p.nphase > 4)
+    if (p.Npad % BN != 0 || p.SEGP % 32 != 0 || p.SEGP < p.SEG || p.NSEG < 1 || p.ksplit < 1 || p.nphase < 1 || p.nphase > 16)
         return hipErrorInvalidValue;
     if (vec4 && ((p.Cs_in & 3) || (p.SEG & 3) || (p.SEG_STRIDE & 3))) return hipErrorInvalidValue;
     if (p.ksplit > 1 && ((p.N & 3) || (p.Cs_out & 3) || (p.c_off & 3) || p.partial == nullptr))

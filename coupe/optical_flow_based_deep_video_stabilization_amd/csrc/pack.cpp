@@ -138,6 +138,24 @@ void pack_deconv5(const float *W, const double *scale, int cin, int cs_in, int c
         }
 }
 
+void pack_winograd(const float *W, const double *scale, int cin, int cout, int npad, float *wpk)
+{
+    static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    const KLayout L = klayout_run(1, 1, cin);
+    const size_t phase_floats = (size_t)L.ktiles() * npad * 32;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            pack_generic(L, cin, cin, 1, cout, npad,
+                         [&](int, int, int ci, int n) {
+                             double u = 0.0;                                   // (G g G^T)[i][j] in double, BatchNorm scale folded in
+                             for (int a = 0; a < 3; ++a)
+                                 for (int b = 0; b < 3; ++b)
+                                     u += G[i][a] * G[j][b] * (double)W[(((size_t)a * 3 + b) * cin + ci) * cout + n];
+                             return (float)(u * scale[n]);
+                         },
+                         wpk + (size_t)(i * 4 + j) * phase_floats);
+}
+
 void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wpk)
 {
     const KLayout L = klayout_run(1, 1, cs_in);

@@ -86,7 +86,7 @@ struct ConvParams {
     int act;                // 0 = none, 1 = leaky relu 0.1 (max(v, 0.1 v)), 2 = relu, 3 = none, ADD to what is in out
     int nphase, ksplit, Mmax;
     int no_remap;           // tuning switch: keep the dispatch order (VSTAB_NO_XCD_REMAP)
-    ConvPhase ph[4];
+    ConvPhase ph[16];       // 4 transposed-conv phases, or the 16 positions of a Winograd-domain GEMM
 };
 
 enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 = 3 };
@@ -128,6 +128,14 @@ inline int rowwin_segp(int off_x, int kw, int cs) { return round_up_c(rowwin_lea
 // Conv weights W[kh][kw][Cin][Cout] -> rowwin packed layout
 void pack_conv_rowwin(const float *W, const double *scale, int kh, int kw, int cin, int cout, int npad,
                       int lead, int segp, float *wpk);
+
+// ---------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) transforms around the MFMA kernel (winograd_ops.hip) and the weight transform + packing:
+// U_xi = (G g G^T)_xi with the BatchNorm scale folded in, 16 blocks of a 1x1-conv operand (klayout_run(1,1,cin)).
+// ---------------------------------------------------------------------------------
+hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_off, int C, float *V, hipStream_t stream);
+hipError_t launch_wino_output(const float *M, int B, int Ho, int Wo, int C, const float *bias, int act, float *out, int Cs_out, int c_off,
+                              hipStream_t stream);
 
 // ---------------------------------------------------------------------------------
 // Small VALU kernels of the flow pyramid and the warp.
@@ -254,6 +262,9 @@ KLayout klayout_deconv(int cs_in);
 // 5x5 stride-2 SAME transposed conv W[5][5][Cout][Cin] (NLDF.py:57-64) -> 4 phase matrices of a 3-row-tap conv
 // in run mode (run = 3*cs_in); the even phases use 2 of the 3 taps (the third gets zero weights).
 void pack_deconv5(const float *W, const double *scale, int cin, int cs_in, int cout, int npad, float *wpk);
+
+// 3x3 conv W[3][3][Cin][Cout] -> 16 Winograd-domain 1x1 operands (position xi = 4 i + j), phase xi starts at xi * ktiles * npad * 32
+void pack_winograd(const float *W, const double *scale, int cin, int cout, int npad, float *wpk);
 
 // predict head W[3][3][Cin][2] -> tap-table weights: 1x1 conv (run mode over cs_in) with 18 (pad npad)
 // output columns, col = tap*2 + o

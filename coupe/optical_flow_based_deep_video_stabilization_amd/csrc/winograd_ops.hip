@@ -1,0 +1,123 @@
+// Winograd F(2x2, 3x3) around the MFMA kernel for the four 3x3 stride-1 stages of the encoder (conv3_1, conv4_1, conv5_1,
+// conv6_1; model.py:818-844): Y = A^T [ (G g G^T) (.) (B^T d B) ] A per 2x2 output tile, summed over the input channels.
+// The element-wise product summed over channels is, for each of the 16 positions xi of the 4x4 transformed tile, a plain
+// GEMM [tiles x Cin] x [Cin x Cout] -- it runs on conv_mfma_kernel as a 16-phase 1x1 convolution (phase = xi) -- and costs
+// 16 * 2 * tiles * Cin * Cout = 4/9 of the direct convolution's multiply-adds.  The two transforms are HBM-bound passes:
+//   wino_input_kernel :  x [B,H,W,Cs] (channels c_off..+C) -> V [B,16,TH,TW,C],   V_xi = (B^T d B)_xi, d = 4x4 patch at
+//                        rows 2ty-1.., columns 2tx-1.. (zero outside the image: the layer's pad 1)
+//   wino_output_kernel:  M [B,16,TH,TW,C] -> out [B,Ho,Wo,Cs_out] (channels c_off..+C), Y = A^T M A + bias, leaky relu
+// One thread per (tile, 4 channels): 16 float4 loads, the transform in registers, 16 (or 4) float4 stores; consecutive
+// threads are consecutive channel quads, so every access is a full 16-byte-per-lane row segment.
+// Same result as the direct convolution up to fp32 rounding (the transforms only add and halve).
+#include <hip/hip_runtime.h>
+
+#include "vstab_internal.h"
+
+namespace vstab {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int H, int W, int Cs, int c_off, int C4,
+                                                         float *__restrict__ V, int TH, int TW)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)TH * TW * C4) return;
+    const int n = blockIdx.y;
+    const int c = (int)(idx % C4);
+    const int tile = (int)(idx / C4);
+    const int ty = tile / TW, tx = tile - ty * TW;
+    const float *xb = x + (long long)n * H * W * Cs + c_off + c * 4;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = 2 * ty - 1 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = 2 * tx - 1 + j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) v = *reinterpret_cast<const f32x4 *>(xb + ((long long)y * W + xx) * Cs);
+            d[i][j] = v;
+        }
+    }
+    // B^T d (rows), then (.) B (columns): B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    f32x4 t[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[0][j] - d[2][j];
+        t[1][j] = d[1][j] + d[2][j];
+        t[2][j] = d[2][j] - d[1][j];
+        t[3][j] = d[1][j] - d[3][j];
+    }
+    float *vb = V + (((long long)n * 16) * TH * TW + tile) * (C4 * 4) + c * 4;
+    const long long xs = (long long)TH * TW * (C4 * 4);                      // stride between the 16 positions
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 0) * xs) = t[i][0] - t[i][2];
+        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 1) * xs) = t[i][1] + t[i][2];
+        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 2) * xs) = t[i][2] - t[i][1];
+        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 3) * xs) = t[i][1] - t[i][3];
+    }
+}
+
+__global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ M, int TH, int TW, int C4, const float *__restrict__ bias,
+                                                          int act, float *__restrict__ out, int Ho, int Wo, int Cs_out, int c_off)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)TH * TW * C4) return;
+    const int n = blockIdx.y;
+    const int c = (int)(idx % C4);
+    const int tile = (int)(idx / C4);
+    const int ty = tile / TW, tx = tile - ty * TW;
+    const float *mb = M + (((long long)n * 16) * TH * TW + tile) * (C4 * 4) + c * 4;
+    const long long xs = (long long)TH * TW * (C4 * 4);
+    f32x4 m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const f32x4 *>(mb + (i * 4 + j) * xs);
+    // A^T m (rows), then (.) A (columns): A^T = [1 1 1 0; 0 1 -1 -1]
+    f32x4 s[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[0][j] = (m[0][j] + m[1][j]) + m[2][j];
+        s[1][j] = (m[1][j] - m[2][j]) - m[3][j];
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + c * 4);
+    const float slope = act == 1 ? 0.1f : 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oy = 2 * ty + a;
+        if (oy >= Ho) continue;
+        f32x4 y0 = ((s[a][0] + s[a][1]) + s[a][2]) + bv;
+        f32x4 y1 = ((s[a][1] - s[a][2]) - s[a][3]) + bv;
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], slope * y0[e]); y1[e] = fmaxf(y1[e], slope * y1[e]); }
+        }
+        float *ob = out + (((long long)n * Ho + oy) * Wo + 2 * tx) * Cs_out + c_off + c * 4;
+        *reinterpret_cast<f32x4 *>(ob) = y0;
+        if (2 * tx + 1 < Wo) *reinterpret_cast<f32x4 *>(ob + Cs_out) = y1;
+    }
+}
+
+hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_off, int C, float *V, hipStream_t stream)
+{
+    if ((C & 3) || (Cs & 3) || (c_off & 3)) return hipErrorInvalidValue;
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    const long long per = (long long)TH * TW * (C / 4);
+    wino_input_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(x, H, W, Cs, c_off, C / 4, V, TH, TW);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino_output(const float *M, int B, int Ho, int Wo, int C, const float *bias, int act, float *out, int Cs_out, int c_off,
+                              hipStream_t stream)
+{
+    if ((C & 3) || (Cs_out & 3) || (c_off & 3)) return hipErrorInvalidValue;
+    const int TH = (Ho + 1) / 2, TW = (Wo + 1) / 2;
+    const long long per = (long long)TH * TW * (C / 4);
+    wino_output_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(M, TH, TW, C / 4, bias, act, out, Ho, Wo,
+                                                                                              Cs_out, c_off);
+    return hipGetLastError();
+}
+
+}  // namespace vstab

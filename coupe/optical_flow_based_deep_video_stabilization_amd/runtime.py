@@ -110,6 +110,13 @@ class Context:
         _lib.check(_lib.lib().vstab_profile_read(self._h, ms, fl, C.byref(n)), self._h)
         return list(ms), list(fl), n.value
 
+    def profile_read_direct(self):
+        """The slots' flops counted as direct convolutions (profile_read gives what the launches issue: Winograd-form stages
+        issue 4/9 of that)."""
+        fl = (C.c_double * 15)()
+        _lib.check(_lib.lib().vstab_profile_read_direct(self._h, fl), self._h)
+        return list(fl)
+
     def profile_kernel_names(self):
         out = []
         for slot in range(15):

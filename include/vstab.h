@@ -111,6 +111,9 @@ VSTAB_API int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B, 
 VSTAB_API int vstab_profile_enable(vstab_ctx *ctx, int enable);
 VSTAB_API int vstab_profile_reset(vstab_ctx *ctx);
 VSTAB_API int vstab_profile_read(vstab_ctx *ctx, double *ms_sum15, double *flops15, int *n_forwards);
+/* vstab_profile_read's flops are what the launches ISSUE: the 3x3 stride-1 encoder stages run in Winograd F(2x2,3x3) form and
+ * issue 4/9 of the direct convolution's multiply-adds.  This returns the same slots counted as direct convolutions. */
+VSTAB_API int vstab_profile_read_direct(vstab_ctx *ctx, double *flops15);
 /* Name (as rocprofv3 prints it) of the kernel instantiation launch slot `slot` used in the last forward. */
 VSTAB_API int vstab_profile_kernel_name(vstab_ctx *ctx, int slot, char *buf, int cap);
 
