@@ -66,6 +66,9 @@ EXPORTS = {
     "vstab_conv_forward_workspace_bytes": (C.c_size_t, [C.c_int] * 14),
     "vstab_conv_forward": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] + [C.c_int] * 6 +
                            [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vstab_conv3x3_winograd_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "vstab_conv3x3_winograd": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p] + [C.c_int] * 3 +
+                               [C.c_void_p, C.c_size_t, C.c_void_p]),
     "vstab_resize_bilinear_backward": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "vstab_pad_nearest_upsample": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vstab_pad_nearest_upsample_backward": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

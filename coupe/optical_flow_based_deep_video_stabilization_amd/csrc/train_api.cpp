@@ -475,3 +475,99 @@ extern "C" int vstab_pf2_taps_backward(const float *g, int cs_g, int B, int H, i
     HIP_TRY(nullptr, launch_pf2_taps_backward(g, cs_g, B, H, W, dT, h2, w2, (hipStream_t)stream));
     return VSTAB_OK;
 }
+
+// ------------------------------------------------------------------------- 3x3 stride-1 conv / its input gradient in Winograd form
+namespace {
+struct WinoPlan {
+    ConvParams p;               // the 16-phase 1x1 GEMM over the transformed tiles
+    size_t phase_floats;        // packed floats per position
+    int32_t *tbl;               // device index table: all 16 positions of the packed operand from Wt [16][K][N]
+    int K, N, TH, TW;
+};
+
+bool wino_plan(int B, int H, int W, int K, int N, WinoPlan &out)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int>, WinoPlan> cache;
+    const auto key = std::make_tuple(B, H, W, K, N);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) { out = it->second; return true; }
+    if ((K & 31) || (N & 63)) return false;
+    WinoPlan d{};
+    d.K = K; d.N = N; d.TH = (H + 1) / 2; d.TW = (W + 1) / 2;
+    if ((long long)B * 16 * d.TH * d.TW * std::max(K, N) * 4 >= 0x80000000LL) return false;
+    ConvParams &p = d.p;
+    std::memset(&p, 0, sizeof p);
+    p.B = B; p.Hi = 16 * d.TH; p.Wi = d.TW; p.Cs_in = K;
+    const KLayout L = klayout_run(1, 1, K);
+    set_layout(p, L);
+    p.s_in = 1; p.s_out = 1; p.Ho = 16 * d.TH; p.Wo = d.TW; p.Cs_out = N; p.c_off = 0;
+    p.N = N; p.Npad = N; p.act = 0; p.nphase = 16; p.ksplit = 1;
+    d.phase_floats = (size_t)L.ktiles() * p.Npad * 32;
+    for (int xi = 0; xi < 16; ++xi) {
+        ConvPhase &ph = p.ph[xi];
+        ph.Hg = d.TH; ph.Wg = d.TW; ph.M = B * d.TH * d.TW;
+        ph.off_y = xi * d.TH; ph.o_y = xi * d.TH;
+        ph.w_off = (long long)xi * d.phase_floats;
+    }
+    p.Mmax = B * d.TH * d.TW;
+    set_ranges(p);
+    std::vector<int32_t> one(d.phase_floats), all(16 * d.phase_floats);
+    pack_index_conv(1, 1, K, K, N, p.Npad, L, one.data());
+    for (int xi = 0; xi < 16; ++xi)
+        for (size_t i = 0; i < d.phase_floats; ++i) all[xi * d.phase_floats + i] = one[i] ? one[i] + xi * K * N : 0;
+    if (hipMalloc(reinterpret_cast<void **>(&d.tbl), all.size() * sizeof(int32_t)) != hipSuccess) return false;
+    if (hipMemcpy(d.tbl, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d.tbl); return false; }
+    cache[key] = d;
+    out = d;
+    return true;
+}
+
+size_t a256(size_t n) { return (n + 255) / 256 * 256; }
+}  // namespace
+
+extern "C" size_t vstab_conv3x3_winograd_workspace_bytes(int B, int H, int W, int cin, int cout, int transpose)
+{
+    WinoPlan d;
+    const int K = transpose ? cout : cin, N = transpose ? cin : cout;
+    if (B < 1 || H < 1 || W < 1 || !wino_plan(B, H, W, K, N, d)) return 0;
+    const size_t tiles = (size_t)B * 16 * d.TH * d.TW;
+    return a256((size_t)16 * K * N * 4) + a256(16 * d.phase_floats * 4) + a256(tiles * K * 4) + a256(tiles * N * 4) + a256((size_t)N * 4) + 256;
+}
+
+extern "C" int vstab_conv3x3_winograd(const float *x, int B, int H, int W, int cs_x, int cx_off, const float *Wf, int cin, int cout, int transpose,
+                                      const float *bias, float *y, int cs_y, int cy_off, int act, void *workspace, size_t workspace_bytes,
+                                      void *stream)
+{
+    if (!x || !Wf || !y || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv3x3_winograd: NULL buffer");
+    const int K = transpose ? cout : cin, N = transpose ? cin : cout;             // reduction / output channels of this call
+    if (B < 1 || H < 1 || W < 1 || cin < 1 || cout < 1 || cx_off < 0 || cy_off < 0 || cx_off + K > cs_x || cy_off + N > cs_y ||
+        (act != 0 && act != 1 && act != 3))
+        return fail(nullptr, VSTAB_E_SHAPE, "conv3x3_winograd: bad shape");
+    if ((cs_x & 3) || (cx_off & 3) || (cs_y & 3) || (cy_off & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 255))
+        return fail(nullptr, VSTAB_E_ALIGN, "conv3x3_winograd: strides / offsets multiples of 4, 16-byte tensors, 256-byte workspace");
+    WinoPlan d;
+    if (!wino_plan(B, H, W, K, N, d)) return fail(nullptr, VSTAB_E_SHAPE, "conv3x3_winograd: needs K %% 32 == 0, N %% 64 == 0 and < 2 GiB per tensor");
+    if (workspace_bytes < vstab_conv3x3_winograd_workspace_bytes(B, H, W, cin, cout, transpose))
+        return fail(nullptr, VSTAB_E_NOMEM, "conv3x3_winograd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(nullptr, conv_set_attributes());
+    char *ws = reinterpret_cast<char *>(workspace);
+    const size_t tiles = (size_t)B * 16 * d.TH * d.TW;
+    float *Wt = reinterpret_cast<float *>(ws); ws += a256((size_t)16 * K * N * 4);
+    float *wpk = reinterpret_cast<float *>(ws); ws += a256(16 * d.phase_floats * 4);
+    float *V = reinterpret_cast<float *>(ws); ws += a256(tiles * K * 4);
+    float *M = reinterpret_cast<float *>(ws); ws += a256(tiles * N * 4);
+    float *bz = reinterpret_cast<float *>(ws);
+    HIP_TRY(nullptr, launch_wino_weights(Wf, cin, cout, transpose, Wt, st));
+    HIP_TRY(nullptr, launch_pack_apply(Wt, d.tbl, (long long)(16 * d.phase_floats), wpk, st));
+    HIP_TRY(nullptr, hipMemsetAsync(bz, 0, (size_t)N * sizeof(float), st));
+    HIP_TRY(nullptr, launch_wino_input(x, B, H, W, cs_x, cx_off, K, V, st));
+    ConvParams p = d.p;
+    p.in = V; p.out = M; p.wpk = wpk; p.bias = bz; p.partial = nullptr;
+    HIP_TRY(nullptr, launch_conv(p, TILE_128x64, true, st));
+    HIP_TRY(nullptr, launch_wino_output(M, B, H, W, N, bias ? bias : bz, act, y, cs_y, cy_off, st));
+    return VSTAB_OK;
+}

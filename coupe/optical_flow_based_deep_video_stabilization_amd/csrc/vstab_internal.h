@@ -134,6 +134,8 @@ void pack_conv_rowwin(const float *W, const double *scale, int kh, int kw, int c
 // U_xi = (G g G^T)_xi with the BatchNorm scale folded in, 16 blocks of a 1x1-conv operand (klayout_run(1,1,cin)).
 // ---------------------------------------------------------------------------------
 hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_off, int C, float *V, hipStream_t stream);
+// device-side weight transform for training: Wt [16][K][N] from W [3,3,cin,cout]; transpose = the input gradient's operand
+hipError_t launch_wino_weights(const float *W, int cin, int cout, int transpose, float *Wt, hipStream_t stream);
 hipError_t launch_wino_output(const float *M, int B, int Ho, int Wo, int C, const float *bias, int act, float *out, int Cs_out, int c_off,
                               hipStream_t stream);
 

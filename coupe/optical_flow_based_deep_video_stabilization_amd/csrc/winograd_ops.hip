@@ -90,14 +90,58 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
         if (oy >= Ho) continue;
         f32x4 y0 = ((s[a][0] + s[a][1]) + s[a][2]) + bv;
         f32x4 y1 = ((s[a][1] - s[a][2]) - s[a][3]) + bv;
-        if (act) {
+        float *ob = out + (((long long)n * Ho + oy) * Wo + 2 * tx) * Cs_out + c_off + c * 4;
+        if (act == 3) {                                         // accumulate (gradient sums)
+            y0 += *reinterpret_cast<const f32x4 *>(ob);
+            if (2 * tx + 1 < Wo) y1 += *reinterpret_cast<const f32x4 *>(ob + Cs_out);
+        } else if (act) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { y0[e] = fmaxf(y0[e], slope * y0[e]); y1[e] = fmaxf(y1[e], slope * y1[e]); }
         }
-        float *ob = out + (((long long)n * Ho + oy) * Wo + 2 * tx) * Cs_out + c_off + c * 4;
         *reinterpret_cast<f32x4 *>(ob) = y0;
         if (2 * tx + 1 < Wo) *reinterpret_cast<f32x4 *>(ob + Cs_out) = y1;
     }
+}
+
+// Winograd-domain weights on the device (training: the filter changes every step): Wt[xi = 4 i + j][k][n] = sum_{a,b} G[i][a] G[j][b] w(a,b,k,n)
+// with w(a,b,k,n) = W[a][b][k][n] (forward: k = input channel, n = output channel) or, for the input gradient, the flipped filter
+// with the channel roles swapped, W[2-a][2-b][n][k] (k = output channel of the layer, n = its input channel)
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restrict__ W, int cin, int cout, int transpose, float *__restrict__ Wt)
+{
+    const int K = transpose ? cout : cin, N = transpose ? cin : cout;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)K * N) return;
+    const int k = (int)(idx / N), n = (int)(idx - (long long)k * N);
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            g[a][b] = transpose ? W[(((long long)(2 - a) * 3 + (2 - b)) * cin + n) * cout + k] : W[(((long long)a * 3 + b) * cin + k) * cout + n];
+    // G g (rows): G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], then (.) G^T (columns)
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * ((g[0][b] + g[1][b]) + g[2][b]);
+        t[2][b] = 0.5f * ((g[0][b] - g[1][b]) + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const long long xs = (long long)K * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        Wt[(i * 4 + 0) * xs + idx] = t[i][0];
+        Wt[(i * 4 + 1) * xs + idx] = 0.5f * ((t[i][0] + t[i][1]) + t[i][2]);
+        Wt[(i * 4 + 2) * xs + idx] = 0.5f * ((t[i][0] - t[i][1]) + t[i][2]);
+        Wt[(i * 4 + 3) * xs + idx] = t[i][2];
+    }
+}
+
+hipError_t launch_wino_weights(const float *W, int cin, int cout, int transpose, float *Wt, hipStream_t stream)
+{
+    const long long n = (long long)cin * cout;
+    wino_weight_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(W, cin, cout, transpose, Wt);
+    return hipGetLastError();
 }
 
 hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_off, int C, float *V, hipStream_t stream)

@@ -89,6 +89,7 @@ class Trainer:
                 self.p[k] = _pad_to(host[k].to(self.dev), self._padded_shape(k, self.shape_real[k])).contiguous()
         self.sbucket = GradBucket({k: tuple(self.p[k].shape) for k in self.p if "moving_" in k}, self.dev)
         self.t = 0
+        self.wino_min_flops = 3.0e9           # a 3x3 stride-1 stage runs in Winograd form once its GEMM issues this much
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.dev)
         self._alloc_buffers()
 
@@ -162,6 +163,22 @@ class Trainer:
                                             k, s, p, dx.data_ptr(), Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0, ws.data_ptr(),
                                             ws.numel(), self.st))
 
+    def _wino(self, x, cx_off, W, transpose, bias, y, cy_off, act):
+        """3x3 stride-1 stage (or its input gradient) in Winograd F(2x2,3x3) form; False when the geometry does not qualify."""
+        B, H, Wd, cs_x = x.shape
+        cin, cout = int(W.shape[2]), int(W.shape[3])
+        K, N = (cout, cin) if transpose else (cin, cout)
+        if 32.0 * B * ((H + 1) // 2) * ((Wd + 1) // 2) * K * N < self.wino_min_flops:   # same break-even as the inference plan
+            return False
+        n = self.L.vstab_conv3x3_winograd_workspace_bytes(B, H, Wd, cin, cout, 1 if transpose else 0)
+        if n == 0:
+            return False
+        ws = self._workspace(n)
+        self._check(self.L.vstab_conv3x3_winograd(x.data_ptr(), B, H, Wd, cs_x, cx_off, W.data_ptr(), cin, cout, 1 if transpose else 0,
+                                                  bias.data_ptr() if bias is not None else None, y.data_ptr(), y.shape[3], cy_off, act,
+                                                  ws.data_ptr(), ws.numel(), self.st))
+        return True
+
     def _wgrad(self, x, cx_off, cin, g, cg_off, cout, k, s, p, dW, db):
         B, Hi, Wi, cs_x = x.shape
         _, Ho, Wo, cs_g = g.shape
@@ -214,7 +231,8 @@ class Trainer:
         for name, k, s, pad, cout in ENC:                                                # model.py:807-844
             ib, ioff, cin = ENC_IN[name]
             ob, ooff = ENC_OUT[name]
-            self._conv_fwd(a[ib], ioff, cin, p[f"{name}/W_conv2d"], p[f"{name}/b_conv2d"], k, s, pad, a[ob], ooff, cout)
+            if not (k == 3 and s == 1 and self._wino(a[ib], ioff, p[f"{name}/W_conv2d"], False, p[f"{name}/b_conv2d"], a[ob], ooff, 0)):
+                self._conv_fwd(a[ib], ioff, cin, p[f"{name}/W_conv2d"], p[f"{name}/b_conv2d"], k, s, pad, a[ob], ooff, cout)
             self._bn_fwd(name, a[ob], ooff, cout)
         prev = None
         for dname, ib, _cin, ob, ooff, cout, pname, uname, foff in DEC:                   # model.py:847-880
@@ -335,7 +353,9 @@ class Trainer:
             self._wgrad(a[ib], ioff, cin, G[ob], ooff, cout, k, s, pad, g[f"{name}/W_conv2d"], None)
             g[f"{name}/b_conv2d"].zero_()               # same: the batch mean removes the bias, its gradient is exactly zero
             if ib != "x0":
-                self._convT(G[ob], ooff, cout, p[f"{name}/W_conv2d"], None, k, s, pad, G[ib], ioff, cin, self._acc(ib))
+                acc = self._acc(ib)
+                if not (k == 3 and s == 1 and self._wino(G[ob], ooff, p[f"{name}/W_conv2d"], True, None, G[ib], ioff, 3 if acc else 0)):
+                    self._convT(G[ob], ooff, cout, p[f"{name}/W_conv2d"], None, k, s, pad, G[ib], ioff, cin, acc)
 
     # ------------------------------------------------------------------ Adam (main:333-335)
     def adam(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):

@@ -205,3 +205,28 @@ def pad_nearest_upsample_backward(dout, src_hw, dsrc=None):
         _lib.check(_lib.lib().vstab_pad_nearest_upsample_backward(dout.data_ptr(), B, H, W, C, dsrc.data_ptr(), dsrc.shape[1], dsrc.shape[2],
                                                                   1 if acc else 0, runtime.stream_ptr()))
     return dsrc
+
+
+def conv3x3_winograd(x, W, transpose: bool = False, bias=None, y=None, cx_off: int = 0, cy_off: int = 0, act: int = 0):
+    """3x3 stride-1 pad-1 convolution (transpose=False: x [..,cin] -> [..,cout]) or its input gradient (transpose=True:
+    x = output gradient [..,cout] -> dx [..,cin]) in Winograd F(2x2,3x3) form; W [3,3,cin,cout] CUDA tensor.  act 0 none,
+    1 leaky relu 0.1, 3 add to what is in y."""
+    if not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        raise ValueError("x must be a float32 CUDA tensor [B,H,W,C]")
+    x, W = x.contiguous(), W.contiguous()
+    B, H, Wd, cs_x = x.shape
+    cin, cout = int(W.shape[2]), int(W.shape[3])
+    n_out = cin if transpose else cout
+    if y is None:
+        y = torch.empty((B, H, Wd, n_out), dtype=torch.float32, device=x.device)
+        cy_off = 0
+    L = _lib.lib()
+    nbytes = L.vstab_conv3x3_winograd_workspace_bytes(B, H, Wd, cin, cout, 1 if transpose else 0)
+    if nbytes == 0:
+        raise ValueError("conv3x3_winograd: unsupported geometry (reduction channels % 32, output channels % 64, < 2 GiB per tensor)")
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.vstab_conv3x3_winograd(x.data_ptr(), B, H, Wd, cs_x, cx_off, W.data_ptr(), cin, cout, 1 if transpose else 0,
+                                            bias.data_ptr() if bias is not None else None, y.data_ptr(), y.shape[3], cy_off, act,
+                                            ws.data_ptr(), ws.numel(), runtime.stream_ptr()))
+    return y

@@ -253,6 +253,14 @@ VSTAB_API size_t vstab_conv_forward_workspace_bytes(int B, int Hi, int Wi, int c
 VSTAB_API int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *W, const float *bias,
                                  int k, int stride, int pad, float *y, int Ho, int Wo, int cs_y, int cy_off, int cout, int act,
                                  void *workspace, size_t workspace_bytes, void *stream);
+/* The same for a 3x3 stride-1 pad-1 layer in Winograd F(2x2,3x3) form (4/9 of the multiply-adds): transpose = 0 is the forward
+ * convolution x [.., cin] -> y [.., cout]; transpose = 1 the input gradient (x = output gradient [.., cout] -> y = dx [.., cin], kernel
+ * flipped, channel roles swapped).  W: DEVICE [3,3,cin,cout]; the Winograd-domain operand is rebuilt on the device every call.
+ * bias [N] or NULL; act 0 none, 1 leaky relu, 3 ADD to what is in y.  Reduction channels % 32 == 0, output channels % 64 == 0. */
+VSTAB_API size_t vstab_conv3x3_winograd_workspace_bytes(int B, int H, int W, int cin, int cout, int transpose);
+VSTAB_API int vstab_conv3x3_winograd(const float *x, int B, int H, int W, int cs_x, int cx_off, const float *Wf, int cin, int cout, int transpose,
+                                     const float *bias, float *y, int cs_y, int cy_off, int act, void *workspace, size_t workspace_bytes,
+                                     void *stream);
 /* din (+)= gain * (adjoint of tf.image.resize_images(., [oh,ow]))(dout): backward of the legacy bilinear resize. */
 VSTAB_API int vstab_resize_bilinear_backward(const float *dout, int B, int oh, int ow, int C, float *din, int h, int w, float gain,
                                              int accumulate, void *stream);

@@ -21,12 +21,14 @@ pytestmark = pytest.mark.gpu
 BN_LAYERS = [e[0] for e in train_step.ENC] + ["deconv5", "deconv4", "deconv3", "deconv2"]
 
 
-def test_network_backward_matches_autograd():
+@pytest.mark.parametrize("winograd", [False, True])
+def test_network_backward_matches_autograd(winograd):
     B, H, W = 2, 192, 256
     w = wts.synthetic_weights(seed=13, cin=27, random_bn=True, flow_gain=0.5)
     g0 = torch.Generator().manual_seed(H)
     feats = torch.rand(B, H, W, 27, generator=g0)
     tr = train_step.Trainer(w, B, H, W)
+    tr.wino_min_flops = 0.0 if winograd else 1e30          # force / forbid the Winograd form of the 3x3 stride-1 stages
     flows = tr.forward(feats.cuda())
 
     Wt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=("moving_" not in k)) for k, v in w.items()}

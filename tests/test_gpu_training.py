@@ -267,3 +267,29 @@ def test_pad_nearest_upsample_forward_and_adjoint(h2, w2, H, W):
     ref.backward(dy.double())
     got = training.pad_nearest_upsample_backward(dy.cuda(), (h2, w2))
     assert float((got.double().cpu() - srcd.grad).abs().max()) <= 1e-5 * max(1.0, float(srcd.grad.abs().max()))
+
+
+# ----------------------------------------------------------------------------- Winograd F(2x2,3x3) with device-resident weights
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 24, 64, 128), (1, 13, 17, 256, 256), (3, 8, 8, 128, 64), (2, 33, 20, 32, 192)])
+def test_conv3x3_winograd_forward_and_input_gradient(B, H, W, cin, cout):
+    import torch.nn.functional as F
+    g0 = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(B, H, W, cin, generator=g0)
+    Wt = torch.randn(3, 3, cin, cout, generator=g0) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g0) * 0.1
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), Wt.double().permute(3, 2, 0, 1), b.double(), padding=1).permute(0, 2, 3, 1)
+    y = training.conv3x3_winograd(x.cuda(), Wt.cuda(), bias=b.cuda())
+    assert float((y.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    yl = training.conv3x3_winograd(x.cuda(), Wt.cuda(), bias=b.cuda(), act=1)
+    assert float((yl.double().cpu() - torch.maximum(ref, 0.1 * ref)).abs().max()) <= 2e-5 * float(ref.abs().max())
+    if cin % 64 == 0 and cout % 32 == 0:                      # the input gradient swaps the channel roles
+        g = torch.randn(B, H, W, cout, generator=g0)
+        dref = _torch_dgrad(g, Wt, 1, 1, (H, W))
+        dx = training.conv3x3_winograd(g.cuda(), Wt.cuda(), transpose=True)
+        assert float((dx.double().cpu() - dref).abs().max()) <= 2e-5 * float(dref.abs().max())
+        base = torch.randn(B, H, W, cin + 8, generator=g0)    # accumulate into a channel slice of a wider tensor
+        out = training.conv3x3_winograd(g.cuda(), Wt.cuda(), transpose=True, y=base.clone().cuda(), cy_off=4, act=3).cpu()
+        exp = base.double().clone()
+        exp[..., 4:4 + cin] += dref
+        assert float((out.double() - exp).abs().max()) <= 2e-5 * float(exp.abs().max())
+        assert torch.equal(out[..., :4], base[..., :4])
