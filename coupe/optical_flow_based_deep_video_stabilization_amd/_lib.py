@@ -85,6 +85,10 @@ EXPORTS = {
     "vstab_lrelu_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p]),
     "vstab_flow_medfilt": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "vstab_flow_mean_fill": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
+    "vstab_homography_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "vstab_homography_fit": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_uint, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vstab_warp_perspective_u8": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vstab_host_xcd_remap": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int32)]),
     "vstab_level_sizes": (C.c_int, [C.c_int, C.c_int, c_int32_p]),
     "vstab_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -41,7 +41,10 @@ def resize_u8(src: torch.Tensor, size_hw) -> torch.Tensor:
 
 class ClipStabiliser:
     def __init__(self, out_h: int, out_w: int, n_clips: int = 1, net_hw=(384, 512), scope: str = 'flownetS',
-                 device: Optional[int] = None):
+                 device: Optional[int] = None, homography: bool = False, ransac: Optional[dict] = None):
+        """homography=True is the evaluator of main:728-743: the frame WRITTEN is the unstable frame under one
+        homography fitted to the dense flow (cv2.findHomography + cv2.warpPerspective), while the history later frames
+        read stays the flow-warped frame (main:739).  `ransac` = keyword arguments of postfilters.find_homography."""
         runtime._require_gpu()
         self.out_h, self.out_w, self.n = int(out_h), int(out_w), int(n_clips)
         self.net_h, self.net_w = int(net_hw[0]), int(net_hw[1])
@@ -53,6 +56,8 @@ class ClipStabiliser:
         self.frame_f = torch.empty((self.n, self.out_h, self.out_w, 3), dtype=torch.float32, device=dev)
         self.i = 0
         self.last_flows = None
+        self.homography, self.ransac, self.last_homography = bool(homography), dict(ransac or {}), None
+        self.last_outflow = None
 
     def reset(self):
         self.i = 0
@@ -84,8 +89,12 @@ class ClipStabiliser:
             _lib.check(L.vstab_quantise_output(warped.data_ptr(), self.n * self.out_h * self.out_w, out.data_ptr(),
                                                runtime.stream_ptr()))                                  # main:625,630
         self.ring[i % RING].copy_(resize_u8(out, (self.net_h, self.net_w)))      # what later frames read back (main:556)
-        self.last_flows = flows
+        self.last_flows, self.last_outflow = flows, outflow
         self.i += 1
+        if self.homography:
+            from . import postfilters
+            self.last_homography, _ = postfilters.find_homography(outflow, **self.ransac)               # main:728-735
+            return postfilters.warp_perspective_u8(f, self.last_homography)                            # main:736,743
         return out
 
     def run(self, clip_bgr_u8: torch.Tensor) -> torch.Tensor:

@@ -1168,6 +1168,38 @@ extern "C" int vstab_flow_medfilt(const float *flow, int B, int h, int w, int kh
     return VSTAB_OK;
 }
 
+extern "C" size_t vstab_homography_workspace_bytes(int B, int H, int W, int K)
+{
+    if (B < 1 || H < 1 || W < 1 || K < 1 || K > 512) return 0;
+    return homography_workspace_bytes(B, H, W, K);
+}
+
+extern "C" int vstab_homography_fit(const float *flow, int B, int H, int W, int K, unsigned seed, double thresh, int refine,
+                                    int stride, double *Hout, int32_t *inliers, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    if (!flow || !Hout || !inliers || !workspace) return fail(nullptr, VSTAB_E_STATE, "homography_fit: NULL buffer");
+    if (B < 1 || H < 2 || W < 2 || (long long)H * W > 0x7fffffffLL) return fail(nullptr, VSTAB_E_SHAPE, "homography_fit: bad shape");
+    if (K < 1 || K > 512 || refine < 1 || refine > 16 || stride < 1 || !(thresh > 0.0))
+        return fail(nullptr, VSTAB_E_SHAPE, "homography_fit: need 1 <= K <= 512, 1 <= refine <= 16, stride >= 1, thresh > 0");
+    if (workspace_bytes < homography_workspace_bytes(B, H, W, K)) return fail(nullptr, VSTAB_E_NOMEM, "homography_fit: workspace too small");
+    if (((uintptr_t)flow | (uintptr_t)Hout | (uintptr_t)workspace) & 7)
+        return fail(nullptr, VSTAB_E_ALIGN, "homography_fit: flow / Hout / workspace must be 8-byte aligned");
+    HIP_TRY(nullptr, launch_homography_fit(flow, B, H, W, K, seed, thresh, refine, stride, Hout, inliers, workspace, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_warp_perspective_u8(const uint8_t *src, int B, int sh, int sw, const double *Hm, uint8_t *dst, int oh, int ow,
+                                         void *stream)
+{
+    if (!src || !Hm || !dst) return fail(nullptr, VSTAB_E_STATE, "warp_perspective_u8: NULL buffer");
+    if (src == dst) return fail(nullptr, VSTAB_E_STATE, "warp_perspective_u8: in-place warping is not supported");
+    if (B < 1 || sh < 1 || sw < 1 || oh < 1 || ow < 1 || sh > 32767 || sw > 32767)
+        return fail(nullptr, VSTAB_E_SHAPE, "warp_perspective_u8: bad shape");
+    HIP_TRY(nullptr, launch_warp_perspective_u8(src, B, sh, sw, Hm, dst, oh, ow, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_flow_mean_fill(const float *flow, int B, int h, int w, float *out, void *stream)
 {
     if (!flow || !out) return fail(nullptr, VSTAB_E_STATE, "flow_mean_fill: NULL buffer");

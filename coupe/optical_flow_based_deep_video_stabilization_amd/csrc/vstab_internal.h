@@ -222,6 +222,14 @@ hipError_t launch_loss_level(const float *pf, const float *G, const float *U, in
                              float scale_tv, float *grad, hipStream_t stream);
 hipError_t launch_flow_medfilt(const float *flow, int B, int h, int w, int kh, int kw, int kc, float *out, hipStream_t stream);
 
+// dense-flow homography fit + cv2.warpPerspective on 8-bit frames (homography_ops.hip)
+int homography_moment_blocks(int H, int W);
+size_t homography_workspace_bytes(int B, int H, int W, int K);
+hipError_t launch_homography_fit(const float *flow, int B, int H, int W, int K, unsigned seed, double thresh, int refine,
+                                 int stride, double *Hout, int *inliers, void *ws, hipStream_t stream);
+hipError_t launch_warp_perspective_u8(const unsigned char *src, int B, int sh, int sw, const double *Hm, unsigned char *dst,
+                                      int oh, int ow, hipStream_t stream);
+
 // NLDF head helpers (nldf_ops.hip)
 hipError_t launch_contrast(float *buf, int B, int H, int W, int C, int Cs, int c_dst, hipStream_t stream);
 hipError_t launch_nldf_score(const float *local2, const float *global2, int B, int npix, float *score, float *prob,

@@ -1,8 +1,9 @@
 """Flow post-filters the reference's other evaluators wrap around the same hot path:
 `evaluate_blurNma` (main_flownetS_pyramid.py:582-700: 75x75 box blur of predict_flow2 blended with a temporal
 EMA), `evaluate_medianNma` (:703-821: scipy.signal.medfilt of the flow, same EMA) and the mean-global-flow variant
-(main_flownetS_pyramid_highTV_noBBloss.py:629-631, 679-685).  The RANSAC homography evaluator (main:735-743)
-needs cv2.findHomography and stays out of scope."""
+(main_flownetS_pyramid_highTV_noBBloss.py:629-631, 679-685), and the homography evaluator of
+main_flownetS_pyramid_noprevloss_dataloader.py:728-743 (cv2.findHomography(RANSAC) on the dense flow, then
+cv2.warpPerspective of the unstable frame) as an on-device dense-flow RANSAC."""
 from __future__ import annotations
 
 import torch
@@ -64,6 +65,43 @@ def mean_flow(flow):
     with torch.cuda.device(f.device):
         _lib.check(_lib.lib().vstab_flow_mean_fill(f.data_ptr(), B, h, w, out.data_ptr(), runtime.stream_ptr()))
     return out
+
+
+def find_homography(flow, K: int = 256, seed: int = 0, thresh: float = 3.0, refine: int = 2, stride: int = 1):
+    """h, _ = cv2.findHomography(gridmesh, gridmesh - flow, cv2.RANSAC) for every sample of a dense flow [B,H,W,2]
+    (main_flownetS_pyramid_noprevloss_dataloader.py:728-735): returns (H [B,3,3] float64 CUDA with h33 = 1, inlier
+    counts int32 [B]).  The fit is the library's deterministic dense-flow RANSAC (include/vstab.h): K hash-drawn
+    4-point hypotheses, 3 px consensus (cv2's default threshold), `refine` least-squares refits on the inliers."""
+    f = _flow(flow)
+    B, h, w, _ = f.shape
+    L = _lib.lib()
+    n = L.vstab_homography_workspace_bytes(B, h, w, int(K))
+    if n == 0:
+        raise ValueError("find_homography: need 1 <= K <= 512")
+    ws = torch.empty(n, dtype=torch.uint8, device=f.device)
+    Hm = torch.empty((B, 3, 3), dtype=torch.float64, device=f.device)
+    inl = torch.empty((B,), dtype=torch.int32, device=f.device)
+    with torch.cuda.device(f.device):
+        _lib.check(L.vstab_homography_fit(f.data_ptr(), B, h, w, int(K), int(seed) & 0xffffffff, float(thresh), int(refine),
+                                          int(stride), Hm.data_ptr(), inl.data_ptr(), ws.data_ptr(), n, runtime.stream_ptr()))
+    return Hm, inl
+
+
+def warp_perspective_u8(frames, Hm, size_hw=None):
+    """cv2.warpPerspective(frame, h, (out_w, out_h)) on uint8 frames [B,H,W,3] with one src->dst matrix per frame
+    (main_flownetS_pyramid_noprevloss_dataloader.py:736)."""
+    if not torch.is_tensor(frames) or not frames.is_cuda or frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+        raise ValueError("frames must be a uint8 CUDA tensor [B,H,W,3]")
+    src = frames.contiguous()
+    B, sh, sw, _ = src.shape
+    if not torch.is_tensor(Hm) or Hm.dtype != torch.float64 or tuple(Hm.shape) != (B, 3, 3) or Hm.device != src.device:
+        raise ValueError("Hm must be a float64 tensor [B,3,3] on the frames' device")
+    oh, ow = (sh, sw) if size_hw is None else (int(size_hw[0]), int(size_hw[1]))
+    dst = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.lib().vstab_warp_perspective_u8(src.data_ptr(), B, sh, sw, Hm.contiguous().data_ptr(), dst.data_ptr(),
+                                                        oh, ow, runtime.stream_ptr()))
+    return dst
 
 
 class BlurEmaFilter:

@@ -305,6 +305,22 @@ VSTAB_API int vstab_flow_medfilt(const float *flow, int B, int h, int w, int kh,
 /* out[b,:,:,c] = mean over the image of flow[b,:,:,c] (main_flownetS_pyramid_highTV_noBBloss.py:629). */
 VSTAB_API int vstab_flow_mean_fill(const float *flow, int B, int h, int w, float *out, void *stream);
 
+/* Homography evaluator (main:728-743, main = main_flownetS_pyramid_noprevloss_dataloader.py): replaces
+ *   h, mask = cv2.findHomography(gridmesh, gridmesh - flow, cv2.RANSAC)        (main:735)
+ * on the dense [B,H,W,2] flow with a deterministic on-device RANSAC: K (<= 512) 4-point hypotheses per sample drawn
+ * by a counter hash of `seed`, consensus = pixels (every `stride`-th) whose reprojection error is <= thresh (cv2's
+ * default is 3.0), then `refine` (1..16) least-squares refits on the inlier set.  Hout[b][9] = row-major src->dst
+ * matrix with h33 = 1 (float64, device), inliers[b] = size of the last consensus set (0: nothing fitted, Hout NaN).
+ * cv2's own RNG cannot be reproduced, so the hypotheses differ from cv2's; the estimator is the same. */
+VSTAB_API size_t vstab_homography_workspace_bytes(int B, int H, int W, int K);
+VSTAB_API int vstab_homography_fit(const float *flow, int B, int H, int W, int K, unsigned seed, double thresh, int refine,
+                                   int stride, double *Hout, int32_t *inliers, void *workspace, size_t workspace_bytes,
+                                   void *stream);
+/* cv2.warpPerspective(src, Hm[b], (ow, oh)) with default flags on uint8 [B,sh,sw,3] frames (main:736): INTER_LINEAR on
+ * coordinates rounded to 1/32 px, 15-bit fixed-point blend, constant-0 border; Hm maps src -> dst (inverted inside). */
+VSTAB_API int vstab_warp_perspective_u8(const uint8_t *src, int B, int sh, int sw, const double *Hm, uint8_t *dst, int oh, int ow,
+                                        void *stream);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU tests) --------------------- */
 /* Level sizes of the encoder for an HxW input: hw[2*i], hw[2*i+1] = (h, w) of stage i
  * (10 stages).  Returns 0 or VSTAB_E_SHAPE. */

@@ -528,6 +528,113 @@ def cv_resize_u8(src: np.ndarray, dh: int, dw: int) -> np.ndarray:
     return np.clip(v, 0, 255).astype(np.uint8)
 
 
+# --------------------------------------------------------------------------- homography evaluator
+def _homog_hash(x):
+    x = np.asarray(x, dtype=np.uint64) & np.uint64(0xffffffff)
+    m = np.uint64(0xffffffff)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & m
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & m
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def homography_fit(flow, K=256, seed=0, thresh=3.0, refine=2, stride=1, sample_index=0):
+    """The estimator behind `h, mask = cv2.findHomography(gridmesh, gridmesh - flow, cv2.RANSAC)` (main:728-735) as
+    the HIP library defines it (include/vstab.h: cv2's RNG cannot be restated, the estimator can): K 4-point
+    hypotheses from hash-drawn pixels, consensus under a `thresh` px reprojection error, arg-max with the lowest
+    index on ties, `refine` least-squares refits on the inliers.  flow [H,W,2] float32 -> (3x3 float64, inliers)."""
+    flow = np.asarray(flow, dtype=np.float32)
+    H, W = flow.shape[:2]
+    npix = H * W
+    cx, cy = 0.5 * (W - 1), 0.5 * (H - 1)
+    sc = 1.0 / max(cx, cy, 1.0)
+    ys, xs = np.divmod(np.arange(npix), W)
+    f = flow.reshape(npix, 2).astype(np.float64)
+    x, y = (xs - cx) * sc, (ys - cy) * sc
+    u, v = (xs - f[:, 0] - cx) * sc, (ys - f[:, 1] - cy) * sc          # gridmeshOF = gridmesh - curoutflow
+    thr2 = thresh * sc * thresh * sc
+
+    def rows(i):
+        z, o = np.zeros_like(x[i]), np.ones_like(x[i])
+        r0 = np.stack([x[i], y[i], o, z, z, z, -u[i] * x[i], -u[i] * y[i]], -1)
+        r1 = np.stack([z, z, z, x[i], y[i], o, -v[i] * x[i], -v[i] * y[i]], -1)
+        return r0, r1
+
+    def inliers_of(h, sel):
+        w = h[6] * x[sel] + h[7] * y[sel] + h[8]
+        with np.errstate(all="ignore"):
+            du = (h[0] * x[sel] + h[1] * y[sel] + h[2]) / w - u[sel]
+            dv = (h[3] * x[sel] + h[4] * y[sel] + h[5]) / w - v[sel]
+            return du * du + dv * dv <= thr2
+
+    scored = np.arange(0, npix, stride)
+    best, best_cnt = None, -1
+    for k in range(K):
+        t = sample_index * K + k
+        ctr = (np.uint64(seed) + np.uint64(0x9E3779B9) * (np.uint64(t * 4) + np.arange(1, 5, dtype=np.uint64))) & np.uint64(0xffffffff)
+        idx = ((_homog_hash(ctr) * np.uint64(npix)) >> np.uint64(32)).astype(np.int64)
+        r0, r1 = rows(idx)
+        A = np.empty((8, 8)); rhs = np.empty(8)
+        A[0::2], A[1::2] = r0, r1
+        rhs[0::2], rhs[1::2] = u[idx], v[idx]
+        try:
+            if abs(np.linalg.det(A)) < 1e-30:
+                continue
+            h = np.append(np.linalg.solve(A, rhs), 1.0)
+        except np.linalg.LinAlgError:
+            continue
+        cnt = int(inliers_of(h, scored).sum())
+        if cnt > best_cnt:
+            best, best_cnt = h, cnt
+    if best is None:
+        return np.full((3, 3), np.nan), 0
+    h, n_in = best, 0
+    allp = np.arange(npix)
+    for _ in range(refine):
+        m = inliers_of(h, allp)
+        n_in = int(m.sum())
+        if n_in < 4:
+            break
+        r0, r1 = rows(np.nonzero(m)[0])
+        A = np.concatenate([r0, r1]); rhs = np.concatenate([u[m], v[m]])
+        try:
+            h = np.append(np.linalg.solve(A.T @ A, A.T @ rhs), 1.0)
+        except np.linalg.LinAlgError:
+            break
+    Hn = h.reshape(3, 3)
+    T = np.array([[sc, 0, -cx * sc], [0, sc, -cy * sc], [0, 0, 1.0]])
+    M = np.linalg.inv(T) @ Hn @ T
+    return M / M[2, 2], n_in
+
+
+def cv_warp_perspective_u8(src, M, oh, ow):
+    """cv2.warpPerspective(src, M, (ow, oh)) on uint8 HxWxC (main:736): default INTER_LINEAR / BORDER_CONSTANT 0, M maps
+    src -> dst.  Restates OpenCV's published 8-bit path (imgwarp.cpp: coordinates rounded to 1/32 px, 15-bit fixed-point
+    bilinear weights); cv2 is not installed here: UNVERIFIED against the library."""
+    sh, sw = src.shape[:2]
+    Mi = np.linalg.inv(np.asarray(M, dtype=np.float64))
+    dx, dy = np.meshgrid(np.arange(ow, dtype=np.float64), np.arange(oh, dtype=np.float64))
+    X0 = Mi[0, 0] * dx + Mi[0, 1] * dy + Mi[0, 2]
+    Y0 = Mi[1, 0] * dx + Mi[1, 1] * dy + Mi[1, 2]
+    Wd = Mi[2, 0] * dx + Mi[2, 1] * dy + Mi[2, 2]
+    with np.errstate(all="ignore"):
+        Wd = np.where(Wd != 0, 32.0 / Wd, 0.0)
+    X = np.rint(np.clip(X0 * Wd, -2147483648.0, 2147483647.0)).astype(np.int64)
+    Y = np.rint(np.clip(Y0 * Wd, -2147483648.0, 2147483647.0)).astype(np.int64)
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
+    ax, ay = X & 31, Y & 31
+    S = src.astype(np.int64)
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < sw) & (yy >= 0) & (yy < sh)
+        return np.where(ok[..., None], S[np.clip(yy, 0, sh - 1), np.clip(xx, 0, sw - 1)], 0)
+
+    w = [(32 - ax) * (32 - ay) * 32, ax * (32 - ay) * 32, (32 - ax) * ay * 32, ax * ay * 32]
+    acc = (w[0][..., None] * tap(sy, sx) + w[1][..., None] * tap(sy, sx + 1) + w[2][..., None] * tap(sy + 1, sx)
+           + w[3][..., None] * tap(sy + 1, sx + 1) + (1 << 14)) >> 15
+    return np.clip(acc, 0, 255).astype(np.uint8)
+
+
 def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32, teacher=None):
     """The loop of evaluate_originalSize (main:540-630) on a clip [T,H,W,3] uint8 BGR -> stabilised uint8 clip.
     `teacher` ([T,H,W,3] uint8, another implementation's outputs): if given, frame i is still computed here but the

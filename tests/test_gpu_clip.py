@@ -67,3 +67,23 @@ def test_lockstep_clips_equal_single_clip_runs():
     outa = clip_driver.ClipStabiliser(H, W, n_clips=1, net_hw=(48, 64)).run(torch.from_numpy(a).cuda()).cpu().numpy()
     d = np.abs(out2[:, 0].astype(np.int32) - outa.astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 0.01                                     # split-K plans may differ with batch
+
+
+def test_homography_evaluator_mode():
+    """main:728-743: the written frame is the homography-warped unstable frame; the history stays flow-warped."""
+    T, H, W = 4, 48, 64
+    clip = smooth_clip(T, H, W, 4)
+    w = wts.synthetic_weights(seed=23, cin=27, random_bn=True, flow_gain=0.5)
+    runtime.reset()
+    vs.assign_weights(w)
+    plain = clip_driver.ClipStabiliser(H, W, net_hw=(48, 64))
+    homo = clip_driver.ClipStabiliser(H, W, net_hw=(48, 64), homography=True, ransac=dict(K=32, seed=5))
+    for t in range(T):
+        f = torch.from_numpy(clip[t:t + 1]).cuda()
+        plain.step(f)
+        got = homo.step(f).cpu().numpy()[0]
+        M = homo.last_homography[0].cpu().numpy()
+        ref_M, _ = vo.homography_fit(homo.last_outflow[0].cpu().numpy(), K=32, seed=5)
+        assert np.abs(M - ref_M).max() <= 1e-7 * max(1.0, np.abs(ref_M).max())
+        assert np.array_equal(got, vo.cv_warp_perspective_u8(clip[t], M, H, W))
+    assert torch.equal(plain.ring, homo.ring)

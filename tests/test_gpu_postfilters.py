@@ -1,4 +1,5 @@
 """GPU parity of the flow post-filters against the oracle."""
+import numpy as np
 import pytest
 import torch
 
@@ -64,3 +65,70 @@ def test_median_ema_filter_and_argument_checks():
         pf.medfilt_flow(torch.zeros(1, 4, 4, 2, device="cuda"), 4)
     with pytest.raises(ValueError):
         pf.medfilt_flow(torch.zeros(1, 4, 4, 2, device="cuda"), (3, 3))
+
+
+def _homography_flow(H, W, Ht, outlier_frac, seed):
+    """Dense flow whose correspondences (x,y) -> (x,y) - flow obey Ht, with a fraction of pixels replaced by noise."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    d = Ht[2, 0] * xs + Ht[2, 1] * ys + Ht[2, 2]
+    u = (Ht[0, 0] * xs + Ht[0, 1] * ys + Ht[0, 2]) / d
+    v = (Ht[1, 0] * xs + Ht[1, 1] * ys + Ht[1, 2]) / d
+    flow = np.stack([xs - u, ys - v], -1).astype(np.float32)
+    out = rng.random((H, W)) < outlier_frac
+    flow[out] += rng.uniform(-25, 25, (int(out.sum()), 2)).astype(np.float32)
+    return flow, out
+
+
+HT = [np.array([[1.02, 0.01, 3.0], [-0.015, 0.99, -2.0], [1e-5, -2e-5, 1.0]]),
+      np.array([[0.97, -0.03, -4.5], [0.02, 1.01, 6.25], [-3e-5, 1e-5, 1.0]])]
+
+
+def test_homography_fit_matches_oracle():
+    H, W, K = 96, 128, 64
+    flows = [_homography_flow(H, W, HT[b], 0.3, 5 + b)[0] for b in range(2)]
+    Hm, inl = pf.find_homography(torch.from_numpy(np.stack(flows)).cuda(), K=K, seed=11, thresh=3.0, refine=2)
+    for b in range(2):
+        ref, n_ref = vo.homography_fit(flows[b], K=K, seed=11, thresh=3.0, refine=2, sample_index=b)
+        assert int(inl[b]) == n_ref
+        assert float(np.abs(Hm[b].cpu().numpy() - ref).max()) <= 1e-8 * max(1.0, float(np.abs(ref).max()))
+    # every `stride`-th pixel scored, one refit
+    Hs, ns = pf.find_homography(torch.from_numpy(flows[0][None]).cuda(), K=32, seed=3, refine=1, stride=7)
+    ref, n_ref = vo.homography_fit(flows[0], K=32, seed=3, refine=1, stride=7)
+    assert int(ns[0]) == n_ref and float(np.abs(Hs[0].cpu().numpy() - ref).max()) <= 1e-8 * float(np.abs(ref).max())
+
+
+def test_homography_fit_recovers_motion_at_full_size():
+    """Size-independent property at the headline size: 40 % gross outliers do not move the estimate."""
+    H, W = 512, 512
+    flow, out = _homography_flow(H, W, HT[0], 0.4, 1)
+    Hm, inl = pf.find_homography(torch.from_numpy(flow[None]).cuda())
+    err = np.abs(Hm[0].cpu().numpy() - HT[0])
+    assert err[:2, :2].max() < 2e-4 and err[:2, 2].max() < 0.05 and err[2, :2].max() < 1e-6
+    assert int((~out).sum()) <= int(inl[0]) <= int((~out).sum()) + int(0.05 * out.sum())
+    again, _ = pf.find_homography(torch.from_numpy(flow[None]).cuda())
+    assert torch.equal(again, Hm)                                           # fixed summation order: bit-reproducible
+    # a pure translation is recovered exactly; an all-outlier field reports few inliers
+    t = torch.zeros(1, 64, 80, 2, device="cuda"); t[..., 0] = 2.5; t[..., 1] = -1.25
+    Ht, n = pf.find_homography(t, K=16)
+    assert int(n[0]) == 64 * 80
+    assert float((Ht[0].cpu() - torch.tensor([[1, 0, -2.5], [0, 1, 1.25], [0, 0, 1]], dtype=torch.float64)).abs().max()) < 1e-9
+    with pytest.raises(ValueError):
+        pf.find_homography(t, K=513)
+    with pytest.raises(ValueError):
+        pf.find_homography(t, refine=0)
+
+
+@pytest.mark.parametrize("sh,sw,oh,ow", [(96, 128, 96, 128), (50, 70, 64, 40), (270, 480, 270, 480)])
+def test_warp_perspective_u8_matches_oracle(sh, sw, oh, ow):
+    rng = np.random.default_rng(sh)
+    img = rng.integers(0, 256, (2, sh, sw, 3), dtype=np.uint8)
+    Ms = np.stack([HT[0], HT[1]])
+    got = pf.warp_perspective_u8(torch.from_numpy(img).cuda(), torch.from_numpy(Ms).cuda(), (oh, ow)).cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(got[b], vo.cv_warp_perspective_u8(img[b], Ms[b], oh, ow))
+    eye = torch.eye(3, dtype=torch.float64).expand(2, 3, 3).contiguous().cuda()
+    same = pf.warp_perspective_u8(torch.from_numpy(img).cuda(), eye)
+    assert np.array_equal(same.cpu().numpy(), img)
+    with pytest.raises(ValueError):
+        pf.warp_perspective_u8(torch.from_numpy(img).cuda(), eye.float())

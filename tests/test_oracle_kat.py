@@ -230,3 +230,26 @@ def test_training_loss_gradient_matches_finite_differences():
         fm[0, y, x, c] -= eps
         num = (float(vo.lossterm(fp, G, U)[0]) - float(vo.lossterm(fm, G, U)[0])) / (2 * eps)
         assert abs(num - float(f.grad[0, y, x, c])) < 2e-4 * max(1.0, abs(num)), (y, x, c, num, float(f.grad[0, y, x, c]))
+
+
+def test_homography_oracle_known_answers():
+    """Known-answer checks of the homography evaluator's restatement (main:728-736)."""
+    H, W = 48, 64
+    Ht = np.array([[1.03, 0.02, 1.5], [-0.01, 0.98, -2.25], [2e-5, -1e-5, 1.0]])
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    d = Ht[2, 0] * xs + Ht[2, 1] * ys + Ht[2, 2]
+    flow = np.stack([xs - (Ht[0, 0] * xs + Ht[0, 1] * ys + Ht[0, 2]) / d, ys - (Ht[1, 0] * xs + Ht[1, 1] * ys + Ht[1, 2]) / d], -1)
+    flow = flow.astype(np.float32)
+    rng = np.random.default_rng(0)
+    bad = rng.random((H, W)) < 0.35
+    flow[bad] += np.where(rng.random((int(bad.sum()), 2)) < 0.5, -1, 1) * rng.uniform(8, 30, (int(bad.sum()), 2)).astype(np.float32)
+    M, n = vo.homography_fit(flow, K=48, seed=2)
+    assert n == int((~bad).sum())                                   # every clean pixel and no corrupted one
+    assert np.abs(M - Ht).max() < 1e-4
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    assert np.array_equal(vo.cv_warp_perspective_u8(img, np.eye(3), H, W), img)
+    sh = vo.cv_warp_perspective_u8(img, np.array([[1, 0, 2.0], [0, 1, 1.0], [0, 0, 1.0]]), H, W)
+    assert np.array_equal(sh[1:, 2:], img[:-1, :-2]) and sh[0].max() == 0 and sh[:, :2].max() == 0     # constant-0 border
+    half = vo.cv_warp_perspective_u8(img, np.array([[1, 0, 0.5], [0, 1, 0.0], [0, 0, 1.0]]), H, W)
+    want = (img[:, :-1].astype(np.int64) + img[:, 1:] + 1) >> 1                                          # a = 16: equal weights
+    assert np.array_equal(half[:, 1:], want.astype(np.uint8))
