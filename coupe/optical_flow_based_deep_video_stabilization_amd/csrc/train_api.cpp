@@ -21,7 +21,7 @@ extern "C" size_t vstab_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int k,
     const int ks = wgrad_choose_split(p);
     const size_t ptab = ((size_t)p.K * sizeof(int4) + 255) / 256 * 256;
     const size_t slabs = ((ks > 1 ? (size_t)ks * p.M * cout * sizeof(float) : 0) + 255) / 256 * 256;
-    return ptab + slabs + (size_t)column_sum_chunks(p.K) * cout * sizeof(float) + 256;
+    return ptab + slabs + (size_t)column_sum_chunks(p.K, cout) * cout * sizeof(float) + 256;
 }
 
 extern "C" int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *gout, int Ho,
@@ -286,7 +286,7 @@ extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs
 extern "C" size_t vstab_bn_scratch_bytes(long long rows, int C)
 {
     if (rows < 1 || C < 1) return 0;
-    return ((size_t)4 * bn_chunks(rows) + 2) * C * sizeof(float) + 256;
+    return ((size_t)4 * bn_chunks(rows, C) + 2) * C * sizeof(float) + 256;
 }
 
 extern "C" int vstab_bn_lrelu_train_forward(float *zy, long long rows, int cs, int c_off, int C, const float *beta, float *moving_mean,
@@ -446,7 +446,7 @@ extern "C" int vstab_adam_step(float *w, const float *g, float *m, float *v, lon
     return VSTAB_OK;
 }
 
-extern "C" size_t vstab_column_sum_scratch_bytes(long long rows, int C) { return rows < 1 || C < 1 ? 0 : (size_t)column_sum_chunks(rows) * C * sizeof(float) + 256; }
+extern "C" size_t vstab_column_sum_scratch_bytes(long long rows, int C) { return rows < 1 || C < 1 ? 0 : (size_t)column_sum_chunks(rows, C) * C * sizeof(float) + 256; }
 
 extern "C" int vstab_column_sum(const float *g, long long rows, int cs, int c_off, int C, float *out, int accumulate, void *scratch,
                                 size_t scratch_bytes, void *stream)

@@ -234,14 +234,32 @@ __global__ __launch_bounds__(256) void bn_moments_kernel(const float *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void bn_moments_final_kernel(const double *__restrict__ part, int chunks, int C, double inv_rows, float eps,
-                                                               float decay, float *__restrict__ mean, float *__restrict__ rstd,
-                                                               float *__restrict__ mov_mean, float *__restrict__ mov_var)
+// second stage (one workgroup of 16 waves per 64 channels): wave w adds chunks w, w+16, ... with four loads in flight;
+// the 16 partial sums are added in wave order, so the statistics are reproducible.
+__global__ __launch_bounds__(1024) void bn_moments_final_kernel(const double *__restrict__ part, int chunks, int C, double inv_rows, float eps,
+                                                                float decay, float *__restrict__ mean, float *__restrict__ rstd,
+                                                                float *__restrict__ mov_mean, float *__restrict__ mov_var)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < chunks; ++k) { s += part[((long long)k * 2 + 0) * C + c]; q += part[((long long)k * 2 + 1) * C + c]; }
+    if (c < C) {
+        int k = wave;
+        for (; k + 16 < chunks; k += 32) {
+            const double a0 = part[((long long)k * 2 + 0) * C + c], b0 = part[((long long)k * 2 + 1) * C + c];
+            const double a1 = part[((long long)(k + 16) * 2 + 0) * C + c], b1 = part[((long long)(k + 16) * 2 + 1) * C + c];
+            s += a0; q += b0; s += a1; q += b1;
+        }
+        for (; k < chunks; k += 16) { s += part[((long long)k * 2 + 0) * C + c]; q += part[((long long)k * 2 + 1) * C + c]; }
+    }
+    red[0][wave][lane] = s;
+    red[1][wave][lane] = q;
+    __syncthreads();
+    if (wave != 0 || c >= C) return;
+    s = 0.0; q = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { s += red[0][w][lane]; q += red[1][w][lane]; }
     const double m = s * inv_rows;
     double var = q * inv_rows - m * m;
     if (var < 0.0) var = 0.0;
@@ -272,13 +290,29 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(float *__restrict__
 }
 
 // backward sums: sums[c] = sum g, sums[C + c] = sum g * xhat (chunks added in order); dbeta = sum g
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restrict__ part, int chunks, int C, float *__restrict__ sums,
-                                                           float *__restrict__ dbeta, int accumulate)
+__global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float *__restrict__ part, int chunks, int C, float *__restrict__ sums,
+                                                            float *__restrict__ dbeta, int accumulate)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[2][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < chunks; ++k) { a += part[((long long)k * 2 + 0) * C + c]; b += part[((long long)k * 2 + 1) * C + c]; }
+    if (c < C) {
+        int k = wave;
+        for (; k + 16 < chunks; k += 32) {
+            const float a0 = part[((long long)k * 2 + 0) * C + c], b0 = part[((long long)k * 2 + 1) * C + c];
+            const float a1 = part[((long long)(k + 16) * 2 + 0) * C + c], b1 = part[((long long)(k + 16) * 2 + 1) * C + c];
+            a += a0; b += b0; a += a1; b += b1;
+        }
+        for (; k < chunks; k += 16) { a += part[((long long)k * 2 + 0) * C + c]; b += part[((long long)k * 2 + 1) * C + c]; }
+    }
+    red[0][wave][lane] = a;
+    red[1][wave][lane] = b;
+    __syncthreads();
+    if (wave != 0 || c >= C) return;
+    a = 0.f; b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { a += red[0][w][lane]; b += red[1][w][lane]; }
     sums[c] = a;
     sums[C + c] = b;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;
@@ -312,18 +346,18 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float *__restrict_
 }
 }  // namespace
 
-int bn_chunks(long long rows) { return (int)min((long long)96, max((long long)1, (rows + 255) / 256)); }
+int bn_chunks(long long rows, int C) { return reduce_chunks(rows, C); }
 
 hipError_t launch_bn_lrelu_train_forward(float *zy, long long rows, int cs, int c_off, int C, const float *beta, float *mov_mean,
                                          float *mov_var, float decay, float eps, float *save_mean, float *save_rstd, float *scratch,
                                          hipStream_t stream)
 {
     if ((C & 3) || (cs & 3) || (c_off & 3)) return hipErrorInvalidValue;
-    const int chunks = bn_chunks(rows);                                   // scratch: 2 * chunks * C doubles
+    const int chunks = bn_chunks(rows, C);                                 // scratch: 2 * chunks * C doubles
     const int rpc = (int)((rows + chunks - 1) / chunks);
     double *part = reinterpret_cast<double *>(scratch);
     bn_moments_kernel<<<dim3((unsigned)((C + 63) / 64), (unsigned)chunks), dim3(256), 0, stream>>>(zy, cs, c_off, rows, rpc, C, part);
-    bn_moments_final_kernel<<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream>>>(part, chunks, C, 1.0 / (double)rows, eps, decay,
+    bn_moments_final_kernel<<<dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, stream>>>(part, chunks, C, 1.0 / (double)rows, eps, decay,
                                                                                        save_mean, save_rstd, mov_mean, mov_var);
     const long long n4 = rows * (C / 4);
     bn_lrelu_apply_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream>>>(zy, cs, c_off, C / 4, rows, save_mean, save_rstd, beta);
@@ -334,12 +368,12 @@ hipError_t launch_bn_lrelu_train_backward(const float *y, int cs_y, int cy_off, 
                                           const float *beta, const float *save_rstd, float *dbeta, int accumulate, float *scratch,
                                           hipStream_t stream)
 {
-    const int chunks = bn_chunks(rows);
+    const int chunks = bn_chunks(rows, C);
     const int rpc = (int)((rows + chunks - 1) / chunks);
     bn_bwd_colsum_kernel<<<dim3((unsigned)((C + 63) / 64), (unsigned)chunks), dim3(256), 0, stream>>>(y, cs_y, cy_off, dy, cs_g, cg_off, beta,
                                                                                                    rows, rpc, C, scratch);
     float *sums = scratch + (size_t)2 * chunks * C;                        // scratch: (2 * chunks + 2) * C floats
-    bn_bwd_final_kernel<<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream>>>(scratch, chunks, C, sums, dbeta, accumulate);
+    bn_bwd_final_kernel<<<dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, stream>>>(scratch, chunks, C, sums, dbeta, accumulate);
     const long long n = rows * C;
     bn_lrelu_bwd_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(y, cs_y, cy_off, dy, cs_g, cg_off, C, rows, sums,
                                                                                          beta, save_rstd, 1.0f / (float)rows);

@@ -213,7 +213,18 @@ hipError_t launch_wgrad_pixel_table(int B, int Hi, int Wi, int Cs, int Ho, int W
 int wgrad_choose_split(const WgradParams &p);
 hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream);
 // out[c] (+)= sum over rows of g[row*Cs + c_off + c]
-int column_sum_chunks(long long rows);        // scratch floats needed = column_sum_chunks(rows) * C
+// chunk count of the two-stage column reductions: enough (64-channel block) x (row chunk) workgroups to fill the chip
+// (about three per CU), at least 128 rows per chunk
+inline int reduce_chunks(long long rows, int C)
+{
+    const long long colblocks = C >= 64 ? (C + 63) / 64 : 1;
+    long long n = 768 / colblocks;
+    if (n < 8) n = 8;
+    const long long by_rows = rows / 128;
+    if (n > by_rows) n = by_rows;
+    return (int)(n < 1 ? 1 : n);
+}
+int column_sum_chunks(long long rows, int C);  // scratch floats needed = column_sum_chunks(rows, C) * C
 hipError_t launch_column_sum(const float *g, long long rows, int Cs, int c_off, int C, float *out, int accumulate, float *scratch,
                              hipStream_t stream);
 
@@ -281,8 +292,8 @@ void pack_winograd(const float *W, const double *scale, int cin, int cout, int n
 void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wpk);
 
 // BatchNormLayer(lrelu 0.1, no gamma) in training mode, in place on an NHWC channel slice, and its backward (train_ops.hip).
-// scratch: 2 * bn_chunks(rows) * C floats.
-int bn_chunks(long long rows);
+// scratch: 2 * bn_chunks(rows, C) * C floats.
+int bn_chunks(long long rows, int C);
 hipError_t launch_bn_lrelu_train_forward(float *zy, long long rows, int cs, int c_off, int C, const float *beta, float *mov_mean,
                                          float *mov_var, float decay, float eps, float *save_mean, float *save_rstd, float *scratch,
                                          hipStream_t stream);

@@ -197,35 +197,60 @@ __global__ __launch_bounds__(256) void wgrad_combine_kernel(const float *__restr
 // (64-channel block) x (row chunk) grid of workgroups -- 4 waves striding over the chunk's rows, coalesced 256-byte row
 // reads -- writes one partial per chunk; the second stage adds the chunks in order.
 __global__ __launch_bounds__(256) void column_sum_kernel(const float *__restrict__ g, long long rows, int rows_per_chunk, int Cs,
-                                                         int c_off, int C, float *__restrict__ part)
+                                                         int c_off, int C, int Cp, float *__restrict__ part)
 {
+    // Cp = min(64, next power of two >= C): a wave covers 64 / Cp rows at once, so narrow slices (the 2-channel flow
+    // gradients) still keep every lane busy
     __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int RW = 64 / Cp, sub = lane / Cp;
+    const int c = blockIdx.x * 64 + (lane & (Cp - 1));
     const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     float s0 = 0.f, s1 = 0.f;
     if (c < C) {
-        long long r = r0 + wave;
-        for (; r + 12 < r1; r += 16) {                               // four rows in flight per wave
-            const float v0 = g[r * Cs + c_off + c], v1 = g[(r + 4) * Cs + c_off + c];
-            const float v2 = g[(r + 8) * Cs + c_off + c], v3 = g[(r + 12) * Cs + c_off + c];
+        const long long st = 4LL * RW;
+        long long r = r0 + wave * RW + sub;
+        for (; r + 3 * st < r1; r += 4 * st) {                       // four rows in flight per lane
+            const float v0 = g[r * Cs + c_off + c], v1 = g[(r + st) * Cs + c_off + c];
+            const float v2 = g[(r + 2 * st) * Cs + c_off + c], v3 = g[(r + 3 * st) * Cs + c_off + c];
             s0 += v0; s1 += v1; s0 += v2; s1 += v3;
         }
-        for (; r < r1; r += 4) s0 += g[r * Cs + c_off + c];
+        for (; r < r1; r += st) s0 += g[r * Cs + c_off + c];
     }
-    red[wave][threadIdx.x & 63] = s0 + s1;
+    float s = s0 + s1;
+    for (int off = Cp; off < 64; off <<= 1) s += __shfl_xor(s, off);
+    red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && c < C)
-        part[(long long)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (wave == 0 && lane < Cp && c < C)
+        part[(long long)blockIdx.y * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-__global__ __launch_bounds__(256) void column_sum_final_kernel(const float *__restrict__ part, int chunks, int C, float *__restrict__ out,
-                                                               int accumulate)
+// second stage: one workgroup of 16 waves per 64 channels; wave w adds chunks w, w+16, ... (four loads in flight), the
+// 16 partial sums are then added in wave order -- a fixed order, so the result is reproducible.
+__global__ __launch_bounds__(1024) void column_sum_final_kernel(const float *__restrict__ part, int chunks, int C, float *__restrict__ out,
+                                                                int accumulate)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += part[(long long)k * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        int k = wave;
+        for (; k + 48 < chunks; k += 64) {
+            const float v0 = part[(long long)k * C + c], v1 = part[(long long)(k + 16) * C + c];
+            const float v2 = part[(long long)(k + 32) * C + c], v3 = part[(long long)(k + 48) * C + c];
+            s0 += v0; s1 += v1; s0 += v2; s1 += v3;
+        }
+        for (; k < chunks; k += 16) s0 += part[(long long)k * C + c];
+    }
+    red[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += red[w][lane];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 int wgrad_choose_split(const WgradParams &p)
@@ -271,15 +296,17 @@ hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream)
     return e;
 }
 
-int column_sum_chunks(long long rows) { return (int)std::min<long long>(96, std::max<long long>(1, (rows + 255) / 256)); }
+int column_sum_chunks(long long rows, int C) { return reduce_chunks(rows, C); }
 
 hipError_t launch_column_sum(const float *g, long long rows, int Cs, int c_off, int C, float *out, int accumulate, float *scratch,
                              hipStream_t stream)
 {
-    const int chunks = column_sum_chunks(rows);                          // scratch: chunks * C floats
+    const int chunks = column_sum_chunks(rows, C);                       // scratch: chunks * C floats
     const int rpc = (int)((rows + chunks - 1) / chunks);
-    column_sum_kernel<<<dim3((unsigned)((C + 63) / 64), (unsigned)chunks), dim3(256), 0, stream>>>(g, rows, rpc, Cs, c_off, C, scratch);
-    column_sum_final_kernel<<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream>>>(scratch, chunks, C, out, accumulate);
+    int Cp = 64;
+    while (Cp / 2 >= C && Cp > 1) Cp /= 2;
+    column_sum_kernel<<<dim3((unsigned)((C + 63) / 64), (unsigned)chunks), dim3(256), 0, stream>>>(g, rows, rpc, Cs, c_off, C, Cp, scratch);
+    column_sum_final_kernel<<<dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, stream>>>(scratch, chunks, C, out, accumulate);
     return hipGetLastError();
 }
 
