@@ -85,6 +85,9 @@ EXPORTS = {
     "vstab_lrelu_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p]),
     "vstab_flow_medfilt": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "vstab_flow_mean_fill": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
+    "vstab_loss_main_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "vstab_loss_main": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]),
     "vstab_homography_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "vstab_homography_fit": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_uint, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -100,6 +103,12 @@ EXPORTS = {
     "vstab_host_pack_layer": (C.c_longlong, [C.c_int, C.c_int, c_float_p, C.POINTER(C.c_double), c_float_p,
                                              C.c_longlong]),
 }
+
+class LossLevelDesc(C.Structure):
+    """vstab_loss_level_desc (include/vstab.h)."""
+    _fields_ = [("pf", C.c_void_p), ("grad", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("cs_pf", C.c_int), ("cs_grad", C.c_int),
+                ("tv_weight", C.c_float)]
+
 
 _lib = None
 

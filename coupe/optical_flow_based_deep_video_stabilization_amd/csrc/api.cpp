@@ -1157,6 +1157,39 @@ extern "C" int vstab_loss_level(const float *pf, const float *gt, const float *u
     return VSTAB_OK;
 }
 
+static int loss_main_check(const vstab_loss_level_desc *lv, int n, int B)
+{
+    if (!lv || n < 1 || n > 8 || B < 1) return VSTAB_E_SHAPE;
+    for (int l = 0; l < n; ++l) {
+        if (!lv[l].pf || lv[l].h < 1 || lv[l].w < 1 || lv[l].cs_pf < 2 || (lv[l].cs_pf & 1)) return VSTAB_E_SHAPE;
+        if (lv[l].grad && (lv[l].cs_grad < 2 || (lv[l].cs_grad & 1))) return VSTAB_E_SHAPE;
+        if (((uintptr_t)lv[l].pf | (uintptr_t)lv[l].grad) & 7) return VSTAB_E_ALIGN;
+    }
+    return VSTAB_OK;
+}
+
+extern "C" size_t vstab_loss_main_workspace_bytes(const vstab_loss_level_desc *levels, int n_levels, int B)
+{
+    if (loss_main_check(levels, n_levels, B) != VSTAB_OK) return 0;
+    static_assert(sizeof(vstab_loss_level_desc) == sizeof(LossLevel), "descriptor layout");
+    return loss_main_workspace_bytes(B, reinterpret_cast<const LossLevel *>(levels), n_levels);
+}
+
+extern "C" int vstab_loss_main(const vstab_loss_level_desc *levels, int n_levels, const float *gtstab, const float *unstab, int B, int H,
+                               int W, double *loss_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int c = loss_main_check(levels, n_levels, B);
+    if (c != VSTAB_OK) return fail(nullptr, c, "loss_main: bad level descriptor (1..8 levels, even channel strides >= 2, 8-byte aligned buffers)");
+    if (!gtstab || !unstab || !loss_out || !workspace) return fail(nullptr, VSTAB_E_STATE, "loss_main: NULL buffer");
+    if (H < 1 || W < 1) return fail(nullptr, VSTAB_E_SHAPE, "loss_main: bad image shape");
+    if (((uintptr_t)loss_out | (uintptr_t)workspace) & 7) return fail(nullptr, VSTAB_E_ALIGN, "loss_main: loss_out / workspace must be 8-byte aligned");
+    const LossLevel *lv = reinterpret_cast<const LossLevel *>(levels);
+    if (workspace_bytes < loss_main_workspace_bytes(B, lv, n_levels)) return fail(nullptr, VSTAB_E_NOMEM, "loss_main: workspace too small");
+    void *ws = (void *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    HIP_TRY(nullptr, launch_loss_main(lv, n_levels, gtstab, unstab, B, H, W, loss_out, ws, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_flow_medfilt(const float *flow, int B, int h, int w, int kh, int kw, int kc, float *out, void *stream)
 {
     if (!flow || !out) return fail(nullptr, VSTAB_E_STATE, "flow_medfilt: NULL buffer");

@@ -51,17 +51,22 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 }  // namespace
 
-// pass 1: sums[3*b + 0] += sum (P*M - G*M)^2, sums[3*b + 1] += sum safe(M) (3 channels), sums[3*b + 2] += TV
-__global__ __launch_bounds__(256) void loss_sums_kernel(const float *__restrict__ pf, const float *__restrict__ G,
+// pass 1: sums[3*b + 0] += sum (P*M - G*M)^2, sums[3*b + 1] += sum safe(M) (3 channels), sums[3*b + 2] += TV.
+// pf: [B,h,w,cs_pf] pixels whose first two channels are the flow (cs_pf even).  A workgroup covers LOSS_PPT * 256 pixels, so
+// a full-resolution level issues ~64 atomics per sample and sum instead of ~1000 (they serialise on one address).
+constexpr int LOSS_PPT = 16;
+__global__ __launch_bounds__(256) void loss_sums_kernel(const float *__restrict__ pf, int cs_pf, const float *__restrict__ G,
                                                         const float *__restrict__ U, int h, int w, double *__restrict__ sums)
 {
     const int n = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
     double num = 0.0, den = 0.0, tv = 0.0;
-    if (idx < h * w) {
+    const float *fb = pf + (long long)n * h * w * cs_pf;
+    auto flow = [&](int i) { return *reinterpret_cast<const f32x2 *>(fb + (long long)i * cs_pf); };
+    for (int it = 0; it < LOSS_PPT; ++it) {
+        const int idx = (blockIdx.x * LOSS_PPT + it) * 256 + threadIdx.x;
+        if (idx >= h * w) break;
         const int yy = idx / w, xx = idx - yy * w;
-        const f32x2 *fb = reinterpret_cast<const f32x2 *>(pf) + (long long)n * h * w;
-        const f32x2 f = fb[idx];
+        const f32x2 f = flow(idx);
         const Corners c = corners(xx, yy, f, h, w);
         const float wa = (c.x1f - c.x) * (c.y1f - c.y), wb = (c.x1f - c.x) * (c.y - c.y0f);
         const float wc = (c.x - c.x0f) * (c.y1f - c.y), wd = (c.x - c.x0f) * (c.y - c.y0f);
@@ -76,9 +81,9 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const float *__restrict_
             const float d = P * M - g[ch] * M;
             num += (double)(d * d);
         }
-        den = 3.0 * (double)(M == 0.f ? M + 1e-8f : M);
-        if (yy + 1 < h) { const f32x2 q = fb[idx + w]; tv += (double)fabsf(q.x - f.x) + (double)fabsf(q.y - f.y); }
-        if (xx + 1 < w) { const f32x2 q = fb[idx + 1]; tv += (double)fabsf(q.x - f.x) + (double)fabsf(q.y - f.y); }
+        den += 3.0 * (double)(M == 0.f ? M + 1e-8f : M);
+        if (yy + 1 < h) { const f32x2 q = flow(idx + w); tv += (double)fabsf(q.x - f.x) + (double)fabsf(q.y - f.y); }
+        if (xx + 1 < w) { const f32x2 q = flow(idx + 1); tv += (double)fabsf(q.x - f.x) + (double)fabsf(q.y - f.y); }
     }
     __shared__ double red[3][4];
     num = wave_sum(num); den = wave_sum(den); tv = wave_sum(tv);
@@ -91,18 +96,19 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const float *__restrict_
     }
 }
 
-// pass 2: grad[b,y,x,:] = d( scale_mse * mean_b(num_b/den_b) + scale_tv * TV ) / d pf[b,y,x,:]
-__global__ __launch_bounds__(256) void loss_grad_kernel(const float *__restrict__ pf, const float *__restrict__ G,
+// pass 2: grad[b,y,x,0:2] = d( scale_mse * mean_b(num_b/den_b) + scale_tv * TV ) / d pf[b,y,x,:]   (grad: [B,h,w,cs_g] pixels)
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float *__restrict__ pf, int cs_pf, const float *__restrict__ G,
                                                         const float *__restrict__ U, int B, int h, int w,
                                                         const double *__restrict__ sums, float scale_mse, float scale_tv,
-                                                        float *__restrict__ grad)
+                                                        float *__restrict__ grad, int cs_g)
 {
     const int n = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= h * w) return;
     const int yy = idx / w, xx = idx - yy * w;
-    const f32x2 *fb = reinterpret_cast<const f32x2 *>(pf) + (long long)n * h * w;
-    const f32x2 f = fb[idx];
+    const float *fb = pf + (long long)n * h * w * cs_pf;
+    auto flow = [&](int i) { return *reinterpret_cast<const f32x2 *>(fb + (long long)i * cs_pf); };
+    const f32x2 f = flow(idx);
     const Corners c = corners(xx, yy, f, h, w);
     const float wa = (c.x1f - c.x) * (c.y1f - c.y), wb = (c.x1f - c.x) * (c.y - c.y0f);
     const float wc = (c.x - c.x0f) * (c.y1f - c.y), wd = (c.x - c.x0f) * (c.y - c.y0f);
@@ -125,14 +131,41 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float *__restrict_
     // total variation: d|q - f| / df = -sign(q - f) at this pixel, +sign(f - p) from the neighbour above / to the left
     auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
     float tx = 0.f, ty = 0.f;
-    if (yy + 1 < h) { const f32x2 q = fb[idx + w]; tx -= sgn(q.x - f.x); ty -= sgn(q.y - f.y); }
-    if (xx + 1 < w) { const f32x2 q = fb[idx + 1]; tx -= sgn(q.x - f.x); ty -= sgn(q.y - f.y); }
-    if (yy > 0) { const f32x2 q = fb[idx - w]; tx += sgn(f.x - q.x); ty += sgn(f.y - q.y); }
-    if (xx > 0) { const f32x2 q = fb[idx - 1]; tx += sgn(f.x - q.x); ty += sgn(f.y - q.y); }
+    if (yy + 1 < h) { const f32x2 q = flow(idx + w); tx -= sgn(q.x - f.x); ty -= sgn(q.y - f.y); }
+    if (xx + 1 < w) { const f32x2 q = flow(idx + 1); tx -= sgn(q.x - f.x); ty -= sgn(q.y - f.y); }
+    if (yy > 0) { const f32x2 q = flow(idx - w); tx += sgn(f.x - q.x); ty += sgn(f.y - q.y); }
+    if (xx > 0) { const f32x2 q = flow(idx - 1); tx += sgn(f.x - q.x); ty += sgn(f.y - q.y); }
     f32x2 o;
     o.x = gx + scale_tv * tx;
     o.y = gy + scale_tv * ty;
-    reinterpret_cast<f32x2 *>(grad)[(long long)n * h * w + idx] = o;
+    *reinterpret_cast<f32x2 *>(grad + ((long long)n * h * w + idx) * cs_g) = o;
+}
+
+// loss_main = sum over levels of [ mean_b(num/den) + tv_weight * sum_b TV ]  (main:213-217, 269-275)
+struct LossTotalArgs { float tvw[8]; int n; };
+__global__ void loss_total_kernel(const double *__restrict__ sums, int B, LossTotalArgs a, double *__restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double total = 0.0;
+    for (int l = 0; l < a.n; ++l) {
+        const double *s = sums + (long long)l * 3 * B;
+        double mse = 0.0, tv = 0.0;
+        for (int b = 0; b < B; ++b) { mse += s[3 * b] / s[3 * b + 1]; tv += s[3 * b + 2]; }
+        total += mse / (double)B + (double)a.tvw[l] * tv;
+    }
+    out[0] = total;
+}
+
+static hipError_t loss_level_kernels(const float *pf, int cs_pf, const float *G, const float *U, int B, int h, int w, double *sums,
+                                     float scale_mse, float scale_tv, float *grad, int cs_g, hipStream_t stream)
+{
+    const int npix = h * w;
+    loss_sums_kernel<<<dim3((unsigned)((npix + 256 * LOSS_PPT - 1) / (256 * LOSS_PPT)), (unsigned)B), dim3(256), 0, stream>>>(pf, cs_pf, G, U, h, w,
+                                                                                                                          sums);
+    if (grad)
+        loss_grad_kernel<<<dim3((unsigned)((npix + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(pf, cs_pf, G, U, B, h, w, sums, scale_mse,
+                                                                                                    scale_tv, grad, cs_g);
+    return hipGetLastError();
 }
 
 hipError_t launch_loss_level(const float *pf, const float *G, const float *U, int B, int h, int w, double *sums, float scale_mse,
@@ -140,9 +173,42 @@ hipError_t launch_loss_level(const float *pf, const float *G, const float *U, in
 {
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 3 * (size_t)B, stream);
     if (e != hipSuccess) return e;
-    dim3 grid((unsigned)((h * w + 255) / 256), (unsigned)B);
-    loss_sums_kernel<<<grid, dim3(256), 0, stream>>>(pf, G, U, h, w, sums);
-    if (grad) loss_grad_kernel<<<grid, dim3(256), 0, stream>>>(pf, G, U, B, h, w, sums, scale_mse, scale_tv, grad);
+    return loss_level_kernels(pf, 2, G, U, B, h, w, sums, scale_mse, scale_tv, grad, 2, stream);
+}
+
+size_t loss_main_workspace_bytes(int B, const LossLevel *lv, int n)
+{
+    size_t img = 0;
+    for (int l = 0; l < n; ++l) img = std::max(img, (size_t)B * lv[l].h * lv[l].w * 3 * sizeof(float));
+    img = (img + 255) & ~(size_t)255;
+    return 256 + (((size_t)n * 3 * B * sizeof(double) + 255) & ~(size_t)255) + 2 * img;
+}
+
+// All levels of loss_main in one call: per level the two tf.image.resize_images (main:202-203), the sums and the gradient written
+// straight into the caller's (strided) flow-gradient buffer; then the scalar.  22 launches instead of ~80 through the per-level API.
+hipError_t launch_loss_main(const LossLevel *lv, int n, const float *gtstab, const float *unstab, int B, int H, int W, double *loss_out,
+                            void *workspace, hipStream_t stream)
+{
+    char *p = static_cast<char *>(workspace);
+    double *sums = reinterpret_cast<double *>(p);
+    const size_t sbytes = ((size_t)n * 3 * B * sizeof(double) + 255) & ~(size_t)255;
+    size_t img = 0;
+    for (int l = 0; l < n; ++l) img = std::max(img, (size_t)B * lv[l].h * lv[l].w * 3 * sizeof(float));
+    img = (img + 255) & ~(size_t)255;
+    float *G = reinterpret_cast<float *>(p + sbytes), *U = reinterpret_cast<float *>(p + sbytes + img);
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)n * 3 * B * sizeof(double), stream);
+    if (e != hipSuccess) return e;
+    LossTotalArgs a;
+    a.n = n;
+    for (int l = 0; l < n; ++l) {
+        a.tvw[l] = lv[l].tv_weight;
+        if ((e = launch_resize_bilinear(gtstab, B, H, W, 3, G, lv[l].h, lv[l].w, stream)) != hipSuccess) return e;
+        if ((e = launch_resize_bilinear(unstab, B, H, W, 3, U, lv[l].h, lv[l].w, stream)) != hipSuccess) return e;
+        if ((e = loss_level_kernels(lv[l].pf, lv[l].cs_pf, G, U, B, lv[l].h, lv[l].w, sums + (size_t)l * 3 * B, 1.0f, lv[l].tv_weight, lv[l].grad,
+                                    lv[l].cs_grad, stream)) != hipSuccess)
+            return e;
+    }
+    loss_total_kernel<<<1, 64, 0, stream>>>(sums, B, a, loss_out);
     return hipGetLastError();
 }
 

@@ -231,6 +231,10 @@ hipError_t launch_column_sum(const float *g, long long rows, int Cs, int c_off, 
 // lossterm / masked_MSE / total_variation of one pyramid level and their gradient w.r.t. the flow (train_ops.hip)
 hipError_t launch_loss_level(const float *pf, const float *G, const float *U, int B, int h, int w, double *sums, float scale_mse,
                              float scale_tv, float *grad, hipStream_t stream);
+struct LossLevel { const float *pf; float *grad; int h, w, cs_pf, cs_grad; float tv_weight; };     // = vstab_loss_level_desc
+size_t loss_main_workspace_bytes(int B, const LossLevel *lv, int n);
+hipError_t launch_loss_main(const LossLevel *lv, int n, const float *gtstab, const float *unstab, int B, int H, int W, double *loss_out,
+                            void *workspace, hipStream_t stream);
 hipError_t launch_flow_medfilt(const float *flow, int B, int h, int w, int kh, int kw, int kc, float *out, hipStream_t stream);
 
 // dense-flow homography fit + cv2.warpPerspective on 8-bit frames (homography_ops.hip)

@@ -278,13 +278,9 @@ class Trainer:
     # ------------------------------------------------------------------ loss + backward
     def loss_and_backward(self, gtstab: torch.Tensor, unstab: torch.Tensor) -> torch.Tensor:
         """loss_main (main:213-217, 269-275) and d loss_main / d every trainable tensor (into self.g)."""
-        from .training import lossterm
+        from .training import loss_main_fused
         self._zero_grads()
-        total = None
-        for level, tvw in zip(LOSS_LEVELS, TV_WEIGHTS):
-            l, grad = lossterm(self.pf[level][..., :2].contiguous(), gtstab, unstab, tvw, True)
-            total = l if total is None else total + l
-            self.dpf[level][..., :2].copy_(grad)
+        total = loss_main_fused(self.pf, gtstab, unstab, self.dpf)        # all five levels, gradients straight into dpf[..., :2]
         self._backward()
         return total
 
@@ -299,9 +295,9 @@ class Trainer:
     def _zero_grads(self):
         # the activation gradients are NOT cleared: the first gradient written into each buffer in _backward covers all of its
         # channels and overwrites (self._fresh tracks that), later contributions accumulate
+        # (nor are the flow gradients dpf: channels 0..1 are overwritten by the loss gradient before anything accumulates into
+        # them, channels 2..3 only ever receive zeros)
         self._fresh = set(self.G.keys())
-        for d in self.dpf.values():
-            d.zero_()
 
     def _acc(self, name) -> bool:
         """False for the first write into activation gradient `name` of this backward pass (overwrite), True afterwards."""

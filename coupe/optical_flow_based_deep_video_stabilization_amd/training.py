@@ -55,6 +55,38 @@ def loss_main(outputs: Dict[str, torch.Tensor], gtstab_image, unstab_image, need
     return total, grads
 
 
+def loss_main_fused(flows: Dict[str, torch.Tensor], gtstab_image, unstab_image, grads: Dict[str, torch.Tensor] = None):
+    """loss_main and (optionally) its flow gradients through ONE library call (`vstab_loss_main`).  flows[name]: [B,h,w,C]
+    float32 CUDA pixels whose channels 0..1 are the flow (C even; the Trainer keeps 4-channel pixels); grads[name] (if
+    given): [B,h,w,C'] buffers whose channels 0..1 are overwritten.  Returns the loss as a 0-dim float64 CUDA tensor."""
+    import ctypes as C
+    stab, unstab = _f32(gtstab_image, "stab_image", 3), _f32(unstab_image, "unstab_image", 3)
+    B, H, W, _ = stab.shape
+    if unstab.shape != stab.shape:
+        raise ValueError("stab_image / unstab_image must have the same shape")
+    desc = (_lib.LossLevelDesc * len(LOSS_LEVELS))()
+    for d, name, tvw in zip(desc, LOSS_LEVELS, TV_WEIGHTS):
+        pf = flows[name]
+        if not pf.is_cuda or pf.dtype != torch.float32 or pf.dim() != 4 or pf.shape[0] != B or not pf.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous float32 CUDA tensor [B,h,w,C]")
+        d.pf, d.h, d.w, d.cs_pf, d.tv_weight = pf.data_ptr(), pf.shape[1], pf.shape[2], pf.shape[3], tvw
+        if grads is not None:
+            g = grads[name]
+            if g.shape[:3] != pf.shape[:3] or g.dtype != torch.float32 or not g.is_contiguous() or g.device != pf.device:
+                raise ValueError(f"grads[{name}] must be a contiguous float32 tensor [B,h,w,C'] beside the flow")
+            d.grad, d.cs_grad = g.data_ptr(), g.shape[3]
+    L = _lib.lib()
+    n = L.vstab_loss_main_workspace_bytes(C.addressof(desc), len(LOSS_LEVELS), B)
+    if n == 0:
+        raise ValueError("loss_main: bad level descriptors (channel counts must be even)")
+    ws = torch.empty(n, dtype=torch.uint8, device=stab.device)
+    out = torch.empty((), dtype=torch.float64, device=stab.device)
+    with torch.cuda.device(stab.device):
+        _lib.check(L.vstab_loss_main(C.addressof(desc), len(LOSS_LEVELS), stab.data_ptr(), unstab.data_ptr(), B, H, W, out.data_ptr(),
+                                     ws.data_ptr(), n, runtime.stream_ptr()))
+    return out
+
+
 # ----------------------------------------------------------------------------- backward building blocks
 def conv_wgrad(x, gout, k: int, stride: int, pad: int, cx_off: int = 0, cin: int = None, cg_off: int = 0, cout: int = None,
                dW=None, db=None, accumulate: bool = False, want_db: bool = True):

@@ -220,6 +220,21 @@ VSTAB_API int vstab_axpby(const float *x, float a, const float *y, float b, floa
 VSTAB_API int vstab_loss_level(const float *pf, const float *gt, const float *unstab, int B, int h, int w, double *sums,
                                float scale_mse, float scale_tv, float *grad_pf, void *stream);
 
+/* loss_main (main:213-217, 269-275) over all pyramid levels in one call: per level the two tf.image.resize_images of the
+ * full-size stable / unstable frames [B,H,W,3] to the flow's size (main:202-203), lossterm + the TV term, and (grad != NULL)
+ * d loss_main / d flow written into channels 0..1 of the caller's [B,h,w,cs_grad] buffer.  pf: [B,h,w,cs_pf] pixels whose
+ * channels 0..1 are the flow; channel strides even.  loss_out: one device double = sum over levels of
+ * mean_b(masked_MSE) + tv_weight * TV. */
+typedef struct vstab_loss_level_desc {
+    const float *pf;
+    float *grad;
+    int h, w, cs_pf, cs_grad;
+    float tv_weight;
+} vstab_loss_level_desc;
+VSTAB_API size_t vstab_loss_main_workspace_bytes(const vstab_loss_level_desc *levels, int n_levels, int B);
+VSTAB_API int vstab_loss_main(const vstab_loss_level_desc *levels, int n_levels, const float *gtstab, const float *unstab, int B, int H,
+                              int W, double *loss_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Weight and bias gradient of PadLayer(pad) -> Conv2d(k, stride, VALID) (model.py:807-844; what tf.gradients yields for
  * the filter of tf.nn.conv2d): dW[ky,kx,ci,co] = sum_{n,oy,ox} x[n, s*oy+ky-pad, s*ox+kx-pad, ci] * gout[n,oy,ox,co] in the
  * reference's HWIO layout, db[co] = sum gout (db may be NULL).  x: [B,Hi,Wi,cs_x] using channels cx_off..cx_off+cin;

@@ -33,6 +33,29 @@ def test_loss_main_value_and_gradients(B, H, W, sizes):
         assert float((g - r).abs().max()) <= tol, (k, float((g - r).abs().max()), float(r.abs().max()))
 
 
+@pytest.mark.parametrize("B,H,W,sizes,C", [(2, 64, 96, [(1, 2), (2, 3), (4, 6), (8, 12), (62, 94)], 4),
+                                           (1, 512, 512, [(8, 8), (16, 16), (32, 32), (64, 64), (510, 510)], 2)])
+def test_loss_main_single_call_equals_per_level_calls(B, H, W, sizes, C):
+    """`vstab_loss_main` (all levels, strided C-channel flow pixels, gradients written in place) against the per-level entry
+    point that the oracle test above pins."""
+    gt, un, flows = _case(B, H, W, sizes, seed=31)
+    ref_loss, ref_grads = training.loss_main({k: v.cuda() for k, v in flows.items()}, gt.cuda(), un.cuda())
+    wide = {k: torch.zeros(*v.shape[:3], C).cuda() for k, v in flows.items()}
+    for k, v in flows.items():
+        wide[k][..., :2] = v.cuda()
+    grads = {k: torch.full_like(v, 7.0) for k, v in wide.items()}
+    loss = training.loss_main_fused(wide, gt.cuda(), un.cuda(), grads)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-8 * max(1.0, abs(float(ref_loss)))      # the TV weights travel as float32
+    for k in vo.LOSS_LEVELS:
+        assert torch.equal(grads[k][..., :2], ref_grads[k]), k
+        if C > 2:
+            assert float((grads[k][..., 2:] - 7.0).abs().max()) == 0.0          # the other channels are not touched
+    assert abs(float(training.loss_main_fused(wide, gt.cuda(), un.cuda())) - float(loss)) <= 1e-12      # value only
+    with pytest.raises(ValueError):
+        training.loss_main_fused({k: v[..., :3].contiguous() for k, v in wide.items()} if C > 2 else
+                                 {k: torch.zeros(*v.shape[:3], 3).cuda() for k, v in wide.items()}, gt.cuda(), un.cuda())
+
+
 def test_lossterm_zero_flow_and_far_flow():
     B, h, w = 2, 9, 11
     g = torch.Generator().manual_seed(5)
