@@ -316,7 +316,7 @@ class Trainer:
                                                    self.st))
         dWT = torch.empty((1, 1, 196, 32), dtype=torch.float32, device=self.dev)
         self._wgrad(c2, 0, 196, self.dT, 0, 32, 1, 1, 0, dWT, None)
-        g["predict2/W_conv2d"].zero_()
+        # (the padded output channels of predict2's filter gradient keep the zeros they were created with)
         g["predict2/W_conv2d"][..., :2].copy_(dWT[0, 0, :, :18].reshape(196, 3, 3, 2).permute(1, 2, 0, 3))
         WTt = self.WT[0, 0].t().contiguous().view(1, 1, 32, 196)
         self._conv_fwd(self.dT, 0, 32, WTt, None, 1, 1, 0, G["concat2"], 0, 196, act=3 if self._acc("concat2") else 0)
@@ -329,7 +329,8 @@ class Trainer:
             # deconvN: BatchNorm backward in place on its slice of the concat gradient, then filter / bias / input gradients
             self._bn_bwd(f"{dname}_bn", a[ob], G[ob], ooff, cout)
             self._wgrad(G[ob], ooff, cout, a[ib], 0, cs_in, 4, 2, 1, g[f"{dname}/W_deconv2d"], None)
-            g[f"{dname}/b_deconv2d"].zero_()          # a bias in front of BatchNorm: sum of dz = 0 exactly (sum of xhat = 0)
+            # (b_deconv2d sits in front of BatchNorm: its gradient, the sum of dz, is exactly 0 -- the buffer is created zero and
+            #  never written)
             self._conv_fwd(G[ob], ooff, cout, p[f"{dname}/W_deconv2d"], None, 4, 2, 1, G[ib], 0, cs_in, act=3 if self._acc(ib) else 0)
             # upsample_flowN: its input is this level's flow
             self._wgrad(G[ob], foff, 4, self.pf[level], 0, 4, 4, 2, 1, g[f"{uname}/W_deconv2d"], None)
@@ -347,7 +348,7 @@ class Trainer:
             ob, ooff = ENC_OUT[name]
             self._bn_bwd(name, a[ob], G[ob], ooff, cout)
             self._wgrad(a[ib], ioff, cin, G[ob], ooff, cout, k, s, pad, g[f"{name}/W_conv2d"], None)
-            g[f"{name}/b_conv2d"].zero_()               # same: the batch mean removes the bias, its gradient is exactly zero
+            # (b_conv2d: same -- the batch mean removes the bias, its gradient stays the zero it was created with)
             if ib != "x0":
                 acc = self._acc(ib)
                 if not (k == 3 and s == 1 and self._wino(G[ob], ooff, p[f"{name}/W_conv2d"], True, None, G[ib], ioff, 3 if acc else 0)):

@@ -1,7 +1,8 @@
-"""Training objective of the reference, first slice of SURVEY.md 8f rank 4: `lossterm` / `masked_MSE` (main:188-210,
-"main" = main_flownetS_pyramid_noprevloss_dataloader.py), the total-variation terms and `loss_main` (main:213-275) --
-forward value AND the gradient with respect to every predicted flow, i.e. what the network's backward pass starts
-from.  The backward pass through the network itself and the Adam step (main:333-335) are not built yet.
+"""Building blocks of the training step, one thin wrapper per library entry point: the objective
+`lossterm` / `masked_MSE` (main:188-210, "main" = main_flownetS_pyramid_noprevloss_dataloader.py), the total-variation
+terms and `loss_main` (main:213-275) with their gradient with respect to every predicted flow; filter / input gradients
+of the conv and transposed-conv layers; BatchNorm(lrelu) in training mode and its backward; the resamplers' adjoints.
+`train_step.Trainer` strings them into the whole step (forward, loss, backward, Adam: main:184-185, 333-335).
 
 Everything runs in the HIP library (csrc/train_ops.hip); there is no CPU path."""
 from __future__ import annotations
