@@ -13,15 +13,39 @@
 
 using namespace vstab;
 
+namespace {
+// The weight-gradient kernel's per-output-pixel table depends on the geometry only: built once per (device, geometry) and kept
+// for the life of the process (16 B per output pixel; a training step used to rebuild 23 of them).
+const int4 *wgrad_pixel_table(int B, int Hi, int Wi, int cs_x, int Ho, int Wo, int stride, int pad, hipStream_t st)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int, int, int, int, int>, int4 *> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const auto key = std::make_tuple(dev, B, Hi, Wi, cs_x, Ho, Wo, stride, pad);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int4 *t = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&t), (size_t)B * Ho * Wo * sizeof(int4)) != hipSuccess) return nullptr;
+    // built on the caller's stream and completed before anyone (on any stream) can be handed the cached pointer
+    if (launch_wgrad_pixel_table(B, Hi, Wi, cs_x, Ho, Wo, stride, pad, t, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipFree(t);
+        return nullptr;
+    }
+    cache[key] = t;
+    return t;
+}
+}  // namespace
+
 extern "C" size_t vstab_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int k, int cin, int cout)
 {
     if (B < 1 || Ho < 1 || Wo < 1 || k < 1 || cin < 1 || cout < 1) return 0;
     WgradParams p{};
     p.M = k * k * cin; p.Cout = cout; p.K = B * Ho * Wo;
     const int ks = wgrad_choose_split(p);
-    const size_t ptab = ((size_t)p.K * sizeof(int4) + 255) / 256 * 256;
     const size_t slabs = ((ks > 1 ? (size_t)ks * p.M * cout * sizeof(float) : 0) + 255) / 256 * 256;
-    return ptab + slabs + (size_t)column_sum_chunks(p.K, cout) * cout * sizeof(float) + 256;
+    return slabs + (size_t)column_sum_chunks(p.K, cout) * cout * sizeof(float) + 256;
 }
 
 extern "C" int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *gout, int Ho,
@@ -54,10 +78,9 @@ extern "C" int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x,
     p.Cs_g = cs_g; p.cg_off = cg_off; p.Cout = cout; p.M = k * k * cin; p.K = B * Ho * Wo;
     p.accumulate = accumulate ? 1 : 0;
     p.ksplit = wgrad_choose_split(p);
-    int4 *ptab = reinterpret_cast<int4 *>(workspace);
-    p.ptab = ptab;
-    p.partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + ((size_t)p.K * sizeof(int4) + 255) / 256 * 256);
-    HIP_TRY(nullptr, launch_wgrad_pixel_table(B, Hi, Wi, cs_x, Ho, Wo, stride, pad, ptab, st));
+    p.ptab = wgrad_pixel_table(B, Hi, Wi, cs_x, Ho, Wo, stride, pad, st);
+    if (!p.ptab) return fail(nullptr, VSTAB_E_NOMEM, "conv_wgrad: cannot build the pixel table");
+    p.partial = reinterpret_cast<float *>(workspace);
     HIP_TRY(nullptr, launch_wgrad(p, st));
     if (db) {
         const size_t slabs = ((p.ksplit > 1 ? (size_t)p.ksplit * p.M * cout * sizeof(float) : 0) + 255) / 256 * 256;

@@ -240,7 +240,9 @@ VSTAB_API int vstab_loss_main(const vstab_loss_level_desc *levels, int n_levels,
  * reference's HWIO layout, db[co] = sum gout (db may be NULL).  x: [B,Hi,Wi,cs_x] using channels cx_off..cx_off+cin;
  * gout: [B,Ho,Wo,cs_g] using channels cg_off..cg_off+cout; all channel counts / strides / offsets multiples of 4.
  * accumulate != 0 adds to dW / db instead of overwriting.  With x = the output gradient and gout = the input of a
- * 4x4 stride-2 SAME transposed conv (k 4, stride 2, pad 1) the result is that layer's [4,4,cout,cin] filter gradient. */
+ * 4x4 stride-2 SAME transposed conv (k 4, stride 2, pad 1) the result is that layer's [4,4,cout,cin] filter gradient.
+ * The first call for a geometry builds a 16 B-per-output-pixel table on the device (and synchronises the stream once); it is
+ * kept for the life of the process. */
 VSTAB_API size_t vstab_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int k, int cin, int cout);
 VSTAB_API int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *gout, int Ho,
                                int Wo, int cs_g, int cg_off, int cout, int k, int stride, int pad, float *dW, float *db,
