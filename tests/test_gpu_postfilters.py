@@ -132,3 +132,15 @@ def test_warp_perspective_u8_matches_oracle(sh, sw, oh, ow):
     assert np.array_equal(same.cpu().numpy(), img)
     with pytest.raises(ValueError):
         pf.warp_perspective_u8(torch.from_numpy(img).cuda(), eye.float())
+
+
+def test_homography_fit_still_camera_and_batch():
+    """A zero flow is the identity with every pixel in the consensus set; samples of a batch are fitted independently."""
+    z = torch.zeros(2, 40, 50, 2, device="cuda")
+    z[1, ..., 0] = 1.0
+    Hm, n = pf.find_homography(z, K=8)
+    assert n.tolist() == [2000, 2000]
+    eye = torch.eye(3, dtype=torch.float64)
+    assert float((Hm[0].cpu() - eye).abs().max()) < 1e-12
+    shift = eye.clone(); shift[0, 2] = -1.0
+    assert float((Hm[1].cpu() - shift).abs().max()) < 1e-12
