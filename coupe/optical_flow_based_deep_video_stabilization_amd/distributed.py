@@ -112,6 +112,42 @@ class GradBucket:
                 numel *= int(s)
             self.views[name] = self.flat[self.offsets[name]:self.offsets[name] + numel].view(tuple(shape))
 
+    def span(self, first: str, last: str):
+        """[lo, hi) element range of the flat buffer that holds tensors `first` .. `last` (in the bucket's own order)."""
+        names = list(self.offsets)
+        i, j = names.index(first), names.index(last)
+        if j < i:
+            raise ValueError("span: `last` comes before `first`")
+        hi = self.offsets[names[j + 1]] if j + 1 < len(names) else self.flat.numel()
+        return self.offsets[first], hi
+
+    def allreduce_range_start(self, lo: int, hi: int, group=None, single_rank_ok: bool = False):
+        """Start averaging flat[lo:hi] over the process group WITHOUT waiting for it: the collective is ordered after the work
+        already queued on the current stream (the kernels that produced those gradients) and runs beside whatever is queued
+        next -- the way a backward pass overlaps the exchange of finished gradient buckets with the layers still to come.
+        Returns a handle for `allreduce_finish` (None without a process group or with a single rank -- unless
+        `single_rank_ok`, which issues the collective anyway so that the path can be exercised on one GPU)."""
+        if not dist.is_available() or not dist.is_initialized():
+            return None
+        world = dist.get_world_size(group)
+        if (world == 1 and not single_rank_ok) or hi <= lo:
+            return None
+        seg = self.flat[lo:hi]
+        if hasattr(dist.ReduceOp, "AVG") and seg.is_cuda:
+            return (dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=group, async_op=True), None, 1.0)
+        return (dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=group, async_op=True), seg, 1.0 / world)      # gloo: no AVG
+
+    @staticmethod
+    def allreduce_finish(handles):
+        """Wait for the collectives started by `allreduce_range_start` (on CUDA: makes the current stream wait for them)."""
+        for h in handles:
+            if h is None:
+                continue
+            work, seg, scale = h
+            work.wait()
+            if seg is not None:
+                seg.mul_(scale)
+
     def allreduce_mean(self, group=None, async_op: bool = False):
         """flat <- mean over ranks.  No-op without an initialised process group or with a single rank."""
         if not dist.is_available() or not dist.is_initialized():

@@ -77,6 +77,13 @@ class Trainer:
         # Trainable parameters, their gradients and the two Adam moments each live in ONE flat buffer with identical offsets
         # (views per tensor): Adam is a single launch over 38.7 M elements, and data-parallel replicas average the gradients with a
         # single all-reduce.  The BatchNorm moving statistics get a bucket of their own so that replicas can average them too.
+        # The buffers are laid out in the order the backward pass COMPLETES the gradients (head, decoder fine to coarse, encoder last
+        # stage first), so that a finished stretch of the backward pass is one contiguous range that can go on the wire (three
+        # overlapped all-reduces, see _grads_ready) while the remaining layers are still being differentiated.
+        order = self._backward_order()
+        if set(order) != set(self.trainable):
+            raise ValueError("weights do not hold the tensors of flownetS_pyramid: " + ", ".join(sorted(set(order) ^ set(self.trainable))))
+        self.trainable = order
         shapes = {k: self._padded_shape(k, self.shape_real[k]) for k in self.trainable}
         self.pbucket, self.gbucket = GradBucket(shapes, self.dev), GradBucket(shapes, self.dev)
         self.mbucket, self.vbucket = GradBucket(shapes, self.dev), GradBucket(shapes, self.dev)
@@ -89,6 +96,8 @@ class Trainer:
                 self.p[k] = _pad_to(host[k].to(self.dev), self._padded_shape(k, self.shape_real[k])).contiguous()
         self.sbucket = GradBucket({k: tuple(self.p[k].shape) for k in self.p if "moving_" in k}, self.dev)
         self.t = 0
+        self._dp_group, self._dp_handles, self._dp_sent = False, [], 0      # False: no exchange in flight (None is a valid group)
+        self.overlap_single_rank = False      # tests: run the overlapped exchange even when the process group has one rank
         self.wino_min_flops = 3.0e9           # a 3x3 stride-1 stage runs in Winograd form once its GEMM issues this much
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.dev)
         self._alloc_buffers()
@@ -111,6 +120,29 @@ class Trainer:
         return {k: t[tuple(slice(0, s) for s in self.shape_real[k])].contiguous().cpu().numpy() for k, t in src.items()}
 
     # ------------------------------------------------------------------ buffers
+    @staticmethod
+    def _backward_order():
+        """Trainable tensors in the order _backward finishes their gradients."""
+        order = ["predict2/b_conv2d", "predict2/W_conv2d"]
+        for dname, _ib, _cin, _ob, _ooff, _cout, pname, uname, _foff in reversed(DEC):
+            order += [f"{dname}_bn/beta", f"{dname}/W_deconv2d", f"{dname}/b_deconv2d", f"{uname}/W_deconv2d", f"{uname}/b_deconv2d",
+                      f"{pname}/W_conv2d", f"{pname}/b_conv2d"]
+        for name, _k, _s, _pad, _cout in reversed(ENC):
+            order += [f"{name}/beta", f"{name}/W_conv2d", f"{name}/b_conv2d"]
+        return order
+
+    # the three gradient buckets of the overlapped exchange: everything up to and including the named tensor (backward order)
+    BUCKET_ENDS = ("predict6/b_conv2d", "4/b_conv2d", "1/b_conv2d")         # decoder | conv6_1..conv4 (2/3 of the weights) | conv3_1..conv1
+
+    def _grads_ready(self, last: str):
+        """Called by _backward when every gradient up to `last` is final: under data parallelism, start that range's all-reduce."""
+        if self._dp_group is False:
+            return
+        lo = self._dp_sent
+        _lo, hi = self.gbucket.span(self.trainable[0], last)
+        self._dp_handles.append(self.gbucket.allreduce_range_start(lo, hi, self._dp_group, self.overlap_single_rank))
+        self._dp_sent = hi
+
     def _alloc_buffers(self):
         B, H, W = self.B, self.H, self.W
         hw = {"x0": (H, W), "conv1": self.sizes[0], "concat2": self.sizes[1], "conv3": self.sizes[2], "concat3": self.sizes[3],
@@ -342,6 +374,7 @@ class Trainer:
             pin, _ = PRED_IN[pname]
             self._wgrad(a[pin], 0, a[pin].shape[3], self.dpf[level], 0, 4, 3, 1, 1, g[f"{pname}/W_conv2d"], g[f"{pname}/b_conv2d"])
             self._convT(self.dpf[level], 0, 4, p[f"{pname}/W_conv2d"], None, 3, 1, 1, G[pin], 0, a[pin].shape[3], self._acc(pin))
+        self._grads_ready(self.BUCKET_ENDS[0])
         # encoder, last stage first
         for name, k, s, pad, cout in reversed(ENC):
             ib, ioff, cin = ENC_IN[name]
@@ -353,6 +386,8 @@ class Trainer:
                 acc = self._acc(ib)
                 if not (k == 3 and s == 1 and self._wino(G[ob], ooff, p[f"{name}/W_conv2d"], True, None, G[ib], ioff, 3 if acc else 0)):
                     self._convT(G[ob], ooff, cout, p[f"{name}/W_conv2d"], None, k, s, pad, G[ib], ioff, cin, acc)
+            if f"{name}/b_conv2d" in self.BUCKET_ENDS:
+                self._grads_ready(f"{name}/b_conv2d")
 
     # ------------------------------------------------------------------ Adam (main:333-335)
     def adam(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
@@ -363,13 +398,21 @@ class Trainer:
                                            self.vbucket.flat.data_ptr(), self.pbucket.flat.numel(), lr_t, beta1, beta2, eps, self.st))
 
     def sync_replicas(self, group=None):
-        """Data-parallel exchange (no-op on one rank): gradients averaged with ONE all-reduce of the flat bucket, BatchNorm
+        """Data-parallel exchange (no-op on one rank): gradients averaged over the replicas -- inside step() in three ranges of the
+        flat bucket whose all-reduces were started during the backward pass and are only waited for here; called on its own,
+        with ONE all-reduce of the whole bucket -- and BatchNorm
         moving statistics averaged the same way (each replica normalises with its own batch statistics, as the reference's
         single-GPU graph would on that shard)."""
         import torch.distributed as dist
-        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not self._dp_handles):
             return
-        self.gbucket.allreduce_mean(group)
+        if self._dp_handles:                       # step(): the buckets went out during the backward pass
+            GradBucket.allreduce_finish(self._dp_handles)
+            if self._dp_sent != self.gbucket.flat.numel():
+                raise RuntimeError("overlapped gradient exchange did not cover the whole bucket")
+            self._dp_handles, self._dp_sent = [], 0
+        else:
+            self.gbucket.allreduce_mean(group)
         for k, v in self.sbucket.views.items():
             v.copy_(self.p[k])
         self.sbucket.allreduce_mean(group)
@@ -394,9 +437,15 @@ class Trainer:
     def step(self, feats, gtstab, unstab, lr: float, beta1: float = 0.9, group=None):
         """One optimiser step; returns this rank's loss_main evaluated before the update (what
         `sess.run([loss_main, optim_main])` prints).  Under torch.distributed the replicas' gradients are averaged first."""
+        import torch.distributed as dist
+        parallel = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.overlap_single_rank)
         with torch.cuda.device(self.dev):
             self.forward(feats)
-            loss = self.loss_and_backward(gtstab, unstab)
+            self._dp_group, self._dp_handles, self._dp_sent = (group if parallel else False), [], 0
+            try:
+                loss = self.loss_and_backward(gtstab, unstab)      # finished gradient buckets go on the wire as it proceeds
+            finally:
+                self._dp_group = False
             self.sync_replicas(group)
             self.adam(lr, beta1)
         return loss

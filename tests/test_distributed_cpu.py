@@ -85,6 +85,15 @@ def _bucket_worker(rank, world, port, q):
         ok = all(torch.allclose(v, torch.full_like(v, mean_rank * (i + 1))) for i, (k, v) in enumerate(b.views.items()))
         ok = ok and b.views["a/W"].shape == (3, 3, 4, 8) and b.offsets["a/b"] % 4 == 0 and b.offsets["c/beta"] % 4 == 0
         ok = ok and b.views["a/b"].data_ptr() == b.flat.data_ptr() + 4 * b.offsets["a/b"]       # views alias the flat buffer
+        # the overlapped exchange: two ranges started one after the other (the second while the first is in flight), finished together
+        for i, (k, v) in enumerate(b.views.items()):
+            v.fill_(float(rank + 1) * (i + 1))
+        lo, mid = b.span("a/W", "a/W")
+        mid2, hi = b.span("a/b", "c/beta")
+        ok = ok and lo == 0 and mid == mid2 == b.offsets["a/b"] and hi == b.flat.numel()
+        handles = [b.allreduce_range_start(lo, mid), b.allreduce_range_start(mid, hi)]
+        vd.GradBucket.allreduce_finish(handles)
+        ok = ok and all(torch.allclose(v, torch.full_like(v, mean_rank * (i + 1))) for i, (k, v) in enumerate(b.views.items()))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -108,3 +117,6 @@ def test_grad_bucket_without_process_group_is_a_noop():
     b = vd.GradBucket({"x": (2, 3)}, "cpu")
     b.views["x"].fill_(2.0)
     assert b.allreduce_mean() is None and float(b.flat[:6].sum()) == 12.0
+    assert b.allreduce_range_start(0, 6) is None
+    vd.GradBucket.allreduce_finish([None])
+    assert b.span("x", "x") == (0, b.flat.numel())

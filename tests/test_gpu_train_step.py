@@ -161,3 +161,40 @@ def test_flownetS_pyramid_is_train_true_and_sync_back():
     assert float((inf["predict_flow2"].double().cpu() - ref2["predict_flow2"]).abs().max()) <= 1e-3
     with pytest.raises(RuntimeError):
         train_step.get_trainer("no_such_scope", B, H, W)
+
+
+def test_overlapped_gradient_exchange_on_one_rank():
+    """step() under a (single-rank) RCCL process group with the overlapped exchange forced on: three all-reduces of bucket ranges
+    are issued during the backward pass and waited for before Adam; averaging over one rank changes nothing, so the parameters
+    after two steps must equal those of a Trainer stepping without a process group, bit for bit."""
+    import os
+    import torch.distributed as dist
+    B, H, W = 1, 96, 128
+    w = wts.synthetic_weights(seed=7, cin=27, random_bn=False, flow_gain=0.2)
+    g0 = torch.Generator().manual_seed(2)
+    feats = torch.rand(B, H, W, 27, generator=g0).cuda()
+    gt, un = torch.rand(B, H, W, 3, generator=g0).cuda(), torch.rand(B, H, W, 3, generator=g0).cuda()
+    ref = train_step.Trainer(w, B, H, W)
+    ref_losses = [float(ref.step(feats, gt, un, lr=1e-4)) for _ in range(2)]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        tr = train_step.Trainer(w, B, H, W)
+        tr.overlap_single_rank = True
+        sent = []
+        orig = tr.gbucket.allreduce_range_start
+        tr.gbucket.allreduce_range_start = lambda lo, hi, group=None, single_rank_ok=False: (sent.append((lo, hi)), orig(lo, hi, group, single_rank_ok))[1]
+        losses = [float(tr.step(feats, gt, un, lr=1e-4)) for _ in range(2)]
+        torch.cuda.synchronize()
+    finally:
+        if own:
+            dist.destroy_process_group()
+    assert losses == ref_losses
+    assert torch.equal(tr.pbucket.flat, ref.pbucket.flat)
+    assert len(sent) == 6 and sent[0][0] == 0 and sent[2][1] == tr.gbucket.flat.numel()            # three ranges per step, gap-free
+    assert sent[0][1] == sent[1][0] and sent[1][1] == sent[2][0]
+    # the middle range (conv6_1 .. conv4) carries most of the 38.7 M parameters
+    assert sent[1][1] - sent[1][0] > 0.5 * tr.gbucket.flat.numel()
