@@ -176,6 +176,39 @@ void set_ranges(ConvParams &p)
     p.w_bytes = (unsigned)std::min<long long>((long long)p.KH * p.NSEG * (p.SEGP / 32) * p.Npad * 128, 0xFFFFFFFFLL);
 }
 
+// The 16-phase 1x1 GEMM over Winograd-transformed tiles (winograd_ops.hip): V [B][16][TH*TW][cin] -> M [B][16][TH*TW][cout]
+void fill_wino_gemm(ConvParams &p, int B, int H, int W, int cin, int cout)
+{
+    std::memset(&p, 0, sizeof p);
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    p.B = B; p.Hi = 16 * TH; p.Wi = TW; p.Cs_in = cin;
+    const KLayout L = klayout_run(1, 1, cin);
+    set_layout(p, L);
+    p.s_in = 1; p.s_out = 1; p.Ho = 16 * TH; p.Wo = TW; p.Cs_out = cout; p.c_off = 0;
+    p.N = cout; p.Npad = cout; p.act = 0; p.nphase = 16;
+    const size_t phase_floats = (size_t)L.ktiles() * p.Npad * 32;
+    for (int xi = 0; xi < 16; ++xi) {
+        ConvPhase &ph = p.ph[xi];
+        ph.Hg = TH; ph.Wg = TW; ph.M = B * TH * TW;
+        ph.off_y = xi * TH; ph.off_x = 0; ph.o_y = xi * TH; ph.o_x = 0;
+        ph.w_off = (long long)xi * phase_floats;
+    }
+    p.Mmax = B * TH * TW;
+    set_ranges(p);
+    p.ksplit = 1;
+}
+
+// does a 3x3 stride-1 pad-1 layer run in Winograd form?  Two extra HBM passes and two more launches: pays once the Winograd-domain
+// GEMM issues a few GFLOP (measured: B=8 512x512 every encoder stage gains, 20..96 us; B=1 384x512 (1.6 GFLOP per stage) loses 2..5 %)
+bool wino_applies(int B, int H, int W, int cin, int cout)
+{
+    static const bool wino_on = getenv("VSTAB_NO_WINOGRAD") == nullptr;
+    if (!wino_on || (cin & 31) || (cout & 127)) return false;                  // whole K tiles, 128x64 output tiles
+    const long long TH = (H + 1) / 2, TW = (W + 1) / 2;
+    if ((long long)B * 16 * TH * TW * std::max(cin, cout) * 4 >= 0x80000000LL) return false;
+    return 32.0 * B * TH * TW * cin * cout >= 3.0e9;
+}
+
 namespace {
 bool make_plan(int B, int H, int W, int Cin, Plan &pl)
 {
@@ -239,44 +272,21 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
     }
     // ---- Winograd form of the 3x3 stride-1 stages: a 16-phase 1x1 GEMM over the transformed tiles (winograd_ops.hip)
-    static const bool wino_on = getenv("VSTAB_NO_WINOGRAD") == nullptr;
     size_t wino_v = 0, wino_m = 0;
     for (int i = 0; i < 10; ++i) {
         pl.wino[i] = false;
         const Enc &e = ENC[i];
-        if (!wino_on || e.k != 3 || e.s != 1 || e.p != 1) continue;
+        if (e.k != 3 || e.s != 1 || e.p != 1) continue;
         const int cin_i = ENC[i - 1].cout;
-        if (ENC_IO[i].cs_in != cin_i || (cin_i & 31) || (e.cout & 127)) continue;      // plain input buffer, whole K tiles
+        if (ENC_IO[i].cs_in != cin_i || !wino_applies(B, pl.eh[i], pl.ew[i], cin_i, e.cout)) continue;      // plain input buffer
         const int TH = (pl.eh[i] + 1) / 2, TW = (pl.ew[i] + 1) / 2;
-        const long long vfl = (long long)B * 16 * TH * TW * cin_i, mfl = (long long)B * 16 * TH * TW * e.cout;
-        if (vfl * 4 >= 0x80000000LL || mfl * 4 >= 0x80000000LL) continue;
-        // two extra HBM passes and two more launches: pays once the Winograd-domain GEMM issues a few GFLOP (measured: B=8 512x512
-        // every stage gains, 20..96 us; B=1 384x512 (1.6 GFLOP per stage) loses 2..5 %)
-        if (32.0 * B * TH * TW * cin_i * e.cout < 3.0e9) continue;
-        ConvParams &p = pl.wcp[i];
-        std::memset(&p, 0, sizeof p);
-        p.B = B; p.Hi = 16 * TH; p.Wi = TW; p.Cs_in = cin_i;
-        const KLayout L = klayout_run(1, 1, cin_i);
-        set_layout(p, L);
-        p.s_in = 1; p.s_out = 1; p.Ho = 16 * TH; p.Wo = TW; p.Cs_out = e.cout; p.c_off = 0;
-        p.N = e.cout; p.Npad = e.cout; p.act = 0; p.nphase = 16;
-        const size_t phase_floats = (size_t)L.ktiles() * p.Npad * 32;
-        for (int xi = 0; xi < 16; ++xi) {
-            ConvPhase &ph = p.ph[xi];
-            ph.Hg = TH; ph.Wg = TW; ph.M = B * TH * TW;
-            ph.off_y = xi * TH; ph.off_x = 0; ph.o_y = xi * TH; ph.o_x = 0;
-            ph.w_off = (long long)xi * phase_floats;
-        }
-        p.Mmax = B * TH * TW;
-        set_ranges(p);
+        fill_wino_gemm(pl.wcp[i], B, pl.eh[i], pl.ew[i], cin_i, e.cout);
         // 128x64 tiles: the reduction is short (K = C_in: 8..32 K-tiles), so prologue and epilogue weigh in and THREE co-resident
         // workgroups per CU (48 KB of LDS each) overlap them better than two 128x128 ones (measured: 181 -> 176, 154 -> 149,
         // 50 -> 45.5 us; a 128x256 tile with one workgroup per CU: 227 / 177 / 88 us)
         pl.wtile[i] = TILE_128x64;
-        p.ksplit = 1;
-        if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad);
-        wino_v = std::max(wino_v, (size_t)vfl);
-        wino_m = std::max(wino_m, (size_t)mfl);
+        wino_v = std::max(wino_v, (size_t)B * 16 * TH * TW * cin_i);
+        wino_m = std::max(wino_m, (size_t)B * 16 * TH * TW * e.cout);
         pl.wino[i] = true;
     }
     pl.bytes[B_WINO_V] = wino_v * 4;
@@ -962,17 +972,22 @@ bool fill_plain_conv(ConvParams &p, ConvTile &tile, bool &vec4, int B, int Hi, i
 }
 
 namespace {
-struct VggPlan { int h[18], w[18], c[18]; size_t partial_floats; };
+struct VggPlan { int h[18], w[18], c[18]; size_t partial_floats, wino_v, wino_m; bool wino[13]; };
 
 bool vgg_plan(int B, int H, int W, VggPlan &v)
 {
     if (B < 1 || H < 1 || W < 1) return false;
     int h = H, w = W, o = 0;
-    v.partial_floats = 0;
+    v.partial_floats = v.wino_v = v.wino_m = 0;
     for (int l = 0; l < 13; ++l) {
         ConvParams p; ConvTile t; bool vec;
         if (!fill_plain_conv(p, t, vec, B, h, w, VGG[l].cin, VGG[l].cin, 3, 1, 1, VGG[l].cout, VGG[l].cout, 0, 2)) return false;
-        if (p.ksplit > 1) v.partial_floats = std::max(v.partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
+        v.wino[l] = VGG[l].cin >= 256 && wino_applies(B, h, w, VGG[l].cin, VGG[l].cout);     // conv3_2 .. conv5_3 when the level is large enough
+        if (v.wino[l]) {
+            const size_t tiles = (size_t)B * 16 * ((h + 1) / 2) * ((w + 1) / 2);
+            v.wino_v = std::max(v.wino_v, tiles * VGG[l].cin);
+            v.wino_m = std::max(v.wino_m, tiles * VGG[l].cout);
+        } else if (p.ksplit > 1) v.partial_floats = std::max(v.partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
         v.h[o] = h; v.w[o] = w; v.c[o] = VGG[l].cout; ++o;
         if (VGG[l].pool_after) {
             h = (h + 1) / 2; w = (w + 1) / 2;
@@ -980,6 +995,12 @@ bool vgg_plan(int B, int H, int W, VggPlan &v)
         }
     }
     return true;
+}
+
+size_t vgg_ws_bytes(const VggPlan &v)       // [split-K slabs | Winograd V | Winograd M], each 256-byte aligned
+{
+    auto a256 = [](size_t n) { return (n + 255) / 256 * 256; };
+    return a256(std::max<size_t>(v.partial_floats * 4, 256)) + a256(v.wino_v * 4) + a256(v.wino_m * 4);
 }
 
 int vgg_max_chunk(int B, int H, int W)
@@ -1008,7 +1029,7 @@ extern "C" size_t vstab_vgg16_workspace_bytes(int B, int H, int W)
     const int chunk = B >= 1 ? vgg_max_chunk(B, H, W) : 0;
     VggPlan v;
     if (chunk < 1 || !vgg_plan(chunk, H, W, v)) { fail(nullptr, VSTAB_E_SHAPE, "vgg16: unsupported problem %dx%dx%d", B, H, W); return 0; }
-    return std::max<size_t>(v.partial_floats * 4, 256);
+    return vgg_ws_bytes(v);
 }
 
 extern "C" int vstab_vgg16_load(vstab_ctx *ctx, const vstab_tensor *t, int count)
@@ -1018,6 +1039,7 @@ extern "C" int vstab_vgg16_load(vstab_ctx *ctx, const vstab_tensor *t, int count
     std::vector<float> host;
     auto reserve = [&](size_t n) { size_t o = (host.size() + 63) / 64 * 64; host.resize(o + n, 0.f); return o; };
     std::vector<double> ones;
+    ctx->vgg_zero = reserve(1024);              // zero bias for the Winograd-domain GEMMs (the inverse transform adds the real one)
     for (int l = 0; l < 13; ++l) {
         const std::string n = VGG[l].name;
         const vstab_tensor *W = find(t, count, n + "/filter"), *b = find(t, count, n + "/biases");
@@ -1030,6 +1052,11 @@ extern "C" int vstab_vgg16_load(vstab_ctx *ctx, const vstab_tensor *t, int count
         fold_bn(b->data, nullptr, nullptr, nullptr, VGG[l].cout, npad, ones.data(), host.data() + ctx->vgg_b[l]);
         ctx->vgg_w[l] = reserve((size_t)L.ktiles() * npad * 32);
         pack_conv(W->data, ones.data(), 3, 3, VGG[l].cin, VGG[l].cin, VGG[l].cout, npad, L, host.data() + ctx->vgg_w[l]);
+        ctx->vgg_wino_w[l] = 0;
+        if (VGG[l].cin >= 256) {                       // Winograd-domain operand for the layers that may run in that form
+            ctx->vgg_wino_w[l] = reserve((size_t)16 * (VGG[l].cin / 32) * VGG[l].cout * 32);
+            pack_winograd(W->data, ones.data(), VGG[l].cin, VGG[l].cout, VGG[l].cout, host.data() + ctx->vgg_wino_w[l]);
+        }
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->vgg_weights) { (void)hipFree(ctx->vgg_weights); ctx->vgg_weights = nullptr; }
@@ -1054,8 +1081,11 @@ extern "C" int vstab_vgg16_forward(vstab_ctx *ctx, const float *input, int B, in
     const int nchunks = (B + cmax - 1) / cmax, chunk = (B + nchunks - 1) / nchunks;
     VggPlan v;
     if (!vgg_plan(chunk, H, W, v)) return fail(ctx, VSTAB_E_SHAPE, "vgg16_forward: plan failed");
-    if (workspace_bytes < v.partial_floats * 4) return fail(ctx, VSTAB_E_NOMEM, "vgg16_forward: workspace %zu < %zu bytes", workspace_bytes, v.partial_floats * 4);
+    if (workspace_bytes < vgg_ws_bytes(v)) return fail(ctx, VSTAB_E_NOMEM, "vgg16_forward: workspace %zu < %zu bytes", workspace_bytes, vgg_ws_bytes(v));
+    if ((uintptr_t)workspace & 255) return fail(ctx, VSTAB_E_ALIGN, "vgg16_forward: workspace must be 256-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
+    float *wsV = reinterpret_cast<float *>(static_cast<char *>(workspace) + (std::max<size_t>(v.partial_floats * 4, 256) + 255) / 256 * 256);
+    float *wsM = reinterpret_cast<float *>(reinterpret_cast<char *>(wsV) + (v.wino_v * 4 + 255) / 256 * 256);
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int bc = std::min(chunk, B - b0);
         const float *cur = input + (size_t)b0 * H * W * 3;
@@ -1065,9 +1095,18 @@ extern "C" int vstab_vgg16_forward(vstab_ctx *ctx, const float *input, int B, in
             if (!fill_plain_conv(p, tile, vec, bc, h, w, VGG[l].cin, VGG[l].cin, 3, 1, 1, VGG[l].cout, VGG[l].cout, 0, 2))
                 return fail(ctx, VSTAB_E_SHAPE, "vgg16_forward: layer %s does not fit", VGG[l].name);
             float *dst = outs[o] + (size_t)b0 * v.h[o] * v.w[o] * v.c[o];
-            p.in = cur; p.out = dst; p.wpk = ctx->vgg_weights + ctx->vgg_w[l]; p.bias = ctx->vgg_weights + ctx->vgg_b[l];
-            p.partial = (float *)workspace;
-            HIP_TRY(ctx, launch_conv(p, tile, vec, stream));
+            if (v.wino[l] && wino_applies(bc, h, w, VGG[l].cin, VGG[l].cout)) {      // (a short last chunk may fall below the break-even)
+                ConvParams q;
+                fill_wino_gemm(q, bc, h, w, VGG[l].cin, VGG[l].cout);
+                HIP_TRY(ctx, launch_wino_input(cur, bc, h, w, VGG[l].cin, 0, VGG[l].cin, wsV, stream));
+                q.in = wsV; q.out = wsM; q.wpk = ctx->vgg_weights + ctx->vgg_wino_w[l]; q.bias = ctx->vgg_weights + ctx->vgg_zero;
+                HIP_TRY(ctx, launch_conv(q, TILE_128x64, true, stream));
+                HIP_TRY(ctx, launch_wino_output(wsM, bc, h, w, VGG[l].cout, ctx->vgg_weights + ctx->vgg_b[l], 2, dst, VGG[l].cout, 0, stream));
+            } else {
+                p.in = cur; p.out = dst; p.wpk = ctx->vgg_weights + ctx->vgg_w[l]; p.bias = ctx->vgg_weights + ctx->vgg_b[l];
+                p.partial = (float *)workspace;
+                HIP_TRY(ctx, launch_conv(p, tile, vec, stream));
+            }
             cur = dst; ++o;
             if (VGG[l].pool_after) {
                 float *pd = outs[o] + (size_t)b0 * v.h[o] * v.w[o] * v.c[o];

@@ -39,6 +39,8 @@ struct vstab_ctx {
     bool vgg_loaded = false;
     float *vgg_weights = nullptr;
     size_t vgg_w[13], vgg_b[13];
+    size_t vgg_wino_w[13] = {0};         // Winograd-domain operands of conv3_2 .. conv5_3
+    size_t vgg_zero = 0;                 // 1024 zeros (bias of the Winograd-domain GEMM)
 };
 
 int fail(vstab_ctx *ctx, int code, const char *fmt, ...);

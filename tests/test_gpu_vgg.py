@@ -25,6 +25,20 @@ def test_vgg16_every_output_vs_oracle(B, H, W):
     assert net.pool5.shape == (B, -(-H // 32), -(-W // 32), 512)
 
 
+def test_vgg16_winograd_levels_vs_oracle():
+    """Large enough (6 x 256 x 256) for conv3_2 .. conv5_3 to run in Winograd form (their Winograd-domain GEMMs issue > 3 GFLOP);
+    the oracle runs in fp32 here (243 GFLOP), so the tolerance covers two fp32 implementations."""
+    B, H, W = 6, 256, 256
+    dd = vvgg.synthetic_data_dict(seed=5)
+    x = torch.rand(B, H, W, 3, generator=torch.Generator().manual_seed(9))
+    net = vvgg.Vgg16(data_dict=dd).build(vvgg.preprocess(x.cuda()))
+    ref = vo.vgg16_build(vo.vgg_preprocess(x, torch.float32), dd, torch.float32)
+    for name in vvgg.OUTPUTS:
+        got, r = getattr(net, name), ref[name]
+        err = float((got.cpu() - r).abs().max())
+        assert err <= 3e-4 * max(1.0, float(r.abs().max())), (name, err, float(r.abs().max()))
+
+
 def test_maxpool_same_on_odd_sizes():
     x = torch.randn(1, 5, 7, 8)
     dd = vvgg.synthetic_data_dict(seed=1)
