@@ -1052,6 +1052,10 @@ extern "C" int vstab_vgg16_load(vstab_ctx *ctx, const vstab_tensor *t, int count
         fold_bn(b->data, nullptr, nullptr, nullptr, VGG[l].cout, npad, ones.data(), host.data() + ctx->vgg_b[l]);
         ctx->vgg_w[l] = reserve((size_t)L.ktiles() * npad * 32);
         pack_conv(W->data, ones.data(), 3, 3, VGG[l].cin, VGG[l].cin, VGG[l].cout, npad, L, host.data() + ctx->vgg_w[l]);
+        if (l == 0) {                                  // conv1_1 also unpacked (HWIO as given) for its store-shaped kernel
+            ctx->vgg_raw0 = reserve((size_t)27 * VGG[0].cout);
+            std::memcpy(host.data() + ctx->vgg_raw0, W->data, sizeof(float) * 27 * VGG[0].cout);
+        }
         ctx->vgg_wino_w[l] = 0;
         if (VGG[l].cin >= 256) {                       // Winograd-domain operand for the layers that may run in that form
             ctx->vgg_wino_w[l] = reserve((size_t)16 * (VGG[l].cin / 32) * VGG[l].cout * 32);
@@ -1095,7 +1099,10 @@ extern "C" int vstab_vgg16_forward(vstab_ctx *ctx, const float *input, int B, in
             if (!fill_plain_conv(p, tile, vec, bc, h, w, VGG[l].cin, VGG[l].cin, 3, 1, 1, VGG[l].cout, VGG[l].cout, 0, 2))
                 return fail(ctx, VSTAB_E_SHAPE, "vgg16_forward: layer %s does not fit", VGG[l].name);
             float *dst = outs[o] + (size_t)b0 * v.h[o] * v.w[o] * v.c[o];
-            if (v.wino[l] && wino_applies(bc, h, w, VGG[l].cin, VGG[l].cout)) {      // (a short last chunk may fall below the break-even)
+            static const bool rgb_kernel = getenv("VSTAB_NO_RGB_CONV") == nullptr;           // A/B switch for tuning runs
+            if (l == 0 && rgb_kernel) {
+                HIP_TRY(ctx, launch_conv3x3_rgb(cur, bc, h, w, ctx->vgg_weights + ctx->vgg_raw0, ctx->vgg_weights + ctx->vgg_b[0], VGG[0].cout, 1, dst, stream));
+            } else if (v.wino[l] && wino_applies(bc, h, w, VGG[l].cin, VGG[l].cout)) {      // (a short last chunk may fall below the break-even)
                 ConvParams q;
                 fill_wino_gemm(q, bc, h, w, VGG[l].cin, VGG[l].cout);
                 HIP_TRY(ctx, launch_wino_input(cur, bc, h, w, VGG[l].cin, 0, VGG[l].cin, wsV, stream));

@@ -40,6 +40,7 @@ struct vstab_ctx {
     float *vgg_weights = nullptr;
     size_t vgg_w[13], vgg_b[13];
     size_t vgg_wino_w[13] = {0};         // Winograd-domain operands of conv3_2 .. conv5_3
+    size_t vgg_raw0 = 0;                 // conv1_1's filter as given (HWIO), for conv3x3_rgb_kernel
     size_t vgg_zero = 0;                 // 1024 zeros (bias of the Winograd-domain GEMM)
 };
 

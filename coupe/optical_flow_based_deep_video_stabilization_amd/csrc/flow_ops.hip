@@ -385,6 +385,77 @@ __global__ __launch_bounds__(256) void scale_shift_kernel(const float *__restric
     out[idx] = x[idx] * scale - mean.m[c];
 }
 
+// VGG16's first layer (conv1_1, vgg16.py:29: 3x3 SAME on the 3-channel image -> 64 channels, ReLU): K = 27 is a single padded
+// K-tile of the MFMA kernel, whose time is then its 4-byte scattered epilogue (1.2 TB/s on the 2.1 GB it writes at 4 x 1080p).  This
+// layer is an HBM-bound WRITE, so it gets a plain kernel shaped for the store: 16 lanes per pixel, one float4 of output channels
+// each (256 contiguous bytes per pixel), four pixels of a row per thread so that each filter chunk is read from LDS once for the
+// four; the 3x6x3 input window comes through L1 (the 16 lanes of a pixel group hit the same addresses), filter + bias sit in LDS.  W: HWIO [3][3][3][cout], cout % 4 == 0, cout <= 64.
+__global__ __launch_bounds__(256) void conv3x3_rgb_kernel(const float *__restrict__ x, int B, int H, int W, const float *__restrict__ Wf,
+                                                          const float *__restrict__ bias, int cout, int relu, float *__restrict__ out)
+{
+    __shared__ f32x4 sW[27 * 16];
+    __shared__ f32x4 sB[16];
+    const int q4 = cout >> 2;
+    for (int i = threadIdx.x; i < 27 * q4; i += 256) sW[(i / q4) * 16 + (i % q4)] = *reinterpret_cast<const f32x4 *>(Wf + (long long)(i / q4) * cout + (i % q4) * 4);
+    if (threadIdx.x < q4) sB[threadIdx.x] = *reinterpret_cast<const f32x4 *>(bias + threadIdx.x * 4);
+    __syncthreads();
+    // a thread: 4 consecutive pixels of a row x one float4 of output channels (the filter chunk is read once for the four)
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int q = (int)(idx & 15);
+    const long long grp = idx >> 4;
+    const int WQ = (W + 3) >> 2;
+    if (grp >= (long long)B * H * WQ || q >= q4) return;
+    const int n = (int)(grp / ((long long)H * WQ));
+    const int rem = (int)(grp - (long long)n * H * WQ);
+    const int y = rem / WQ, x0 = (rem - y * WQ) * 4;
+    const float *xb = x + (long long)n * H * W * 3;
+    f32x4 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[p] = sB[q];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+        const bool yok = (unsigned)iy < (unsigned)H;
+        float v[6][3];                                   // input columns x0-1 .. x0+4 of this row
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int ix = x0 + j - 1;
+            const bool ok = yok && (unsigned)ix < (unsigned)W;
+            const float *px = xb + ((long long)iy * W + ix) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[j][c] = ok ? px[c] : 0.f;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x4 w = sW[((ky * 3 + kx) * 3 + c) * 16 + q];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p] += v[p + kx][c] * w;
+            }
+    }
+    float *o = out + (((long long)n * H + y) * W + x0) * cout + q * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (x0 + p >= W) break;
+        f32x4 r = acc[p];
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+        }
+        *reinterpret_cast<f32x4 *>(o + (long long)p * cout) = r;
+    }
+}
+
+hipError_t launch_conv3x3_rgb(const float *x, int B, int H, int W, const float *Wf, const float *bias, int cout, int relu, float *out,
+                              hipStream_t stream)
+{
+    if ((cout & 3) || cout > 64 || cout < 4) return hipErrorInvalidValue;
+    const long long n = (long long)B * H * ((W + 3) / 4) * 16;
+    conv3x3_rgb_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(x, B, H, W, Wf, bias, cout, relu, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_scale_shift(const float *x, long long npix, int C, float scale, const float *mean4, float *out, hipStream_t stream)
 {
     if (C < 1 || C > 4) return hipErrorInvalidValue;

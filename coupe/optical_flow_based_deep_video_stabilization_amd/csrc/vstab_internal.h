@@ -165,6 +165,9 @@ hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int
                             int C, hipStream_t stream);
 // 2x2 stride-2 SAME max pool (vgg16.py:51-53), NHWC, C % 4 == 0
 hipError_t launch_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, hipStream_t stream);
+// 3x3 SAME conv on a 3-channel image (VGG16 conv1_1): W HWIO [3][3][3][cout] unpacked, cout % 4 == 0, cout <= 64
+hipError_t launch_conv3x3_rgb(const float *x, int B, int H, int W, const float *Wf, const float *bias, int cout, int relu, float *out,
+                              hipStream_t stream);
 // y = x * scale - mean[c]  (NLDF.py:29 preprocessing), C <= 4
 hipError_t launch_scale_shift(const float *x, long long npix, int C, float scale, const float *mean4, float *out,
                               hipStream_t stream);
