@@ -91,8 +91,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     }
     __syncthreads();
 
-    const int kps = p.SEGP >> 5;                  // K-tiles per segment
-    const int KT = p.KH * p.NSEG * kps;
+    // this phase's K layout (its own, or the launch-wide one)
+    const bool own = ph.KH != 0;
+    const int L_KH = own ? ph.KH : p.KH, L_NSEG = own ? ph.NSEG : p.NSEG, L_SEG = own ? ph.SEG : p.SEG;
+    const int L_SEGP = own ? ph.SEGP : p.SEGP, L_STRIDE = own ? ph.SEG_STRIDE : p.SEG_STRIDE;
+    const int kps = L_SEGP >> 5;                  // K-tiles per segment
+    const int KT = L_KH * L_NSEG * kps;
     const int kts = (KT + p.ksplit - 1) / p.ksplit;
     const int kt0 = split * kts;
     const int kt1 = min(KT, kt0 + kts);
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     // K-tile cursor (row tap, segment, chunk) of the NEXT tile to load
     int c_ky, c_sg, c_kc;
     {
-        const int per_row = p.NSEG * kps;
+        const int per_row = L_NSEG * kps;
         c_ky = kt0 / per_row;
         const int r = kt0 - c_ky * per_row;
         c_sg = r / kps;
@@ -130,12 +134,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     auto load_tile = [&](int kt) {
         const int ky = c_ky;
         const int qseg = c_kc * 32;                       // float offset inside the segment
-        const int qabs0 = c_sg * p.SEG_STRIDE + qseg;     // float offset from the run start
+        const int qabs0 = c_sg * L_STRIDE + qseg;     // float offset from the run start
         {   // advance the cursor without branches (keeps the loop body one scheduling region)
             const int kc1 = c_kc + 1;
             const bool wrap_kc = kc1 == kps;
             const int sg1 = c_sg + (wrap_kc ? 1 : 0);
-            const bool wrap_sg = sg1 == p.NSEG;
+            const bool wrap_sg = sg1 == L_NSEG;
             c_kc = wrap_kc ? 0 : kc1;
             c_sg = wrap_sg ? 0 : sg1;
             c_ky += wrap_sg ? 1 : 0;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
             const int qs = qseg + (tid & 7) * 4;
             const int qa = qabs0 + (tid & 7) * 4;
             const int rowoff = ky * row_pitch + qa;
-            const bool segok = qs < p.SEG;
+            const bool segok = qs < L_SEG;
 #pragma unroll
             for (int j = 0; j < A_ROWS_V; ++j) {
                 const bool ok = segok & ((unsigned)(R[j].y + ky) < (unsigned)p.Hi) & (qa >= R[j].z) & (qa < R[j].w);
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
             const int qs = qseg + (tid & 31);
             const int qa = qabs0 + (tid & 31);
             const int rowoff = ky * row_pitch + qa;
-            const bool segok = qs < p.SEG;
+            const bool segok = qs < L_SEG;
 #pragma unroll
             for (int j = 0; j < A_ELEMS_S; ++j) {
                 const int4 ri = rinfo[(tid >> 5) + 8 * j];
@@ -213,18 +217,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
         for (int j = 0; j < A_ROWS_V; ++j) {
             const int row = (tid >> 3) + 32 * j;
             const int c4 = ((tid & 7) ^ ((row >> 1) & 7)) * 4;            // source chunk (floats) for this LDS slot
-            RA[j] = make_int4((R[j].x + c4 + bias_el) * 4, R[j].z - c4, R[j].w - c4, p.SEG - c4);
+            RA[j] = make_int4((R[j].x + c4 + bias_el) * 4, R[j].z - c4, R[j].w - c4, L_SEG - c4);
         }
     }
     auto dma_tile = [&](int kt, int buf) {
         const int ky = c_ky;
         const int qseg = c_kc * 32;
-        const int qabs0 = c_sg * p.SEG_STRIDE + qseg;
+        const int qabs0 = c_sg * L_STRIDE + qseg;
         {
             const int kc1 = c_kc + 1;
             const bool wrap_kc = kc1 == kps;
             const int sg1 = c_sg + (wrap_kc ? 1 : 0);
-            const bool wrap_sg = sg1 == p.NSEG;
+            const bool wrap_sg = sg1 == L_NSEG;
             c_kc = wrap_kc ? 0 : kc1;
             c_sg = wrap_sg ? 0 : sg1;
             c_ky += wrap_sg ? 1 : 0;

@@ -1,6 +1,7 @@
 // C ABI of the training-side building blocks: convolution weight / bias gradients.
 // The loss entry point lives in api.cpp next to the other small wrappers.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -187,8 +188,41 @@ bool dgrad_plan(int B, int Ho, int Wo, int cs_g, int cout, int k, int stride, in
                 ++d.nsub;
             }
         if (d.nsub == 0) return false;
-        d.p = d.sp[0];
-        d.tile = d.stile[0];
+        static const bool sublaunch = getenv("VSTAB_DGRAD_SUBLAUNCH") != nullptr;       // A/B switch: always one launch per phase
+        long long tiles_all = 0;
+        for (int s = 0; s < d.nsub; ++s) tiles_all += (long long)((d.sp[s].ph[0].M + 127) / 128) * (npad / BN);
+        if (!sublaunch && tiles_all <= 256) {
+            // Small layers: ONE launch in which every phase carries its own K layout (ConvPhase::KH ...), split-K sized for the four
+            // together -- instead of four launches that each fill a fraction of the chip (conv6 at B=8 512x512: 112 -> 85 us; the
+            // whole B=1 step 3.45 -> 3.37 ms).  Large layers stay one launch per phase: merged they were SLOWER (conv3 523 -> 585 us,
+            // conv2 557 -> 633 us): a launch that works on one phase keeps a quarter of the filter hot in L2.
+            p = d.sp[0];
+            p.nphase = d.nsub;
+            p.Mmax = 0;
+            unsigned wmax = 0;
+            long long tiles = 0;
+            int kt_min = 1 << 30;
+            for (int s = 0; s < d.nsub; ++s) {
+                const ConvParams &q = d.sp[s];
+                ConvPhase &ph = p.ph[s];
+                ph = q.ph[0];
+                ph.w_off = (long long)d.soff[s];
+                ph.KH = q.KH; ph.NSEG = q.NSEG; ph.SEG = q.SEG; ph.SEGP = q.SEGP; ph.SEG_STRIDE = q.SEG_STRIDE;
+                p.Mmax = std::max(p.Mmax, ph.M);
+                wmax = std::max(wmax, q.w_bytes);
+                tiles += (long long)((ph.M + 127) / 128) * (npad / BN);
+                kt_min = std::min(kt_min, q.KH * q.NSEG * (q.SEGP / 32));
+            }
+            p.w_bytes = wmax;
+            int ks = (int)(512 / std::max<long long>(tiles, 1));                  // two co-resident workgroups per CU
+            ks = std::max(1, std::min(ks, std::max(1, kt_min / 4)));
+            p.ksplit = ks;
+            d.tile = base;
+            d.nsub = 0;
+        } else {
+            d.p = d.sp[0];
+            d.tile = d.stile[0];
+        }
     } else {
         const int kt2 = (k + 1) / 2;
         std::memset(&p, 0, sizeof p);

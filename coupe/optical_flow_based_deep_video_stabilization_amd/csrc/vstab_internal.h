@@ -66,6 +66,11 @@ struct ConvPhase {
     int o_y, o_x;           // output offsets
     int pad_;
     long long w_off;        // float offset of this phase's packed weights inside wpk
+    // K layout of THIS phase when it differs from ConvParams' (KH == 0: use the launch-wide one).  The output-parity phases of an
+    // odd-k stride-2 input gradient have different tap counts ((k+1)/2 or (k-1)/2 per axis); giving each phase its own reduction
+    // length lets all four run in ONE launch with exactly their taps.
+    int KH, NSEG, SEG, SEGP, SEG_STRIDE;
+    int pad2_;
 };
 
 struct ConvParams {
