@@ -85,6 +85,9 @@ EXPORTS = {
     "vstab_lrelu_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p]),
     "vstab_flow_medfilt": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "vstab_flow_mean_fill": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
+    "vstab_conv3x3_winograd_wgrad_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "vstab_conv3x3_winograd_wgrad": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_size_t,
+                                               C.c_void_p]),
     "vstab_loss_main_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "vstab_loss_main": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),

@@ -628,3 +628,65 @@ extern "C" int vstab_conv3x3_winograd(const float *x, int B, int H, int W, int c
     HIP_TRY(nullptr, launch_wino_output(M, B, H, W, N, bias ? bias : bz, act, y, cs_y, cy_off, st));
     return VSTAB_OK;
 }
+
+// ------------------------------------------------------------------------- filter gradient of a 3x3 stride-1 conv in Winograd form
+namespace {
+bool wino_wgrad_shape(int B, int H, int W, int cin, int cout, WgradParams &p, int &TH, int &TW)
+{
+    if (B < 1 || H < 1 || W < 1 || cin < 4 || cout < 4 || (cin & 3) || (cout & 3)) return false;
+    TH = (H + 1) / 2; TW = (W + 1) / 2;
+    const long long T = (long long)B * TH * TW;
+    if (T * 16 * std::max(cin, cout) * 4 >= 0x80000000LL || T * std::max(cin, cout) * 4 >= 0x80000000LL) return false;
+    p = WgradParams{};
+    p.Hi = (int)T; p.Wi = 1; p.Cs_x = cin; p.cx_off = 0; p.Cin = cin; p.KH = 1; p.KW = 1;
+    p.Cs_g = cout; p.cg_off = 0; p.Cout = cout; p.M = cin; p.K = (int)T;
+    p.nbatch = 16;
+    p.ksplit = wgrad_choose_split(p);
+    return true;
+}
+}  // namespace
+
+extern "C" size_t vstab_conv3x3_winograd_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout)
+{
+    WgradParams p; int TH, TW;
+    if (!wino_wgrad_shape(B, H, W, cin, cout, p, TH, TW)) return 0;
+    const size_t T = (size_t)B * TH * TW;
+    return a256(T * 16 * cin * 4) + a256(T * 16 * cout * 4) + a256((size_t)16 * cin * cout * 4) +
+           a256(p.ksplit > 1 ? (size_t)16 * p.ksplit * cin * cout * 4 : 0) + 256;
+}
+
+extern "C" int vstab_conv3x3_winograd_wgrad(const float *x, int B, int H, int W, int cs_x, int cx_off, int cin, const float *gout, int cs_g,
+                                            int cg_off, int cout, float *dW, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!x || !gout || !dW || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv3x3_winograd_wgrad: NULL buffer");
+    if (cx_off < 0 || cg_off < 0 || cx_off + cin > cs_x || cg_off + cout > cs_g)
+        return fail(nullptr, VSTAB_E_SHAPE, "conv3x3_winograd_wgrad: bad channel slices");
+    WgradParams p; int TH, TW;
+    if (!wino_wgrad_shape(B, H, W, cin, cout, p, TH, TW))
+        return fail(nullptr, VSTAB_E_SHAPE, "conv3x3_winograd_wgrad: needs channel counts that are multiples of 4 and < 2 GiB per tensor");
+    if ((cs_x & 3) || (cx_off & 3) || (cs_g & 3) || (cg_off & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(gout) & 15) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 255))
+        return fail(nullptr, VSTAB_E_ALIGN, "conv3x3_winograd_wgrad: strides / offsets multiples of 4, 16-byte tensors, 256-byte workspace");
+    if (workspace_bytes < vstab_conv3x3_winograd_wgrad_workspace_bytes(B, H, W, cin, cout))
+        return fail(nullptr, VSTAB_E_NOMEM, "conv3x3_winograd_wgrad: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t T = (size_t)B * TH * TW;
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *V = reinterpret_cast<float *>(ws); ws += a256(T * 16 * cin * 4);
+    float *dM = reinterpret_cast<float *>(ws); ws += a256(T * 16 * cout * 4);
+    float *dU = reinterpret_cast<float *>(ws); ws += a256((size_t)16 * cin * cout * 4);
+    p.partial = reinterpret_cast<float *>(ws);
+    HIP_TRY(nullptr, launch_wino_input(x, B, H, W, cs_x, cx_off, cin, V, st, true));           // V  [16][T][cin]
+    HIP_TRY(nullptr, launch_wino_outgrad(gout, B, H, W, cs_g, cg_off, cout, dM, st));            // dM [16][T][cout]
+    // 16 independent reductions dU_xi [cin x cout] = V_xi^T [cin x T] . dM_xi [T x cout]: the weight-gradient kernel's batched form over
+    // a 1x1 "image" of T pixels
+    p.ptab = wgrad_pixel_table(1, (int)T, 1, cin, (int)T, 1, 1, 0, st);
+    if (!p.ptab) return fail(nullptr, VSTAB_E_NOMEM, "conv3x3_winograd_wgrad: cannot build the pixel table");
+    p.x = V; p.g = dM; p.dW = dU;
+    p.x_bytes = (unsigned)(T * cin * 4); p.g_bytes = (unsigned)(T * cout * 4);
+    p.x_bstride = (long long)(T * cin); p.g_bstride = (long long)(T * cout);
+    p.accumulate = 0;
+    HIP_TRY(nullptr, launch_wgrad(p, st));
+    HIP_TRY(nullptr, launch_wino_filter_grad(dU, cin, cout, dW, st));
+    return VSTAB_OK;
+}

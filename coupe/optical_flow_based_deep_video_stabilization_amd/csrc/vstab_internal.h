@@ -138,7 +138,12 @@ void pack_conv_rowwin(const float *W, const double *scale, int kh, int kw, int c
 // Winograd F(2x2,3x3) transforms around the MFMA kernel (winograd_ops.hip) and the weight transform + packing:
 // U_xi = (G g G^T)_xi with the BatchNorm scale folded in, 16 blocks of a 1x1-conv operand (klayout_run(1,1,cin)).
 // ---------------------------------------------------------------------------------
-hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_off, int C, float *V, hipStream_t stream);
+// filter gradient of a 3x3 stride-1 layer in the Winograd domain (winograd_ops.hip): dM = A dY A^T per 2x2 tile of the output
+// gradient -> [B][16][TH*TW][C]; dg = G^T dU G from the 16 position gradients dU [16][cin][cout] -> HWIO [3][3][cin][cout]
+hipError_t launch_wino_outgrad(const float *dy, int B, int H, int W, int Cs, int c_off, int C, float *dM, hipStream_t stream);
+hipError_t launch_wino_filter_grad(const float *dU, int cin, int cout, float *dW, hipStream_t stream);
+hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_off, int C, float *V, hipStream_t stream,
+                             bool pos_major = false);       // pos_major: V as [16][B*tiles][C] instead of [B][16][tiles][C]
 // device-side weight transform for training: Wt [16][K][N] from W [3,3,cin,cout]; transpose = the input gradient's operand
 hipError_t launch_wino_weights(const float *W, int cin, int cout, int transpose, float *Wt, hipStream_t stream);
 hipError_t launch_wino_output(const float *M, int B, int Ho, int Wo, int C, const float *bias, int act, float *out, int Cs_out, int c_off,
@@ -216,6 +221,11 @@ struct WgradParams {
     int Cs_g, cg_off, Cout;
     int M, K;               // KH*KW*Cin, B*Ho*Wo
     int ksplit, accumulate; // accumulate: dW += result
+    // batched form (nbatch > 1): independent reductions z = 0..nbatch-1 over the same pixel table, operands x + z*x_bstride and
+    // g + z*g_bstride (elements; x_bytes / g_bytes then size ONE batch), result dW + z*M*Cout.  The 16 positions of a
+    // Winograd-domain filter gradient are such a batch.  0 or 1: the plain form.
+    int nbatch;
+    long long x_bstride, g_bstride;
 };
 hipError_t launch_wgrad_pixel_table(int B, int Hi, int Wi, int Cs, int Ho, int Wo, int s, int pad, int4 *ptab, hipStream_t stream);
 int wgrad_choose_split(const WgradParams &p);

@@ -61,14 +61,16 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
     unsigned bx_, by_, bz_;
     xcd_remap(bx_, by_, bz_);                       // the tiles of one K split (which all read the same pixels) share an XCD
     const int m0 = (int)bx_ * BM, n0 = (int)by_ * BN;
-    const int split = (int)bz_;
+    const int batch = (int)bz_ / p.ksplit, split = (int)bz_ - batch * p.ksplit;
     const int ktiles = (p.K + KT - 1) / KT;
     const int kts = (ktiles + p.ksplit - 1) / p.ksplit;
     const int kt0 = split * kts, kt1 = min(ktiles, kt0 + kts);
 
     const unsigned OOB = 0xC0000000u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.g), 0, p.g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x) + (long long)batch * p.x_bstride, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.g) + (long long)batch * p.g_bstride, 0, p.g_bytes, 0x00020000);
     const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
 
     // this thread's column chunk (4 floats) inside the 128-float tile rows: constant over the whole K loop
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
     }
 
     // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float *dst = p.ksplit > 1 ? p.partial + (size_t)split * p.M * p.Cout : p.dW;
+    float *dst = p.ksplit > 1 ? p.partial + (size_t)(batch * p.ksplit + split) * p.M * p.Cout : p.dW + (size_t)batch * p.M * p.Cout;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int col = n0 + wn * (BN / 2) + nb * 32 + li;
@@ -176,11 +178,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
     }
 }
 
+// n = M*Cout elements per batch; blockIdx.y = batch (slabs [batch][ks][n], result [batch][n])
 __global__ __launch_bounds__(256) void wgrad_combine_kernel(const float *__restrict__ partial, int ks, long long n,
                                                             int accumulate, float *__restrict__ dW)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    partial += (long long)blockIdx.y * ks * n;
+    dW += (long long)blockIdx.y * n;
     float s = 0.f;
     int k = 0;
     for (; k + 4 <= ks; k += 4) {
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(1024) void column_sum_final_kernel(const float *__r
 int wgrad_choose_split(const WgradParams &p)
 {
     const int bn = p.Cout <= 64 ? 64 : 128;
-    const long long tiles = (long long)((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);
+    const long long tiles = (long long)((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn) * (p.nbatch > 1 ? p.nbatch : 1);
     const int ktiles = (p.K + 31) / 32;
     int ks = (int)(512 / (tiles > 0 ? tiles : 1));                           // two 64 KB workgroups fit a CU
     if (ks < 1) ks = 1;
@@ -279,18 +284,19 @@ hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream)
     if ((p.Cin & 3) || (p.Cs_x & 3) || (p.cx_off & 3) || (p.Cs_g & 3) || (p.cg_off & 3) || p.ksplit < 1) return hipErrorInvalidValue;
     if (p.x_bytes >= 0x80000000u || p.g_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.ksplit > 1 && !p.partial) return hipErrorInvalidValue;
+    const unsigned nb = (unsigned)(p.nbatch > 1 ? p.nbatch : 1);
     if (p.Cout <= 64) {
-        dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)((p.Cout + 63) / 64), (unsigned)p.ksplit);
+        dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)((p.Cout + 63) / 64), (unsigned)p.ksplit * nb);
         wgrad_mfma_kernel<64><<<grid, dim3(256), 2 * 32 * (128 + 64) * sizeof(float), stream>>>(p);
     } else {
-        dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)((p.Cout + 127) / 128), (unsigned)p.ksplit);
+        dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)((p.Cout + 127) / 128), (unsigned)p.ksplit * nb);
         wgrad_mfma_kernel<128><<<grid, dim3(256), 2 * 32 * (128 + 128) * sizeof(float), stream>>>(p);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (p.ksplit > 1) {
         const long long n = (long long)p.M * p.Cout;
-        wgrad_combine_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(p.partial, p.ksplit, n, p.accumulate, p.dW);
+        wgrad_combine_kernel<<<dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, stream>>>(p.partial, p.ksplit, n, p.accumulate, p.dW);
         e = hipGetLastError();
     }
     return e;

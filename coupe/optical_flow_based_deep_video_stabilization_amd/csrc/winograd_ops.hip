@@ -17,8 +17,10 @@ namespace vstab {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// (sample_stride, pos_stride) in floats: (16*tiles*C, tiles*C) = [B][16][tiles][C] for the forward GEMM's phases,
+// (tiles*C, B*tiles*C) = [16][B*tiles][C] when the reduction runs over all tiles of the batch (filter gradient)
 __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int H, int W, int Cs, int c_off, int C4,
-                                                         float *__restrict__ V, int TH, int TW)
+                                                         float *__restrict__ V, int TH, int TW, long long sample_stride, long long pos_stride)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)TH * TW * C4) return;
@@ -48,8 +50,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
         t[2][j] = d[2][j] - d[1][j];
         t[3][j] = d[1][j] - d[3][j];
     }
-    float *vb = V + (((long long)n * 16) * TH * TW + tile) * (C4 * 4) + c * 4;
-    const long long xs = (long long)TH * TW * (C4 * 4);                      // stride between the 16 positions
+    float *vb = V + (long long)n * sample_stride + (long long)tile * (C4 * 4) + c * 4;
+    const long long xs = pos_stride;                                         // stride between the 16 positions
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         *reinterpret_cast<f32x4 *>(vb + (i * 4 + 0) * xs) = t[i][0] - t[i][2];
@@ -137,6 +139,92 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restric
     }
 }
 
+// Output-gradient transform of the Winograd-domain filter gradient: dM = A dY A^T per 2x2 tile (A = [1 0; 1 1; 1 -1; 0 -1], the
+// transpose of the output transform's A^T; pixels of a tile that lie outside an odd-sized image count as zero).
+// dy [B,H,W,Cs] (channels c_off..+C) -> dM [B,16,TH,TW,C], one thread per (tile, 4 channels) like the input transform.
+__global__ __launch_bounds__(256) void wino_outgrad_kernel(const float *__restrict__ dy, int H, int W, int Cs, int c_off, int C4,
+                                                           float *__restrict__ dM, int TH, int TW, long long sample_stride, long long pos_stride)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)TH * TW * C4) return;
+    const int n = blockIdx.y;
+    const int c = (int)(idx % C4);
+    const int tile = (int)(idx / C4);
+    const int ty = tile / TW, tx = tile - ty * TW;
+    const float *yb = dy + (long long)n * H * W * Cs + c_off + c * 4;
+    f32x4 d[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int y = 2 * ty + a, xx = 2 * tx + b;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (y < H && xx < W) v = *reinterpret_cast<const f32x4 *>(yb + ((long long)y * W + xx) * Cs);
+            d[a][b] = v;
+        }
+    f32x4 t[4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        t[0][b] = d[0][b];
+        t[1][b] = d[0][b] + d[1][b];
+        t[2][b] = d[0][b] - d[1][b];
+        t[3][b] = -d[1][b];
+    }
+    float *mb = dM + (long long)n * sample_stride + (long long)tile * (C4 * 4) + c * 4;
+    const long long xs = pos_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4 *>(mb + (i * 4 + 0) * xs) = t[i][0];
+        *reinterpret_cast<f32x4 *>(mb + (i * 4 + 1) * xs) = t[i][0] + t[i][1];
+        *reinterpret_cast<f32x4 *>(mb + (i * 4 + 2) * xs) = t[i][0] - t[i][1];
+        *reinterpret_cast<f32x4 *>(mb + (i * 4 + 3) * xs) = -t[i][1];
+    }
+}
+
+// dg[a][b][ci][co] = sum_{i,j} G[i][a] G[j][b] dU[4 i + j][ci][co]  (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]): the 16 position
+// gradients back to the 3x3 filter, HWIO
+__global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float *__restrict__ dU, long long n, float *__restrict__ dW)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    float u[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[i][j] = dU[(long long)(i * 4 + j) * n + idx];
+    float t[3][4];                                   // G^T u: rows a
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+        t[1][j] = 0.5f * (u[1][j] - u[2][j]);
+        t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        dW[(long long)(a * 3 + 0) * n + idx] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+        dW[(long long)(a * 3 + 1) * n + idx] = 0.5f * (t[a][1] - t[a][2]);
+        dW[(long long)(a * 3 + 2) * n + idx] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+    }
+}
+
+// dM: [16][B*tiles][C] (position-major over the whole batch)
+hipError_t launch_wino_outgrad(const float *dy, int B, int H, int W, int Cs, int c_off, int C, float *dM, hipStream_t stream)
+{
+    if ((C & 3) || (Cs & 3) || (c_off & 3)) return hipErrorInvalidValue;
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    const long long per = (long long)TH * TW * (C / 4);
+    wino_outgrad_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(dy, H, W, Cs, c_off, C / 4, dM, TH, TW,
+                                                                                                (long long)TH * TW * C, (long long)B * TH * TW * C);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino_filter_grad(const float *dU, int cin, int cout, float *dW, hipStream_t stream)
+{
+    const long long n = (long long)cin * cout;
+    wino_filter_grad_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(dU, n, dW);
+    return hipGetLastError();
+}
+
 hipError_t launch_wino_weights(const float *W, int cin, int cout, int transpose, float *Wt, hipStream_t stream)
 {
     const long long n = (long long)cin * cout;
@@ -144,12 +232,13 @@ hipError_t launch_wino_weights(const float *W, int cin, int cout, int transpose,
     return hipGetLastError();
 }
 
-hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_off, int C, float *V, hipStream_t stream)
+hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_off, int C, float *V, hipStream_t stream, bool pos_major)
 {
     if ((C & 3) || (Cs & 3) || (c_off & 3)) return hipErrorInvalidValue;
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
-    const long long per = (long long)TH * TW * (C / 4);
-    wino_input_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(x, H, W, Cs, c_off, C / 4, V, TH, TW);
+    const long long per = (long long)TH * TW * (C / 4), tc = (long long)TH * TW * C;
+    wino_input_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(x, H, W, Cs, c_off, C / 4, V, TH, TW,
+                                                                                              pos_major ? tc : 16 * tc, pos_major ? B * tc : tc);
     return hipGetLastError();
 }
 

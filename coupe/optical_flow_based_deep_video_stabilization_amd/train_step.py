@@ -241,6 +241,19 @@ class Trainer:
                                                          self.p[f"{name}/beta"].data_ptr(), self.save[name][1].data_ptr(),
                                                          self.g[f"{name}/beta"].data_ptr(), 0, ws.data_ptr(), ws.numel(), self.st))
 
+    def _wino_wgrad(self, x, cx_off, cin, G, cg_off, cout, dW):
+        """Filter gradient of a 3x3 stride-1 stage in the Winograd domain; False when the geometry does not qualify."""
+        B, H, Wd, cs_x = x.shape
+        if (cin & 31) or (cout & 63) or 32.0 * B * ((H + 1) // 2) * ((Wd + 1) // 2) * cin * cout < self.wino_min_flops:
+            return False
+        n = self.L.vstab_conv3x3_winograd_wgrad_workspace_bytes(B, H, Wd, cin, cout)
+        if n == 0:
+            return False
+        ws = self._workspace(n)
+        self._check(self.L.vstab_conv3x3_winograd_wgrad(x.data_ptr(), B, H, Wd, cs_x, cx_off, cin, G.data_ptr(), G.shape[3], cg_off, cout,
+                                                        dW.data_ptr(), ws.data_ptr(), ws.numel(), self.st))
+        return True
+
     def _resize(self, x, out):
         B, h, w, C = x.shape
         self._check(self.L.vstab_resize_bilinear(x.data_ptr(), B, h, w, C, out.data_ptr(), out.shape[1], out.shape[2], self.st))
@@ -380,7 +393,8 @@ class Trainer:
             ib, ioff, cin = ENC_IN[name]
             ob, ooff = ENC_OUT[name]
             self._bn_bwd(name, a[ob], G[ob], ooff, cout)
-            self._wgrad(a[ib], ioff, cin, G[ob], ooff, cout, k, s, pad, g[f"{name}/W_conv2d"], None)
+            if not (k == 3 and s == 1 and self._wino_wgrad(a[ib], ioff, cin, G[ob], ooff, cout, g[f"{name}/W_conv2d"])):
+                self._wgrad(a[ib], ioff, cin, G[ob], ooff, cout, k, s, pad, g[f"{name}/W_conv2d"], None)
             # (b_conv2d: same -- the batch mean removes the bias, its gradient stays the zero it was created with)
             if ib != "x0":
                 acc = self._acc(ib)

@@ -263,3 +263,27 @@ def conv3x3_winograd(x, W, transpose: bool = False, bias=None, y=None, cx_off: i
                                             bias.data_ptr() if bias is not None else None, y.data_ptr(), y.shape[3], cy_off, act,
                                             ws.data_ptr(), ws.numel(), runtime.stream_ptr()))
     return y
+
+
+def conv3x3_winograd_wgrad(x, gout, cx_off: int = 0, cin: int = None, cg_off: int = 0, cout: int = None, dW=None):
+    """Filter gradient of PadLayer(1) -> Conv2d(3, 1, VALID) (model.py:822, 829, 836, 843) in the Winograd domain
+    (`vstab_conv3x3_winograd_wgrad`): same result as `conv_wgrad(x, gout, 3, 1, 1)` up to fp32 rounding at 4/9 of its
+    multiply-adds.  x [B,H,W,Cs_x] (channels cx_off..+cin), gout [B,H,W,Cs_g] (channels cg_off..+cout) -> dW [3,3,cin,cout]."""
+    x, gout = x.contiguous(), gout.contiguous()
+    B, H, W, cs_x = x.shape
+    cs_g = gout.shape[3]
+    cin = cs_x - cx_off if cin is None else int(cin)
+    cout = cs_g - cg_off if cout is None else int(cout)
+    if gout.shape[:3] != x.shape[:3]:
+        raise ValueError("gout must have the spatial size of x (stride 1, pad 1)")
+    L = _lib.lib()
+    n = L.vstab_conv3x3_winograd_wgrad_workspace_bytes(B, H, W, cin, cout)
+    if n == 0:
+        raise ValueError("conv3x3_winograd_wgrad: channel counts must be multiples of 4 (and tensors < 2 GiB)")
+    if dW is None:
+        dW = torch.empty((3, 3, cin, cout), dtype=torch.float32, device=x.device)
+    ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.vstab_conv3x3_winograd_wgrad(x.data_ptr(), B, H, W, cs_x, cx_off, cin, gout.data_ptr(), cs_g, cg_off, cout,
+                                                  dW.data_ptr(), ws.data_ptr(), n, runtime.stream_ptr()))
+    return dW

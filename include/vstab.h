@@ -278,6 +278,13 @@ VSTAB_API size_t vstab_conv3x3_winograd_workspace_bytes(int B, int H, int W, int
 VSTAB_API int vstab_conv3x3_winograd(const float *x, int B, int H, int W, int cs_x, int cx_off, const float *Wf, int cin, int cout, int transpose,
                                      const float *bias, float *y, int cs_y, int cy_off, int act, void *workspace, size_t workspace_bytes,
                                      void *stream);
+/* Filter gradient of the same 3x3 stride-1 pad-1 layer in the Winograd domain: V = B^T d B of the input tiles, dM = A dY A^T of the
+ * output-gradient tiles, the 16 position gradients dU_xi = V_xi^T dM_xi as ONE batched reduction on the weight-gradient MFMA
+ * kernel (4/9 of the direct filter gradient's multiply-adds), dW = G^T dU G.  dW: HWIO [3][3][cin][cout], overwritten.
+ * x: [B,H,W,cs_x] channels cx_off..+cin; gout: [B,H,W,cs_g] channels cg_off..+cout; channel counts multiples of 4. */
+VSTAB_API size_t vstab_conv3x3_winograd_wgrad_workspace_bytes(int B, int H, int W, int cin, int cout);
+VSTAB_API int vstab_conv3x3_winograd_wgrad(const float *x, int B, int H, int W, int cs_x, int cx_off, int cin, const float *gout, int cs_g,
+                                           int cg_off, int cout, float *dW, void *workspace, size_t workspace_bytes, void *stream);
 /* din (+)= gain * (adjoint of tf.image.resize_images(., [oh,ow]))(dout): backward of the legacy bilinear resize. */
 VSTAB_API int vstab_resize_bilinear_backward(const float *dout, int B, int oh, int ow, int C, float *din, int h, int w, float gain,
                                              int accumulate, void *stream);

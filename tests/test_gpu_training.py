@@ -318,3 +318,21 @@ def test_conv3x3_winograd_forward_and_input_gradient(B, H, W, cin, cout):
         exp[..., 4:4 + cin] += dref
         assert float((out.double() - exp).abs().max()) <= 2e-5 * float(exp.abs().max())
         assert torch.equal(out[..., :4], base[..., :4])
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 24, 64, 128), (1, 13, 17, 256, 256), (3, 9, 8, 128, 64), (2, 33, 20, 32, 192), (4, 64, 64, 256, 256)])
+def test_conv3x3_winograd_filter_gradient(B, H, W, cin, cout):
+    """dW of a 3x3 stride-1 layer through the Winograd domain against autograd (and against the direct MFMA filter gradient)."""
+    import torch.nn.functional as F
+    g0 = torch.Generator().manual_seed(cout + W)
+    x = torch.randn(B, H, W, cin + 4, generator=g0)                 # channel slices of wider tensors on both sides
+    g = torch.randn(B, H, W, cout + 8, generator=g0)
+    Wt = torch.zeros(3, 3, cin, cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x[..., 4:].double().permute(0, 3, 1, 2), Wt.permute(3, 2, 0, 1), padding=1)
+    y.backward(g[..., :cout].double().permute(0, 3, 1, 2))
+    ref = Wt.grad
+    dW = training.conv3x3_winograd_wgrad(x.cuda(), g.cuda(), cx_off=4, cin=cin, cg_off=0, cout=cout)
+    assert tuple(dW.shape) == (3, 3, cin, cout)
+    assert float((dW.double().cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+    direct, _ = training.conv_wgrad(x.cuda(), g.cuda(), 3, 1, 1, cx_off=4, cin=cin, cg_off=0, cout=cout, want_db=False)
+    assert float((dW - direct).abs().max()) <= 3e-5 * float(ref.abs().max())
