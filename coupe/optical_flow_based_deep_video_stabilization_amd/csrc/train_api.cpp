@@ -39,14 +39,33 @@ const int4 *wgrad_pixel_table(int B, int Hi, int Wi, int cs_x, int Ho, int Wo, i
 }
 }  // namespace
 
+namespace {
+// How a filter gradient with `cout` columns is launched: as one launch, or -- 128 k + a few columns (the decoder's concat inputs:
+// 1026 / 770 / 386 channels + padding) -- as its 128-wide part plus a narrow tail, instead of a whole 128-column tile row for the tail.
+struct WgradSplit { int n_main, n_tail, ks_main, ks_tail; size_t slab_floats; };
+WgradSplit wgrad_split(int M, int cout, int K)
+{
+    WgradSplit s{};
+    WgradParams p{};
+    p.M = M; p.K = K;
+    s.n_main = cout / 128 * 128; s.n_tail = cout - s.n_main;
+    if (!(s.n_main >= 128 && s.n_tail > 0 && s.n_tail <= 32)) { s.n_main = cout; s.n_tail = 0; }
+    p.Cout = s.n_main; s.ks_main = wgrad_choose_split(p);
+    s.slab_floats = s.ks_main > 1 ? (size_t)s.ks_main * M * s.n_main : 0;
+    if (s.n_tail) {
+        p.Cout = s.n_tail; s.ks_tail = wgrad_choose_split(p);
+        s.slab_floats = std::max(s.slab_floats, s.ks_tail > 1 ? (size_t)s.ks_tail * M * s.n_tail : 0);      // the launches run one after the other
+    }
+    return s;
+}
+}  // namespace
+
 extern "C" size_t vstab_conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int k, int cin, int cout)
 {
     if (B < 1 || Ho < 1 || Wo < 1 || k < 1 || cin < 1 || cout < 1) return 0;
-    WgradParams p{};
-    p.M = k * k * cin; p.Cout = cout; p.K = B * Ho * Wo;
-    const int ks = wgrad_choose_split(p);
-    const size_t slabs = ((ks > 1 ? (size_t)ks * p.M * cout * sizeof(float) : 0) + 255) / 256 * 256;
-    return slabs + (size_t)column_sum_chunks(p.K, cout) * cout * sizeof(float) + 256;
+    const WgradSplit s = wgrad_split(k * k * cin, cout, B * Ho * Wo);
+    const size_t slabs = (s.slab_floats * sizeof(float) + 255) / 256 * 256;
+    return slabs + (size_t)column_sum_chunks((long long)B * Ho * Wo, cout) * cout * sizeof(float) + 256;
 }
 
 extern "C" int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *gout, int Ho,
@@ -78,13 +97,18 @@ extern "C" int vstab_conv_wgrad(const float *x, int B, int Hi, int Wi, int cs_x,
     p.Hi = Hi; p.Wi = Wi; p.Cs_x = cs_x; p.cx_off = cx_off; p.Cin = cin; p.KH = k; p.KW = k;
     p.Cs_g = cs_g; p.cg_off = cg_off; p.Cout = cout; p.M = k * k * cin; p.K = B * Ho * Wo;
     p.accumulate = accumulate ? 1 : 0;
-    p.ksplit = wgrad_choose_split(p);
+    const WgradSplit sp = wgrad_split(p.M, cout, p.K);
     p.ptab = wgrad_pixel_table(B, Hi, Wi, cs_x, Ho, Wo, stride, pad, st);
     if (!p.ptab) return fail(nullptr, VSTAB_E_NOMEM, "conv_wgrad: cannot build the pixel table");
     p.partial = reinterpret_cast<float *>(workspace);
+    p.Cout = sp.n_main; p.ldw = cout; p.col0 = 0; p.ksplit = sp.ks_main;
     HIP_TRY(nullptr, launch_wgrad(p, st));
+    if (sp.n_tail) {
+        p.Cout = sp.n_tail; p.cg_off = cg_off + sp.n_main; p.col0 = sp.n_main; p.ksplit = sp.ks_tail;
+        HIP_TRY(nullptr, launch_wgrad(p, st));
+    }
     if (db) {
-        const size_t slabs = ((p.ksplit > 1 ? (size_t)p.ksplit * p.M * cout * sizeof(float) : 0) + 255) / 256 * 256;
+        const size_t slabs = (sp.slab_floats * sizeof(float) + 255) / 256 * 256;
         float *scratch = reinterpret_cast<float *>(reinterpret_cast<char *>(p.partial) + slabs);
         HIP_TRY(nullptr, launch_column_sum(gout, (long long)p.K, cs_g, cg_off, cout, db, accumulate ? 1 : 0, scratch, st));
     }

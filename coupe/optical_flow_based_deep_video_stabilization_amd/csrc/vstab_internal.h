@@ -226,6 +226,10 @@ struct WgradParams {
     // Winograd-domain filter gradient are such a batch.  0 or 1: the plain form.
     int nbatch;
     long long x_bstride, g_bstride;
+    // column window: this launch computes columns col0 .. col0+Cout of a dW whose rows are ldw floats apart (0: ldw = Cout, col0 = 0).
+    // Lets a layer with 128 k + few output columns (the concat inputs: 1026, 770, 386 channels) run its 128-wide part and its narrow
+    // tail as two launches instead of paying a whole 128-column tile for the tail.
+    int ldw, col0;
 };
 hipError_t launch_wgrad_pixel_table(int B, int Hi, int Wi, int Cs, int Ho, int Wo, int s, int pad, int4 *ptab, hipStream_t stream);
 int wgrad_choose_split(const WgradParams &p);

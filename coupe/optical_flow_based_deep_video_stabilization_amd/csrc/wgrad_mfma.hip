@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
     }
 
     // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float *dst = p.ksplit > 1 ? p.partial + (size_t)(batch * p.ksplit + split) * p.M * p.Cout : p.dW + (size_t)batch * p.M * p.Cout;
+    const bool slab = p.ksplit > 1;
+    const int ld = slab ? p.Cout : (p.ldw ? p.ldw : p.Cout);
+    float *dst = slab ? p.partial + (size_t)(batch * p.ksplit + split) * p.M * p.Cout : p.dW + (size_t)batch * p.M * p.Cout + p.col0;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int col = n0 + wn * (BN / 2) + nb * 32 + li;
@@ -171,21 +173,23 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
                 const int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < p.M) {
                     float v = acc[mb][nb][r];
-                    if (p.ksplit == 1 && p.accumulate) v += dst[(size_t)row * p.Cout + col];
-                    dst[(size_t)row * p.Cout + col] = v;
+                    if (p.ksplit == 1 && p.accumulate) v += dst[(size_t)row * ld + col];
+                    dst[(size_t)row * ld + col] = v;
                 }
             }
     }
 }
 
-// n = M*Cout elements per batch; blockIdx.y = batch (slabs [batch][ks][n], result [batch][n])
+// n = M*Cout elements per batch; blockIdx.y = batch (slabs [batch][ks][n], result [batch][n]); the result's rows are ld floats apart
+// and start at column col0 (a column window of a wider dW)
 __global__ __launch_bounds__(256) void wgrad_combine_kernel(const float *__restrict__ partial, int ks, long long n,
-                                                            int accumulate, float *__restrict__ dW)
+                                                            int accumulate, float *__restrict__ dW, int cout, int ld, int col0)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     partial += (long long)blockIdx.y * ks * n;
-    dW += (long long)blockIdx.y * n;
+    const long long row = i / cout;
+    dW += (long long)blockIdx.y * n + row * (ld - cout) + col0;
     float s = 0.f;
     int k = 0;
     for (; k + 4 <= ks; k += 4) {
@@ -265,7 +269,7 @@ int wgrad_choose_split(const WgradParams &p)
     const int ktiles = (p.K + 31) / 32;
     int ks = (int)(512 / (tiles > 0 ? tiles : 1));                           // two 64 KB workgroups fit a CU
     if (ks < 1) ks = 1;
-    if (ks > 64) ks = 64;
+    if (ks > 256) ks = 256;                                                  // (a couple of tiles over a million pixels: the tap-table head)
     const int cap = ktiles / 4 > 1 ? ktiles / 4 : 1;
     if (ks > cap) ks = cap;
     const int kts = (ktiles + ks - 1) / ks;
@@ -296,7 +300,8 @@ hipError_t launch_wgrad(const WgradParams &p, hipStream_t stream)
     if (e != hipSuccess) return e;
     if (p.ksplit > 1) {
         const long long n = (long long)p.M * p.Cout;
-        wgrad_combine_kernel<<<dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, stream>>>(p.partial, p.ksplit, n, p.accumulate, p.dW);
+        wgrad_combine_kernel<<<dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, stream>>>(p.partial, p.ksplit, n, p.accumulate, p.dW, p.Cout,
+                                                                                            p.ldw ? p.ldw : p.Cout, p.col0);
         e = hipGetLastError();
     }
     return e;

@@ -111,6 +111,8 @@ def _torch_wgrad(x, g, k, s, p):
     (2, 8, 8, 196, 64, 1, 1, 0),          # 1x1
     (1, 20, 24, 64, 64, 7, 2, 3),         # 7x7
     (8, 16, 16, 64, 128, 5, 2, 2),        # longer reduction -> split-K
+    (2, 12, 16, 32, 132, 3, 1, 1),        # 128 + 4 output columns: the 128-wide part and the narrow tail as two launches
+    (1, 40, 48, 16, 388, 1, 1, 0),        # 3 x 128 + 4 columns with a long reduction (both parts split-K)
 ])
 def test_conv_wgrad_matches_autograd(B, Hi, Wi, cin, cout, k, s, p):
     g0 = torch.Generator().manual_seed(B * 100 + cin)
