@@ -139,7 +139,8 @@ struct DgradPlan {
     ConvTile tile;
     bool vec4;
     size_t packed_floats;       // all phases
-    int32_t *tbl;               // device index table, owned by the cache
+    int32_t *tbl;               // device index table, owned by the cache (NULL when `blocked`)
+    int blocked_K;              // > 0: the operand is a plain [K][N] matrix -> launch_pack_blocked instead of the table
     // odd-k stride-2 input gradients: the four output-parity phases have DIFFERENT tap counts ((k+1)/2 or (k-1)/2 per axis), so each
     // is its own launch with exactly its taps instead of one 4-phase launch padded to ceil(k/2)^2 (44 % / 31 % of the MACs of a
     // 3x3 / 5x5 layer were zero taps).  nsub == 0: the single launch `p` is the whole plan.
@@ -433,10 +434,14 @@ bool fwd_plan(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int p
     const KLayout L{d.p.KH, d.p.NSEG, d.p.SEG, d.p.SEGP, d.p.SEG_STRIDE};
     d.packed_floats = (size_t)L.ktiles() * d.p.Npad * 32;
     if (d.p.ksplit > 1) d.part_floats = (size_t)d.p.nphase * d.p.ksplit * d.p.Mmax * d.p.Npad;
-    std::vector<int32_t> tbl(d.packed_floats);
-    pack_index_conv(k, k, cin, cs_x, cout, d.p.Npad, L, tbl.data());
-    if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;
-    if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d.tbl); return false; }
+    if (L.NSEG == 1 && L.SEG == L.SEGP && cs_x == cin && (cout & 3) == 0 && (d.p.Npad & 63) == 0) {
+        d.blocked_K = L.KH * L.SEG;              // HWIO with its first three axes flattened IS the [K][N] matrix
+    } else {
+        std::vector<int32_t> tbl(d.packed_floats);
+        pack_index_conv(k, k, cin, cs_x, cout, d.p.Npad, L, tbl.data());
+        if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;
+        if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d.tbl); return false; }
+    }
     cache[key] = d;
     out = d;
     return true;
@@ -473,7 +478,8 @@ extern "C" int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_
     char *ws = reinterpret_cast<char *>(workspace);
     float *wpk = reinterpret_cast<float *>(ws);
     float *bias = reinterpret_cast<float *>(ws + bias_off);
-    HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
+    if (d.blocked_K) HIP_TRY(nullptr, launch_pack_blocked(W, d.blocked_K, cout, d.p.Npad, 1, wpk, st));
+    else HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
     if (!bias_in && d.p.Npad <= 8192 && zero_bias()) bias = const_cast<float *>(zero_bias());
     else if (bias_in && cout == d.p.Npad) bias = const_cast<float *>(bias_in);
     else {
@@ -562,7 +568,6 @@ namespace {
 struct WinoPlan {
     ConvParams p;               // the 16-phase 1x1 GEMM over the transformed tiles
     size_t phase_floats;        // packed floats per position
-    int32_t *tbl;               // device index table: all 16 positions of the packed operand from Wt [16][K][N]
     int K, N, TH, TW;
 };
 
@@ -594,12 +599,6 @@ bool wino_plan(int B, int H, int W, int K, int N, WinoPlan &out)
     }
     p.Mmax = B * d.TH * d.TW;
     set_ranges(p);
-    std::vector<int32_t> one(d.phase_floats), all(16 * d.phase_floats);
-    pack_index_conv(1, 1, K, K, N, p.Npad, L, one.data());
-    for (int xi = 0; xi < 16; ++xi)
-        for (size_t i = 0; i < d.phase_floats; ++i) all[xi * d.phase_floats + i] = one[i] ? one[i] + xi * K * N : 0;
-    if (hipMalloc(reinterpret_cast<void **>(&d.tbl), all.size() * sizeof(int32_t)) != hipSuccess) return false;
-    if (hipMemcpy(d.tbl, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d.tbl); return false; }
     cache[key] = d;
     out = d;
     return true;
@@ -643,7 +642,7 @@ extern "C" int vstab_conv3x3_winograd(const float *x, int B, int H, int W, int c
     float *M = reinterpret_cast<float *>(ws); ws += a256(tiles * N * 4);
     float *bz = reinterpret_cast<float *>(ws);
     HIP_TRY(nullptr, launch_wino_weights(Wf, cin, cout, transpose, Wt, st));
-    HIP_TRY(nullptr, launch_pack_apply(Wt, d.tbl, (long long)(16 * d.phase_floats), wpk, st));
+    HIP_TRY(nullptr, launch_pack_blocked(Wt, K, N, N, 16, wpk, st));           // 16 x [K][N] -> 16 x [K/32][N][32]
     HIP_TRY(nullptr, hipMemsetAsync(bz, 0, (size_t)N * sizeof(float), st));
     HIP_TRY(nullptr, launch_wino_input(x, B, H, W, cs_x, cx_off, K, V, st));
     ConvParams p = d.p;

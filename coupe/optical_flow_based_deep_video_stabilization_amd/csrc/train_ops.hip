@@ -651,6 +651,48 @@ __global__ __launch_bounds__(256) void pack_apply_kernel(const float *__restrict
     wpk[i] = t ? W[t - 1] : 0.f;
 }
 
+// The same packing without a table for the common case: a plain [K][N] matrix (HWIO with its first three axes flattened -- a layer
+// whose K runs are whole 32-float chunks -- or one Winograd position) -> [K/32][Npad][32] with the 16-byte chunks of row n XOR-swizzled
+// by ((n >> 1) & 7).  A 32 x 64 block goes through LDS so that both the read (rows of N) and the write (128-byte rows) are coalesced;
+// the table replay reads 4 scattered bytes per element plus its 4-byte index.  grid (K/32, Npad/64, batch); N % 4 == 0.
+__global__ __launch_bounds__(256) void pack_blocked_kernel(const float *__restrict__ W, int K, int N, int Npad, float *__restrict__ wpk)
+{
+    __shared__ float tile[32][65];
+    const int kt = blockIdx.x, n0 = blockIdx.y * 64;
+    const float *Wb = W + (long long)blockIdx.z * K * N;
+    float *ob = wpk + (long long)blockIdx.z * (K / 32) * Npad * 32;
+    {
+        const int r = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;
+        const float *src = Wb + (long long)(kt * 32 + r) * N + n0 + c8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            if (n0 + c8 + 4 * h < N) v = *reinterpret_cast<const f32x4v *>(src + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r][c8 + 4 * h + e] = v[e];
+        }
+    }
+    __syncthreads();
+    const int nl = threadIdx.x >> 2, n = n0 + nl;
+    if (n >= Npad) return;
+    float *orow = ob + ((long long)kt * Npad + n) * 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = (threadIdx.x & 3) * 2 + h;
+        f32x4v v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tile[4 * c + e][nl];
+        *reinterpret_cast<f32x4v *>(orow + ((c ^ ((n >> 1) & 7)) << 2)) = v;
+    }
+}
+
+hipError_t launch_pack_blocked(const float *W, int K, int N, int Npad, int batch, float *wpk, hipStream_t stream)
+{
+    if ((K & 31) || (N & 3) || (Npad & 63) || N > Npad || batch < 1) return hipErrorInvalidValue;
+    pack_blocked_kernel<<<dim3((unsigned)(K / 32), (unsigned)(Npad / 64), (unsigned)batch), dim3(256), 0, stream>>>(W, K, N, Npad, wpk);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_apply(const float *W, const int32_t *tbl, long long n, float *wpk, hipStream_t stream)
 {
     pack_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(W, tbl, n, wpk);

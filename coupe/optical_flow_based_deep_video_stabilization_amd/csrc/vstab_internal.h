@@ -348,5 +348,7 @@ void pack_index_dgrad_s2(int k, int pad, int cin, int cout, int cs_g, const KLay
 void pack_index_phase(int k, int cin, int cout, int cs_g, const KLayout &L, int npad, int t0y, int nty, int t0x, int ntx, int32_t *tbl);
 // wpk[i] = tbl[i] ? W[tbl[i]-1] : 0
 hipError_t launch_pack_apply(const float *W, const int32_t *tbl, long long n, float *wpk, hipStream_t stream);
+// table-free packing of a plain [batch][K][N] matrix (K % 32 == 0, N % 4 == 0, Npad % 64 == 0) into [batch][K/32][Npad][32]
+hipError_t launch_pack_blocked(const float *W, int K, int N, int Npad, int batch, float *wpk, hipStream_t stream);
 
 }  // namespace vstab
