@@ -25,10 +25,11 @@ def test_vgg16_every_output_vs_oracle(B, H, W):
     assert net.pool5.shape == (B, -(-H // 32), -(-W // 32), 512)
 
 
-def test_vgg16_winograd_levels_vs_oracle():
-    """Large enough (6 x 256 x 256) for conv3_2 .. conv5_3 to run in Winograd form (their Winograd-domain GEMMs issue > 3 GFLOP);
-    the oracle runs in fp32 here (243 GFLOP), so the tolerance covers two fp32 implementations."""
-    B, H, W = 6, 256, 256
+@pytest.mark.parametrize("B,H,W", [(6, 256, 256), (6, 200, 264)])
+def test_vgg16_winograd_levels_vs_oracle(B, H, W):
+    """Large enough for conv3_2 .. conv5_3 to run in Winograd form (their Winograd-domain GEMMs issue > 3 GFLOP); the second
+    shape makes conv4_x (25x33) and conv5_x (13x17) odd-sized, so tiles hang over the bottom / right edge.  The oracle runs in
+    fp32 here (~200 GFLOP), so the tolerance covers two fp32 implementations."""
     dd = vvgg.synthetic_data_dict(seed=5)
     x = torch.rand(B, H, W, 3, generator=torch.Generator().manual_seed(9))
     net = vvgg.Vgg16(data_dict=dd).build(vvgg.preprocess(x.cuda()))
