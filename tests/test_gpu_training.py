@@ -338,3 +338,37 @@ def test_conv3x3_winograd_filter_gradient(B, H, W, cin, cout):
     assert float((dW.double().cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
     direct, _ = training.conv_wgrad(x.cuda(), g.cuda(), 3, 1, 1, cx_off=4, cin=cin, cg_off=0, cout=cout, want_db=False)
     assert float((dW - direct).abs().max()) <= 3e-5 * float(ref.abs().max())
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """Every C entry point returns a negative code (raised here as ValueError / RuntimeError) instead of launching on bad input."""
+    import ctypes as C
+    from coupe.optical_flow_based_deep_video_stabilization_amd import _lib, runtime
+    L = _lib.lib()
+    x = torch.zeros(1, 8, 8, 32, device="cuda")
+    g = torch.zeros(1, 8, 8, 64, device="cuda")
+    with pytest.raises(ValueError):                                        # gout of another spatial size
+        training.conv3x3_winograd_wgrad(x, torch.zeros(1, 8, 7, 64, device="cuda"))
+    with pytest.raises(ValueError):                                        # channel count not a multiple of 4
+        training.conv3x3_winograd_wgrad(torch.zeros(1, 8, 8, 6, device="cuda"), g)
+    assert L.vstab_conv3x3_winograd_wgrad_workspace_bytes(0, 8, 8, 32, 64) == 0
+    dW = torch.empty(3, 3, 32, 64, device="cuda")
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    code = L.vstab_conv3x3_winograd_wgrad(x.data_ptr(), 1, 8, 8, 32, 0, 32, g.data_ptr(), 64, 0, 64, dW.data_ptr(), ws.data_ptr(), 16,
+                                          runtime.stream_ptr())
+    assert code < 0 and b"workspace" in L.vstab_last_error(None)          # workspace too small
+    code = L.vstab_conv3x3_winograd_wgrad(None, 1, 8, 8, 32, 0, 32, g.data_ptr(), 64, 0, 64, dW.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          runtime.stream_ptr())
+    assert code < 0
+    # loss_main: odd channel stride, too many levels, NULL images
+    desc = (_lib.LossLevelDesc * 1)()
+    pf = torch.zeros(1, 4, 4, 3, device="cuda")
+    desc[0].pf, desc[0].h, desc[0].w, desc[0].cs_pf, desc[0].tv_weight = pf.data_ptr(), 4, 4, 3, 0.0
+    assert L.vstab_loss_main_workspace_bytes(C.addressof(desc), 1, 1) == 0
+    desc[0].cs_pf = 2
+    assert L.vstab_loss_main_workspace_bytes(C.addressof(desc), 9, 1) == 0
+    n = L.vstab_loss_main_workspace_bytes(C.addressof(desc), 1, 1)
+    assert n > 0
+    out = torch.zeros((), dtype=torch.float64, device="cuda")
+    assert L.vstab_loss_main(C.addressof(desc), 1, None, None, 1, 4, 4, out.data_ptr(), ws.data_ptr(), n, runtime.stream_ptr()) < 0
+    torch.cuda.synchronize()
