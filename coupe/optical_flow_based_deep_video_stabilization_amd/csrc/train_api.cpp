@@ -157,8 +157,10 @@ bool dgrad_plan(int B, int Ho, int Wo, int cs_g, int cout, int k, int stride, in
                 int accumulate, DgradPlan &out)
 {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int, int>, DgradPlan> cache;
-    const auto key = std::make_tuple(B, Ho, Wo, cs_g, cout, k, stride, pad, Hi, Wi, cs_x, cx_off, cin, accumulate);
+    static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int, int, int>, DgradPlan> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;             // the plan owns an index table in THIS device's memory
+    const auto key = std::make_tuple(dev, B, Ho, Wo, cs_g, cout, k, stride, pad, Hi, Wi, cs_x, cx_off, cin, accumulate);
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) { out = it->second; return true; }
@@ -414,8 +416,10 @@ bool fwd_plan(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int p
               DgradPlan &out)
 {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int, int>, DgradPlan> cache;
-    const auto key = std::make_tuple(B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo);
+    static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int, int, int>, DgradPlan> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;             // (a table-packed plan owns device memory)
+    const auto key = std::make_tuple(dev, B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo);
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) { out = it->second; return true; }
