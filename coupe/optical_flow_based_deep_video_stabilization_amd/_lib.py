@@ -91,6 +91,7 @@ EXPORTS = {
     "vstab_loss_main_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "vstab_loss_main": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),
+    "vstab_resize_f32_to_u8": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vstab_homography_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "vstab_homography_fit": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_uint, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_size_t, C.c_void_p]),

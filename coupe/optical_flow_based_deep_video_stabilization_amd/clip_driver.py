@@ -104,3 +104,65 @@ class ClipStabiliser:
         self.reset()
         out = torch.stack([self.step(clip[t]) for t in range(clip.shape[0])])
         return out[:, 0] if single else out
+
+
+class NativeClipStabiliser:
+    """The native-resolution evaluator loop (`evaluate`, main:758-866; with a `flow_filter` also `evaluate_blurNma` /
+    `evaluate_medianNma` of main_flownetS_pyramid.py:582-821): every frame is brought to the network resolution (cv2.resize),
+    stacked behind the previously OUTPUT frames at lags 1,2,3,4,7,15,23,31 (main:844 -- the other order than evaluate_originalSize),
+    and the current frame, resized to the 382x510 flow grid, is warped by predict_flow2 (or by `flow_filter(predict_flow2)`:
+    `postfilters.BlurEmaFilter()`, `MedianEmaFilter()`).  The warped frame, resized back to 384x512 and quantised, is both the result
+    and the history (main:861-863).  Frames: uint8 [n_clips, H, W, 3] BGR CUDA tensors; results uint8 [n_clips, 384, 512, 3]."""
+    LAGS = (1, 2, 3, 4, 7, 15, 23, 31)            # stabidxs, main:844
+
+    def __init__(self, n_clips: int = 1, net_hw=(384, 512), scope: str = 'flownetS', device: Optional[int] = None, flow_filter=None):
+        runtime._require_gpu()
+        self.n, self.net_h, self.net_w = int(n_clips), int(net_hw[0]), int(net_hw[1])
+        self.scope, self.flow_filter = scope, flow_filter
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.device = dev
+        self.ring = torch.zeros((RING, self.n, self.net_h, self.net_w, 3), dtype=torch.uint8, device=dev)
+        self.feats = torch.empty((self.n, self.net_h, self.net_w, 27), dtype=torch.float32, device=dev)
+        self.i = 0
+        self.last_flows = None
+
+    def reset(self):
+        self.i = 0
+        self.last_flows = None
+
+    def step(self, frame_bgr_u8: torch.Tensor) -> torch.Tensor:
+        from .model import flownetS_pyramid
+        from .warp_flow import resize_images, tf_warp
+        f = _u8(frame_bgr_u8, "frame")
+        if f.shape[0] != self.n:
+            raise ValueError(f"frame must hold {self.n} clips, got {f.shape[0]}")
+        L = _lib.lib()
+        i = self.i
+        cur_small = resize_u8(f, (self.net_h, self.net_w))                       # main:842-843
+        slots = [cur_small if i == 0 else self.ring[max(i - lag, 0) % RING] for lag in self.LAGS]      # main:845-849
+        slots.append(cur_small)
+        ptrs = (C.c_void_p * 9)(*[s.data_ptr() for s in slots])
+        with torch.cuda.device(self.device):
+            _lib.check(L.vstab_assemble_input(ptrs, self.n, self.net_h, self.net_w, self.feats.data_ptr(), runtime.stream_ptr()))
+        flows = flownetS_pyramid(self.feats, self.n, is_train=False, scope=self.scope)                  # main:804
+        of = flows['predict_flow2']
+        flow = self.flow_filter(of) if self.flow_filter is not None else of
+        fh, fw = self.net_h - 2, self.net_w - 2
+        unstab = resize_images(self.feats[..., 24:27].contiguous(), (fh, fw))                           # main:806
+        warped = tf_warp(unstab, flow, fh, fw)                                                          # main:807
+        out = torch.empty((self.n, self.net_h, self.net_w, 3), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.vstab_resize_f32_to_u8(warped.data_ptr(), self.n, fh, fw, out.data_ptr(), self.net_h, self.net_w,
+                                                runtime.stream_ptr()))                                   # main:861, 863
+        self.ring[i % RING].copy_(out)
+        self.last_flows = flows
+        self.i += 1
+        return out
+
+    def run(self, clip_bgr_u8: torch.Tensor) -> torch.Tensor:
+        """clip [T, n, H, W, 3] (or [T, H, W, 3] for one clip) -> stabilised clip [T, n, 384, 512, 3] (or [T, 384, 512, 3])."""
+        single = clip_bgr_u8.dim() == 4
+        clip = clip_bgr_u8.unsqueeze(1) if single else clip_bgr_u8
+        self.reset()
+        out = torch.stack([self.step(clip[t]) for t in range(clip.shape[0])])
+        return out[:, 0] if single else out

@@ -1151,6 +1151,14 @@ extern "C" int vstab_resize_u8(const uint8_t *src, int B, int sh, int sw, uint8_
     return VSTAB_OK;
 }
 
+extern "C" int vstab_resize_f32_to_u8(const float *src, int B, int sh, int sw, uint8_t *dst, int dh, int dw, void *stream)
+{
+    if (!src || !dst) return fail(nullptr, VSTAB_E_STATE, "resize_f32_to_u8: NULL buffer");
+    if (B < 1 || sh < 1 || sw < 1 || dh < 1 || dw < 1) return fail(nullptr, VSTAB_E_SHAPE, "resize_f32_to_u8: bad shape");
+    HIP_TRY(nullptr, launch_resize_f32_to_u8(src, B, sh, sw, dst, dh, dw, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_assemble_input(const uint8_t *const *slots9, int B, int h, int w, float *feats, void *stream)
 {
     if (!slots9 || !feats) return fail(nullptr, VSTAB_E_STATE, "assemble_input: NULL buffer");

@@ -94,6 +94,50 @@ __global__ __launch_bounds__(256) void quantise_output_kernel(const float *__res
     }
 }
 
+// The native-resolution evaluator (main:758-866; also evaluate_blurNma / evaluate_medianNma of main_flownetS_pyramid.py) keeps its
+// history as  totaloutputFrame[i] = cv2.cvtColor(cv2.resize(warped, (512, 384)) * 255, COLOR_RGB2BGR)  (main:861) and reads it back
+// through np.uint8 (main:849, 863): cv2.resize on a float32 image is the same half-pixel-centre bilinear as the 8-bit path with float
+// coefficients (HResizeLinear: S[x0]*a0 + S[x1]*a1, then VResizeLinear: b0*R0 + b1*R1), then * 255, channels swapped, truncated.
+// UNVERIFIED against cv2 like resize_u8_kernel; the oracle restates the same arithmetic.  src f32 [B,sh,sw,3] -> dst u8 [B,dh,dw,3].
+__global__ __launch_bounds__(256) void resize_f32_to_u8_kernel(const float *__restrict__ src, int B, int sh, int sw,
+                                                               unsigned char *__restrict__ dst, int dh, int dw)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * dh * dw) return;
+    const int n = (int)(idx / (dh * dw));
+    const int rem = (int)(idx - (long long)n * dh * dw);
+    const int dy = rem / dw, dx = rem - dy * dw;
+    auto tap = [](int d, int dn, int sn, int &i0, int &i1, float &a0, float &a1) {
+        const float scale = (float)((double)sn / (double)dn);
+        float f = (float)(((double)d + 0.5) * (double)scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= sn - 1) { f = 0.f; s = sn - 1; }
+        i0 = s; i1 = min(s + 1, sn - 1); a0 = 1.f - f; a1 = f;
+    };
+    int x0, x1, y0, y1;
+    float ax0, ax1, ay0, ay1;
+    tap(dx, dw, sw, x0, x1, ax0, ax1);
+    tap(dy, dh, sh, y0, y1, ay0, ay1);
+    const float *b = src + (long long)n * sh * sw * 3;
+    const float *r0 = b + (long long)y0 * sw * 3, *r1 = b + (long long)y1 * sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float R0 = r0[x0 * 3 + c] * ax0 + r0[x1 * 3 + c] * ax1;
+        const float R1 = r1[x0 * 3 + c] * ax0 + r1[x1 * 3 + c] * ax1;
+        const float v = (ay0 * R0 + ay1 * R1) * 255.0f;
+        dst[idx * 3 + (2 - c)] = (unsigned char)fminf(fmaxf(truncf(v), 0.f), 255.f);
+    }
+}
+
+hipError_t launch_resize_f32_to_u8(const float *src, int B, int sh, int sw, unsigned char *dst, int dh, int dw, hipStream_t stream)
+{
+    const long long total = (long long)B * dh * dw;
+    resize_f32_to_u8_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(src, B, sh, sw, dst, dh, dw);
+    return hipGetLastError();
+}
+
 hipError_t launch_resize_u8(const unsigned char *src, int B, int sh, int sw, unsigned char *dst, int dh, int dw, hipStream_t stream)
 {
     const long long total = (long long)B * dh * dw;

@@ -198,6 +198,7 @@ hipError_t launch_vec2mtrx(const float *p, int B, int dim, int approx, float *ou
 
 // clip driver helpers (clip_ops.hip)
 hipError_t launch_resize_u8(const unsigned char *src, int B, int sh, int sw, unsigned char *dst, int dh, int dw, hipStream_t stream);
+hipError_t launch_resize_f32_to_u8(const float *src, int B, int sh, int sw, unsigned char *dst, int dh, int dw, hipStream_t stream);
 hipError_t launch_assemble_input(const unsigned char *const *slots9, int B, int h, int w, float *feats, hipStream_t stream);
 hipError_t launch_frame_to_float(const unsigned char *f, long long npix, float *out, hipStream_t stream);
 hipError_t launch_quantise_output(const float *warped, long long npix, unsigned char *out, hipStream_t stream);

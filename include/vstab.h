@@ -195,6 +195,9 @@ VSTAB_API int vstab_nldf_forward(vstab_ctx *ctx, const float *const *pools5, int
  * All frames are uint8 [B,h,w,3] in cv2's BGR order, device memory. */
 /* cv2.resize(src, (dw, dh)), INTER_LINEAR, 8-bit (main:550,556-558): restated fixed-point algorithm, see clip_ops.hip. */
 VSTAB_API int vstab_resize_u8(const uint8_t *src, int B, int sh, int sw, uint8_t *dst, int dh, int dw, void *stream);
+/* np.uint8(cv2.cvtColor(cv2.resize(img_f32, (dw, dh)) * 255, COLOR_RGB2BGR)) (main:861-863: the native evaluator's history frame):
+ * float bilinear resize with cv2's half-pixel centres, * 255, channels 0 and 2 swapped, truncated to 8 bits.  src [B,sh,sw,3]. */
+VSTAB_API int vstab_resize_f32_to_u8(const float *src, int B, int sh, int sw, uint8_t *dst, int dh, int dw, void *stream);
 /* curinput (main:550-558): feats[B,h,w,27]; slot j < 8 = history frame of lag {31,23,15,7,4,3,2,1}[j], slot 8 = current
  * frame, each u8 [B,h,w,3] at network resolution; channels swapped (COLOR_RGB2BGR) and divided by 255. */
 VSTAB_API int vstab_assemble_input(const uint8_t *const *slots9, int B, int h, int w, float *feats, void *stream);

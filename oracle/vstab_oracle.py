@@ -664,6 +664,59 @@ def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32, t
     return np.stack(outs)
 
 
+def cv_resize_f32(src: np.ndarray, dh: int, dw: int) -> np.ndarray:
+    """cv2.resize(src, (dw, dh)) INTER_LINEAR on a float32 HxWxC image (main:861): the taps of cv_resize_u8 with float coefficients,
+    horizontal pass then vertical pass in float32.  UNVERIFIED against cv2 (not installed)."""
+    sh, sw = src.shape[:2]
+
+    def taps(dn, sn):
+        scale = np.float32(np.float64(sn) / np.float64(dn))
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * np.float64(scale) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        f[lo] = 0; s[lo] = 0
+        hi = s >= sn - 1
+        f[hi] = 0; s[hi] = sn - 1
+        return s, np.minimum(s + 1, sn - 1), (np.float32(1) - f).astype(np.float32), f
+
+    x0, x1, ax0, ax1 = taps(dw, sw)
+    y0, y1, ay0, ay1 = taps(dh, sh)
+    S = src.astype(np.float32)
+    R = (S[:, x0] * ax0[None, :, None] + S[:, x1] * ax1[None, :, None]).astype(np.float32)
+    return (ay0[:, None, None] * R[y0] + ay1[:, None, None] * R[y1]).astype(np.float32)
+
+
+def native_clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32, flow_filter=None, teacher=None):
+    """The loop of evaluate() (main:831-863) on a clip [T,H,W,3] uint8 BGR -> [T,384,512,3] uint8; `flow_filter(of)` maps predict_flow2 to
+    the flow that warps (evaluate_blurNma / evaluate_medianNma); `teacher` as in clip_loop."""
+    T = frames_bgr_u8.shape[0]
+    nh, nw = net_hw
+    lags = (1, 2, 3, 4, 7, 15, 23, 31)                                             # main:844
+    total = np.zeros((T, nh, nw, 3), np.float64)
+    outs = []
+    for i in range(T):
+        small = cv_resize_u8(frames_bgr_u8[i], nh, nw)
+        if i == 0:
+            total[0] = small                                                       # main:841
+        cur = np.zeros((1, nh, nw, 27), np.float64)
+        cur[0, :, :, 24:27] = small[..., ::-1] / 255.0                             # main:842
+        for j, lag in enumerate(lags):                                             # main:845-849
+            src = total[0] if i - lag < 0 else total[i - lag]
+            q = np.clip(np.trunc(src), 0, 255).astype(np.uint8)
+            cur[0, :, :, 3 * j:3 * j + 3] = np.float32(q[..., ::-1]) / 255.0
+        flows = flownetS_pyramid(cur, weights, dtype=dtype)
+        of = flows["predict_flow2"]
+        flow = of if flow_filter is None else flow_filter(of)
+        unstab = resize_bilinear_legacy(_t(cur[..., 24:27], dtype), nh - 2, nw - 2)   # main:806
+        warped = tf_warp(unstab, flow, nh - 2, nw - 2, dtype)[0].numpy().astype(np.float32)
+        total[i] = (cv_resize_f32(warped, nh, nw) * np.float32(255))[..., ::-1]    # main:861
+        outs.append(np.clip(np.trunc(total[i]), 0, 255).astype(np.uint8))          # main:863
+        if teacher is not None:
+            total[i] = teacher[i].astype(np.float64)
+    return np.stack(outs)
+
+
 # --------------------------------------------------------------------------- training objective
 LOSS_LEVELS = ("predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3", "predict_flow2")
 TV_WEIGHTS = (2e-8 * 3, 2e-8 * 3, 2e-8 * 3, 4e-8 * 1.5, 4e-8 * 1.5)          # main:269-273
