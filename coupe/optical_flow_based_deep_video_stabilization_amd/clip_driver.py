@@ -41,10 +41,12 @@ def resize_u8(src: torch.Tensor, size_hw) -> torch.Tensor:
 
 class ClipStabiliser:
     def __init__(self, out_h: int, out_w: int, n_clips: int = 1, net_hw=(384, 512), scope: str = 'flownetS',
-                 device: Optional[int] = None, homography: bool = False, ransac: Optional[dict] = None):
+                 device: Optional[int] = None, homography: bool = False, ransac: Optional[dict] = None, flow_filter=None):
         """homography=True is the evaluator of main:728-743: the frame WRITTEN is the unstable frame under one
         homography fitted to the dense flow (cv2.findHomography + cv2.warpPerspective), while the history later frames
-        read stays the flow-warped frame (main:739).  `ransac` = keyword arguments of postfilters.find_homography."""
+        read stays the flow-warped frame (main:739).  `ransac` = keyword arguments of postfilters.find_homography.
+        `flow_filter` (e.g. postfilters.MeanFlow3Filter(): the highTV evaluator, ...highTV...:629-631) maps the output-resolution flow
+        to the flow that warps."""
         runtime._require_gpu()
         self.out_h, self.out_w, self.n = int(out_h), int(out_w), int(n_clips)
         self.net_h, self.net_w = int(net_hw[0]), int(net_hw[1])
@@ -58,6 +60,7 @@ class ClipStabiliser:
         self.last_flows = None
         self.homography, self.ransac, self.last_homography = bool(homography), dict(ransac or {}), None
         self.last_outflow = None
+        self.flow_filter = flow_filter
 
     def reset(self):
         self.i = 0
@@ -83,7 +86,7 @@ class ClipStabiliser:
             _lib.check(L.vstab_assemble_input(ptrs, self.n, self.net_h, self.net_w, self.feats.data_ptr(), runtime.stream_ptr()))
             _lib.check(L.vstab_frame_to_float(f.data_ptr(), self.n * self.out_h * self.out_w, self.frame_f.data_ptr(),
                                               runtime.stream_ptr()))                                   # main:568
-        flows, outflow, warped = stabilise_originalsize(self.feats, self.frame_f, scope=self.scope)    # main:569
+        flows, outflow, warped = stabilise_originalsize(self.feats, self.frame_f, scope=self.scope, flow_filter=self.flow_filter)    # main:569
         out = torch.empty_like(f)
         with torch.cuda.device(self.device):
             _lib.check(L.vstab_quantise_output(warped.data_ptr(), self.n * self.out_h * self.out_w, out.data_ptr(),

@@ -6,14 +6,15 @@ from .model import flownetS_pyramid
 from .warp_flow import flow_to_output_res, resize_images, tf_warp
 
 
-def stabilise_originalsize(feats, frame, scope='flownetS'):
+def stabilise_originalsize(feats, frame, scope='flownetS', flow_filter=None):
     """feats [B,Hn,Wn,Cin] network input, frame [B,oh,ow,3] the unstable frame at output
-    resolution -> (flows dict, outflow [B,oh,ow,2], warped [B,oh,ow,3])  (main:495-514)."""
+    resolution -> (flows dict, outflow [B,oh,ow,2], warped [B,oh,ow,3])  (main:495-514).  `flow_filter(outflow)` (e.g.
+    postfilters.MeanFlow3Filter, the highTV evaluator) replaces the flow that warps; the returned outflow is the filter's input."""
     flows = flownetS_pyramid(feats, feats.shape[0], is_train=False, scope=scope)
     Hn, Wn = feats.shape[1], feats.shape[2]
     oh, ow = frame.shape[1], frame.shape[2]
     outflow = flow_to_output_res(flows['predict_flow2'], Hn, Wn, oh, ow)
-    return flows, outflow, tf_warp(frame, outflow, oh, ow)
+    return flows, outflow, tf_warp(frame, outflow if flow_filter is None else flow_filter(outflow), oh, ow)
 
 
 def stabilise_native(feats, scope='flownetS'):

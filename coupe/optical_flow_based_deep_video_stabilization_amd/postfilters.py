@@ -135,3 +135,23 @@ class MedianEmaFilter(BlurEmaFilter):
         out = axpby(self.alpha, med, 1.0 - self.alpha, self.prev)
         self.prev = axpby(self.alpha, self.prev, 1.0 - self.alpha, med)
         return out
+
+
+class MeanFlow3Filter:
+    """The highTV evaluator's flow (main_flownetS_pyramid_highTV_noBBloss.py:629-631, 679-685): the output-resolution flow is replaced
+    by its per-channel global mean (a pure translation), and the frame is warped by the average of this mean flow and the mean flows
+    of the previous (up to) two frames:  outflowMean = (ofsum + outflow) / ofnum,  ofnum = min(i + 1, 3)."""
+
+    def __init__(self, n: int = 3):
+        self.n, self.hist = int(n), []
+
+    def __call__(self, outflow):
+        m = mean_flow(outflow)
+        k = min(len(self.hist) + 1, self.n)
+        s = m
+        for j in range(k - 1):                              # curflowsum += totaloutputOF[i-j-1]  (:681-682)
+            s = axpby(1.0, s, 1.0, self.hist[-1 - j])
+        self.hist.append(m)
+        if len(self.hist) > self.n:
+            self.hist.pop(0)
+        return axpby(1.0 / k, s, 0.0, s)

@@ -294,15 +294,32 @@ def warp_discontinuity_mask(flow, H: int, W: int, delta: float = 1e-2):
 
 
 # --------------------------------------------------------------------------- whole path
-def stabilise_originalsize(feats, frame, weights, dtype=torch.float64):
+def stabilise_originalsize(feats, frame, weights, dtype=torch.float64, flow_filter=None):
     """The graph `evaluate_originalSize` builds (main:491-514): network on `feats`
-    [B,Hn,Wn,Cin], flow brought to the output resolution of `frame` [B,oh,ow,3], warp."""
+    [B,Hn,Wn,Cin], flow brought to the output resolution of `frame` [B,oh,ow,3], warp (by `flow_filter(outflow)` if given)."""
     flows = flownetS_pyramid(feats, weights, dtype)
     Hn, Wn = feats.shape[1], feats.shape[2]
     oh, ow = frame.shape[1], frame.shape[2]
     outflow = flow_to_output_res(flows["predict_flow2"], Hn, Wn, oh, ow)
-    warped = tf_warp(_t(frame, dtype), outflow.to(torch.float32), oh, ow, dtype)
+    wf = outflow if flow_filter is None else flow_filter(outflow)
+    warped = tf_warp(_t(frame, dtype), wf.to(torch.float32), oh, ow, dtype)
     return flows, outflow, warped
+
+
+class MeanFlow3:
+    """main_flownetS_pyramid_highTV_noBBloss.py:629-631, 679-685: warp by (sum of the previous <= 2 mean flows + this mean flow) / min(i+1, 3)."""
+
+    def __init__(self):
+        self.hist = []
+
+    def __call__(self, outflow):
+        m = mean_flow(outflow)
+        k = min(len(self.hist) + 1, 3)
+        s = m.clone()
+        for j in range(k - 1):
+            s = s + self.hist[-1 - j]
+        self.hist.append(m)
+        return s / k
 
 
 def stabilise_native(feats, weights, dtype=torch.float64):
@@ -635,7 +652,7 @@ def cv_warp_perspective_u8(src, M, oh, ow):
     return np.clip(acc, 0, 255).astype(np.uint8)
 
 
-def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32, teacher=None):
+def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32, teacher=None, flow_filter=None):
     """The loop of evaluate_originalSize (main:540-630) on a clip [T,H,W,3] uint8 BGR -> stabilised uint8 clip.
     `teacher` ([T,H,W,3] uint8, another implementation's outputs): if given, frame i is still computed here but the
     HISTORY later frames read is the teacher's frame i -- a per-frame check that cannot drift (the free-running loop
@@ -656,7 +673,7 @@ def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32, t
             q = np.clip(np.trunc(src), 0, 255).astype(np.uint8)                    # np.uint8(...)
             cur[0, :, :, 3 * j:3 * j + 3] = np.float32(cv_resize_u8(q, nh, nw)[..., ::-1]) / 255.0
         frame_f = (frame[..., ::-1] / 255.0).astype(np.float32)[None]              # main:568
-        _, _, warped = stabilise_originalsize(cur, frame_f, weights, dtype)        # main:569
+        _, _, warped = stabilise_originalsize(cur, frame_f, weights, dtype, flow_filter)        # main:569
         total[i] = (warped[0].numpy().astype(np.float64) * 255.0)[..., ::-1]       # main:625
         outs.append(np.clip(np.trunc(total[i]), 0, 255).astype(np.uint8))          # main:630
         if teacher is not None:
