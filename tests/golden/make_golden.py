@@ -55,7 +55,44 @@ def make_warp():
     print("warp_37x53", out.shape)
 
 
+def make_widening():
+    """Small vectors for the rows built around the path: cv2-style resizes, homography evaluator, training loss."""
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    out = {"img_u8": img, "resize_u8_48x64": vo.cv_resize_u8(img, 48, 64)}
+    imgf = rng.random((46, 62, 3), dtype=np.float32)
+    out["img_f32"] = imgf
+    out["resize_f32_48x64"] = vo.cv_resize_f32(imgf, 48, 64)
+    # a homography field with 30 % gross outliers
+    H, W = 48, 64
+    Ht = np.array([[1.02, 0.01, 1.5], [-0.015, 0.99, -1.0], [1e-5, -2e-5, 1.0]])
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    d = Ht[2, 0] * xs + Ht[2, 1] * ys + Ht[2, 2]
+    flow = np.stack([xs - (Ht[0, 0] * xs + Ht[0, 1] * ys + Ht[0, 2]) / d, ys - (Ht[1, 0] * xs + Ht[1, 1] * ys + Ht[1, 2]) / d], -1).astype(np.float32)
+    bad = rng.random((H, W)) < 0.3
+    flow[bad] += rng.uniform(-25, 25, (int(bad.sum()), 2)).astype(np.float32)
+    M, n_in = vo.homography_fit(flow, K=64, seed=9, thresh=3.0, refine=2)
+    frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    out.update(homo_flow=flow, homo_H=M, homo_inliers=np.int64(n_in), homo_frame=frame,
+               homo_warped=vo.cv_warp_perspective_u8(frame, M, H, W))
+    # loss_main on seeded flows
+    B, Hh, Ww = 2, 64, 96
+    sizes = [(1, 2), (2, 3), (4, 6), (8, 12), (62, 94)]
+    g = torch.Generator().manual_seed(5)
+    gt, un = torch.rand(B, Hh, Ww, 3, generator=g), torch.rand(B, Hh, Ww, 3, generator=g)
+    flows = {k: (torch.randn(B, h, w, 2, generator=g) * 1.5).requires_grad_(True) for k, (h, w) in zip(vo.LOSS_LEVELS, sizes)}
+    loss = vo.loss_main(flows, gt, un)
+    loss.backward()
+    out.update(loss_gt=gt.numpy(), loss_un=un.numpy(), loss_value=np.float64(loss.detach()))
+    for k in vo.LOSS_LEVELS:
+        out["loss_flow_" + k] = flows[k].detach().numpy()
+        out["loss_grad_" + k] = flows[k].grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "widening_small.npz"), **out)
+    print("widening_small", {k: getattr(v, "shape", ()) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     for n in CASES:
         make(n)
     make_warp()
+    make_widening()

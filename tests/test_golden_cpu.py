@@ -98,3 +98,16 @@ def test_sizes_rule():
     with pytest.raises(ValueError):
         netspec.sizes_for(2, 2)
     assert abs(netspec.gflop_per_sample(512, 512) - 52.43) < 0.01
+
+
+def test_widening_golden_oracle():
+    """The oracle reproduces the committed vectors of the rows built around the path (tests/golden/make_golden.py: make_widening)."""
+    z = np.load(os.path.join(GOLD, "widening_small.npz"))
+    assert np.array_equal(vo.cv_resize_u8(z["img_u8"], 48, 64), z["resize_u8_48x64"])
+    assert np.array_equal(vo.cv_resize_f32(z["img_f32"], 48, 64), z["resize_f32_48x64"])
+    M, n = vo.homography_fit(z["homo_flow"], K=64, seed=9, thresh=3.0, refine=2)
+    assert n == int(z["homo_inliers"]) and np.abs(M - z["homo_H"]).max() < 1e-10
+    assert np.array_equal(vo.cv_warp_perspective_u8(z["homo_frame"], z["homo_H"], 48, 64), z["homo_warped"])
+    flows = {k: torch.from_numpy(z["loss_flow_" + k]) for k in vo.LOSS_LEVELS}
+    loss = vo.loss_main(flows, torch.from_numpy(z["loss_gt"]), torch.from_numpy(z["loss_un"]))
+    assert abs(float(loss) - float(z["loss_value"])) < 1e-10

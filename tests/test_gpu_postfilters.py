@@ -144,3 +144,27 @@ def test_homography_fit_still_camera_and_batch():
     assert float((Hm[0].cpu() - eye).abs().max()) < 1e-12
     shift = eye.clone(); shift[0, 2] = -1.0
     assert float((Hm[1].cpu() - shift).abs().max()) < 1e-12
+
+
+def test_widening_golden_gpu():
+    """HIP path against the committed vectors of tests/golden/widening_small.npz (resizes, homography evaluator, training loss)."""
+    import os
+    from coupe.optical_flow_based_deep_video_stabilization_amd import _lib, clip_driver, runtime, training
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "widening_small.npz"))
+    got = clip_driver.resize_u8(torch.from_numpy(z["img_u8"][None]).cuda(), (48, 64)).cpu().numpy()[0]
+    assert np.array_equal(got, z["resize_u8_48x64"])
+    src = torch.from_numpy(z["img_f32"][None]).cuda()
+    dst = torch.empty((1, 48, 64, 3), dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.lib().vstab_resize_f32_to_u8(src.data_ptr(), 1, 46, 62, dst.data_ptr(), 48, 64, runtime.stream_ptr()))
+    want = np.clip(np.trunc(z["resize_f32_48x64"] * np.float32(255)), 0, 255).astype(np.uint8)[..., ::-1]
+    assert np.array_equal(dst.cpu().numpy()[0], want)
+    Hm, inl = pf.find_homography(torch.from_numpy(z["homo_flow"][None]).cuda(), K=64, seed=9, thresh=3.0, refine=2)
+    assert int(inl[0]) == int(z["homo_inliers"]) and np.abs(Hm[0].cpu().numpy() - z["homo_H"]).max() <= 1e-8
+    w = pf.warp_perspective_u8(torch.from_numpy(z["homo_frame"][None]).cuda(), torch.from_numpy(z["homo_H"][None]).cuda())
+    assert np.array_equal(w.cpu().numpy()[0], z["homo_warped"])
+    flows = {k: torch.from_numpy(z["loss_flow_" + k]).cuda() for k in vo.LOSS_LEVELS}
+    loss, grads = training.loss_main(flows, torch.from_numpy(z["loss_gt"]).cuda(), torch.from_numpy(z["loss_un"]).cuda())
+    assert abs(float(loss) - float(z["loss_value"])) <= 2e-5 * max(1.0, abs(float(z["loss_value"])))
+    for k in vo.LOSS_LEVELS:
+        r = z["loss_grad_" + k]
+        assert np.abs(grads[k].cpu().numpy() - r).max() <= 2e-5 * max(float(np.abs(r).max()), 1e-6) + 1e-9, k
