@@ -28,6 +28,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = vector fp32 peak
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def load_launch_module():
+    """coupe/.../launch.py loaded by path: the parent of a self-launched job must not import the package
+    (which loads the HIP library) or touch the GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "vstab_launch", os.path.join(ROOT, "coupe", "optical_flow_based_deep_video_stabilization_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def log(*a):
@@ -102,12 +114,17 @@ def main():
                     help="BASELINE config 5: also run the VGG16 trunk (preprocess + 13 conv + 5 pool) on the warped frames")
     args = ap.parse_args()
 
+    # --gpus N without a launcher: start the N ranks ourselves as a CHILD job, before anything touches the GPU
+    # (VSTAB_FORCE_DIST=1 rehearses the same launcher + RCCL path with however many ranks --gpus names, also 1)
+    rc = load_launch_module().maybe_self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus,
+                                                force=os.environ.get("VSTAB_FORCE_DIST") == "1")
+    if rc is not None:
+        raise SystemExit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)

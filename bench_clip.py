@@ -7,8 +7,8 @@ samples and the clip shards by contiguous blocks (the autoregressi
 not shard by frame -- that is clip_driver.ClipStabiliser, batched over clips instead).  Strong scaling:
 the clip is fixed, ranks split it.
 
-    python bench_clip.py --frames 1000 [--height 1080 --width 1920 --micro-batch 8]
-    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 bench_clip.py --frames 1000
+    python bench_clip.py --frames 1000 [--gpus N --height 1080 --width 1920 --micro-batch 8]     (starts its own N ranks)
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 bench_clip.py --gpus N --frames 1000
 """
 import argparse
 import json
@@ -31,7 +31,17 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--cin", type=int, default=27)
     ap.add_argument("--micro-batch", type=int, default=8)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to start when not already under a launcher")
     args = ap.parse_args()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "vstab_launch", os.path.join(ROOT, "coupe", "optical_flow_based_deep_video_stabilization_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    rc = launch.maybe_self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus,
+                                  force=os.environ.get("VSTAB_FORCE_DIST") == "1")     # child job; nothing here touches the GPU
+    if rc is not None:
+        raise SystemExit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
