@@ -197,6 +197,7 @@ def main():
     torch.cuda.synchronize()
     use_events = not args.no_kernel_events
     ctx.profile(use_events)
+    runtime.hbm_profile(1 if use_events else 0)     # dispatch-timestamp events around the glue+warp launch too
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -207,6 +208,7 @@ def main():
         if use_events:
             on = (k % ev_every == 0)
             ctx.profile_set(on)
+            runtime.hbm_profile(2 if on else 0)
             n_event_steps += int(on)
         out = step()
     if gather is not None:
@@ -246,20 +248,24 @@ def main():
                 log(f"{name:<14}{m:>9.4f}{f / 1e9:>10.2f}{tf:>10.1f}{tf / MFMA_F32_PEAK_TFLOPS:>8.3f}  {k}")
             log(f"{'all conv':<14}{tot_ms:>9.4f}{tot_fl / 1e9:>10.2f}{tot_fl / (tot_ms * 1e-3) / 1e12:>10.1f}"
                 f"{tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS:>8.3f}   step {elapsed / args.steps * 1e3:.3f} ms")
-        traffic = None
-        try:     # HBM bytes per launch of the dominant kernel, from the latest committed rocprofv3 PMC pass
-            import glob
-            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_*.json")))
-            if pj:
-                traffic = json.load(open(pj[-1])).get(dom, {}).get("hbm_bytes_per_launch_corrected")
-        except Exception:
-            traffic = None
+        traffic, traffic_source = None, "none"
+        if (B, H, W, Cin) == (8, 512, 512, 27):
+            try:     # NOT measured by this run: HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC pass of
+                     # this workload (counters need their own profiler runs; scripts/gpu_profile.sh + scripts/pmc_summary.py)
+                import glob
+                pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_*.json")))
+                if pj:
+                    traffic = json.load(open(pj[-1])).get(dom, {}).get("hbm_bytes_per_launch_corrected")
+                    if traffic is not None:
+                        traffic_source = "static: profiles/" + os.path.basename(pj[-1]) + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of the same command, corrected per MI355X_MICROARCH.md)"
+            except Exception:
+                traffic, traffic_source = None, "none"
         d_ms, d_fl, d_n, d_dfl = groups[dom]
         tot_dfl = sum(dflops)
         achieved = d_fl / (d_ms * 1e-3) / 1e12
         all_tf = tot_fl / (tot_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": dom, "launches_per_step": d_n, "event_steps": n_event_steps,
                     "avg_launch_us": round(d_ms / d_n * 1e3, 2),
                     "alg_flops_per_launch_avg": d_fl / d_n,
@@ -274,10 +280,33 @@ def main():
                                           "alg_flops_per_step": tot_fl, "direct_flops_per_step": tot_dfl,
                                           "frac_direct": round(tot_dfl / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}}
 
+    # ---- HBM-side roofline: the glue + warp launch of the same timed steps.  achieved = ALGORITHMIC bytes of the
+    # launch (8 B per source-flow pixel + 8 B output flow + 12 B frame read + 12 B written per output pixel) / its kernel time
+    # from dispatch-timestamp events on the launch stream; peak = 8 TB/s (HBM3E spec; 6.3 TB/s is what a float4 copy reaches).
+    roofline_hbm = None
+    if use_events:
+        runtime.hbm_profile(0)
+        hp = runtime.hbm_profile_read()
+        name = max(hp, key=lambda k: hp[k][0])
+        ms_sum, nl, by = hp[name]
+        if nl > 0 and ms_sum > 0:
+            kernels = {"flow_glue_warp": "warp3_tile_kernel<true, true, 4, 16, 32, 2, true, false, " + ("true" if W % 4 == 0 else "false") + ">",
+                       "warp_flow": "warp3_tile_kernel<false, false, ...>", "flow_resize_scale": "flow_resize_scale_kernel"}
+            gbs = by / (ms_sum * 1e-3) / 1e9
+            roofline_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": "not measured by this run",
+                            "kernel": kernels[name], "entry_point": "vstab_" + name, "launches": nl,
+                            "avg_launch_us": round(ms_sum / nl * 1e3, 2), "alg_bytes_per_launch": by / nl,
+                            "alg_bytes_per_output_pixel": round(by / nl / (B * H * W), 2),
+                            "note": "limit is the L1 tag pipe (12-byte gathers), not HBM: profiles/README.md, r02 warp study; "
+                                    "flows of a random-weight network on noise frames move neighbouring sample points ~0.6 px apart per pixel"}
+            if rank == 0:
+                log(f"{name:<18}{ms_sum / nl:>9.4f} ms  {by / nl / 1e6:>9.1f} MB  {gbs:>8.1f} GB/s  frac {gbs / HBM_PEAK_GBS:.3f} of 8 TB/s")
+
     samples = world * B * args.steps
     value = samples / elapsed
     res = {
-        "metric": "stabilised frame-pairs/sec @512x512",
+        "metric": f"stabilised frame-pairs/sec @{H}x{W}",
         "value": round(value, 2),
         "unit": "frame-pairs/s",
         "n_gpus": world,
@@ -296,6 +325,7 @@ def main():
                    "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL") if gather is not None else False,
                    "vgg16_trunk": bool(args.vgg16)},
         "roofline": roofline,
+        "roofline_hbm": roofline_hbm,
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -35,6 +35,9 @@ EXPORTS = {
                                 [C.c_float] * 3 + [C.c_void_p]),
     "vstab_resize_bilinear": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]),
     "vstab_warp_flow": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "vstab_flow_glue_warp": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float] * 3 + [C.c_void_p]),
+    "vstab_hbm_profile_enable": (C.c_int, [C.c_int]),
+    "vstab_hbm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "vstab_get_pixel_value": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
     "vstab_st_transform": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vstab_st_bilinear_interp": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

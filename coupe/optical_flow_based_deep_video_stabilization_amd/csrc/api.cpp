@@ -881,6 +881,34 @@ extern "C" int vstab_warp_flow(const float *img, const float *flow, float *out, 
     return VSTAB_OK;
 }
 
+extern "C" int vstab_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *warped, int oh,
+                                    int ow, int C, float pre, float sx, float sy, void *stream)
+{
+    if (!flow || !img || !warped) return fail(nullptr, VSTAB_E_STATE, "flow_glue_warp: NULL buffer");
+    if (B < 1 || h < 1 || w < 1 || oh < 1 || ow < 1) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: bad shape");
+    if (C != 3) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: C must be 3 (use flow_resize_scale + warp_flow otherwise)");
+    if ((long long)B * oh * ow >= (1ll << 31)) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: B*oh*ow must be < 2^31");
+    if (((uintptr_t)flow & 7) || (((uintptr_t)img | (uintptr_t)outflow | (uintptr_t)warped) & 15))
+        return fail(nullptr, VSTAB_E_ALIGN, "flow_glue_warp: flow 8-byte, img/outflow/warped 16-byte alignment");
+    HIP_TRY(nullptr, launch_flow_glue_warp(flow, B, h, w, img, outflow, warped, oh, ow, C, pre, sx, sy, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_hbm_profile_enable(int mode)
+{
+    if (mode < 0 || mode > 2) return fail(nullptr, VSTAB_E_SHAPE, "hbm_profile_enable: mode must be 0, 1 or 2");
+    hbm_profile_enable(mode);
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg_bytes_sum)
+{
+    if (!ms_sum || !launches || !alg_bytes_sum) return fail(nullptr, VSTAB_E_STATE, "hbm_profile_read: NULL argument");
+    if (slot < 0 || slot >= HBM_SLOTS) return fail(nullptr, VSTAB_E_SHAPE, "hbm_profile_read: slot out of range");
+    HIP_TRY(nullptr, hbm_profile_read(slot, ms_sum, launches, alg_bytes_sum));
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_get_pixel_value(const float *img, const int32_t *x, const int32_t *y, float *out, int B, int H,
                                      int W, int C, int Hi, int Wi, void *stream)
 {

@@ -3,11 +3,76 @@
 // Built with -ffp-contract=off so that the lerp / weight arithmetic is the same sequence
 // of fp32 roundings the reference's TF graph performs; dot products use explicit fmaf.
 #include "vstab_internal.h"
+#include <hip/hip_ext.h>
+#include <mutex>
+#include <vector>
 
 namespace vstab {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- optional per-launch timing of the HBM-side kernels (bench.py's roofline_hbm block): when switched on, a launch goes through
+// hipExtLaunchKernelGGL, which stamps the kernel's own start/stop into two events on the launch stream (the same mechanism as the
+// conv launches' profile slots); off (the default) it is a plain launch.  Process-wide, instrumentation only.
+struct HbmProfState {
+    std::mutex mu;
+    bool on = false;
+    struct Rec { hipEvent_t a, b; };
+    std::vector<Rec> recs[HBM_SLOTS];
+    double bytes[HBM_SLOTS] = {0};
+};
+static HbmProfState &hbm_prof() { static HbmProfState s; return s; }
+
+void hbm_profile_enable(int mode)      // 0 = off (records kept), 1 = clear the records and switch on, 2 = switch on again, records kept
+{
+    HbmProfState &P = hbm_prof();
+    std::lock_guard<std::mutex> g(P.mu);
+    const bool on = mode != 0;
+    if (mode == 1)
+        for (int i = 0; i < HBM_SLOTS; ++i) {
+            for (auto &r : P.recs[i]) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+            P.recs[i].clear(); P.bytes[i] = 0;
+        }
+    P.on = on;
+}
+
+hipError_t hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg_bytes_sum)
+{
+    HbmProfState &P = hbm_prof();
+    std::lock_guard<std::mutex> g(P.mu);
+    if (slot < 0 || slot >= HBM_SLOTS) return hipErrorInvalidValue;
+    double ms = 0;
+    for (auto &r : P.recs[slot]) {
+        float m = 0.f;
+        const hipError_t e = hipEventElapsedTime(&m, r.a, r.b);      // the stream must have been synchronised
+        if (e != hipSuccess) return e;
+        ms += m;
+    }
+    *ms_sum = ms; *launches = (int)P.recs[slot].size(); *alg_bytes_sum = P.bytes[slot];
+    return hipSuccess;
+}
+
+template <typename... KArgs, typename... Args>
+static hipError_t launch_timed(int slot, double alg_bytes, void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, Args... args)
+{
+    HbmProfState &P = hbm_prof();
+    if (P.on) {
+        HbmProfState::Rec r;
+        hipError_t e = hipEventCreate(&r.a);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&r.b);
+        if (e != hipSuccess) return e;
+        {
+            std::lock_guard<std::mutex> g(P.mu);
+            P.recs[slot].push_back(r); P.bytes[slot] += alg_bytes;
+        }
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, r.a, r.b, 0, static_cast<KArgs>(args)...);
+    } else {
+        kernel<<<grid, block, 0, stream>>>(static_cast<KArgs>(args)...);
+    }
+    return hipGetLastError();
+}
 
 // ---- legacy TF bilinear (ResizeBilinear, align_corners=False, no half-pixel centres):
 // f = i * (in/out) in fp32, lo = floor(f), hi = min(lo+1, in-1), t = f - lo
@@ -259,9 +324,8 @@ hipError_t launch_flow_resize_scale(const float *flow, int B, int h, int w, floa
     const long long total = (long long)B * oh * ow;
     // same size: TF returns the tensor unchanged; scale 1.0 gives lo = i, t = 0 -> identical values
     const float ry = (float)h / (float)oh, rx = (float)w / (float)ow;
-    flow_resize_scale_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(flow, B, h, w, out, oh, ow,
-                                                                                           pre, sx, sy, ry, rx);
-    return hipGetLastError();
+    return launch_timed(HBM_SLOT_GLUE, 8.0 * B * h * w + 8.0 * total, flow_resize_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                        stream, flow, B, h, w, out, oh, ow, pre, sx, sy, ry, rx);
 }
 
 // generic NHWC legacy-bilinear resize (main:806; one thread per output element)
@@ -330,14 +394,172 @@ __global__ __launch_bounds__(256) void warp_flow_kernel(const float *__restrict_
     for (int c = 0; c < Cc; ++c) o[c] = ((wa * Ia[c] + wb * Ib[c]) + wc * Ic[c]) + wd * Id[c];   // tf.add_n order
 }
 
+// ---------------------------------------------------------------------------------
+// W1 for 3-channel frames, shaped for the memory system (32 B/px algorithmic: 12 gathered + 8 flow + 12 written), optionally
+// with the flow glue G1 (main:497-498) fused in front so that the output-resolution flow is produced in registers, written
+// once (the evaluator returns it) and never re-read -- main:497-514 is one graph in the reference (40 B/px with the flow
+// written: 8 source flow + 8 output flow + 12 + 12).
+// What bounds it (profiles/README.md, "r02 warp study"; PMC TCP_TOTAL_CACHE_ACCESSES): the L1 looks up one 64-byte piece per
+// four lanes per cycle, and a gather of 12-byte pixels costs 1.75 lookups per four lanes even when they are neighbours -- the
+// L1 tag pipe saturates before HBM does.  So the kernel minimises lookups per pixel:
+//   * a workgroup owns a 16 x 32 tile of ONE sample's output pixels and every wave instruction works on a 4 x 16 patch, so the
+//     lines a gather instruction touches are a compact 2-D footprint ((4 + spread) rows x (16 + spread) pixels) whether or not
+//     the flow is smooth (a 1-D run of 64 pixels touches 64 x `spread` lines once neighbouring flows differ: 0.37 -> 0.55 of
+//     8 TB/s on the benchmark's flows, which move neighbouring pixels' sample points 0.6 px apart per pixel);
+//   * one 3-dword load per corner (never three scalar ones), both pixels of a thread's loads issued back to back;
+//   * results leave through LDS as 16-byte stores of whole 384-byte tile rows (W % 4 == 0; otherwise 12-byte stores);
+//   * workgroups are numbered through the XCD map: one XCD's L2 sees a contiguous band of tile rows;
+//   * no 64-bit divisions.
+// The arithmetic is the sequence of warp_flow_kernel / flow_resize_scale_kernel above, statement for statement: results are
+// bit-identical to the two-launch path (tests: test_warp_tiled_kernel_bit_exact_vs_fp32_oracle, test_fused_glue_warp_bit_identical).
+// Rejected after measurement (tools/warp_variants.inc): 1-D 1024-pixel tiles with LDS-staged stores, an LDS-staged source
+// window (bounding box of the tile's corners, coalesced fill, gathers from LDS) and its persistent, flow-prefetching form.
+// ---------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) rgb3 { float r, g, b; };
+struct GlueParams { int h, w; float pre, sx, sy, ry, rx; };      // source flow grid + the constants of main:497-498
+
+// a workgroup owns a TH x TW tile of ONE sample's output pixels; a wave instruction works on a WH x WW patch (WH * WW = 64)
+template <bool FUSED, bool WRITE_FLOW, int WH, int WW, int TW, int PPT, bool REMAP = true, bool NT = false, bool STAGE = false>
+__global__ __launch_bounds__(256) void warp3_tile_kernel(const float *__restrict__ img, const float *__restrict__ flow,
+                                                         float *__restrict__ out, float *__restrict__ outflow, int B,
+                                                         int H, int W, int tiles_x, int tiles_y, GlueParams G)
+{
+    static_assert(WH * WW == 64 && TW % WW == 0 && (4 * PPT) % (TW / WW) == 0, "patch / tile shapes");
+    constexpr int PPR = TW / WW;                    // patches per tile row
+    constexpr int TH = WH * (4 * PPT) / PPR;
+    __shared__ __attribute__((aligned(16))) float stage[STAGE ? TH * TW * 3 : 4];
+    unsigned bx = blockIdx.x, by, bz;
+    if (REMAP) xcd_remap_calc(gridDim.x, 1, 1, blockIdx.x, bx, by, bz);
+    const int tpi = tiles_x * tiles_y;
+    const int n = (int)bx / tpi, trem = (int)bx - n * tpi;
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long HW = (long long)H * W;
+
+    int yy[PPT], xx[PPT];
+    bool ok[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int q = j * 4 + wave;
+        yy[j] = ty0 + (q / PPR) * WH + lane / WW;
+        xx[j] = tx0 + (q % PPR) * WW + lane % WW;
+        ok[j] = yy[j] < H && xx[j] < W;
+        if (!ok[j]) { yy[j] = 0; xx[j] = 0; }
+    }
+    f32x2 f[PPT];
+    if (FUSED) {
+        f32x2 tl[PPT], tr[PPT], bl[PPT], br[PPT];
+        Lerp Y[PPT], X[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            Y[j] = legacy_coord(yy[j], G.ry, G.h); X[j] = legacy_coord(xx[j], G.rx, G.w);
+            const f32x2 *b = reinterpret_cast<const f32x2 *>(flow) + (long long)n * G.h * G.w;
+            tl[j] = b[Y[j].lo * G.w + X[j].lo]; tr[j] = b[Y[j].lo * G.w + X[j].hi];
+            bl[j] = b[Y[j].hi * G.w + X[j].lo]; br[j] = b[Y[j].hi * G.w + X[j].hi];
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            f[j].x = lerp2(tl[j].x * G.pre, tr[j].x * G.pre, bl[j].x * G.pre, br[j].x * G.pre, X[j].t, Y[j].t) * G.sx;
+            f[j].y = lerp2(tl[j].y * G.pre, tr[j].y * G.pre, bl[j].y * G.pre, br[j].y * G.pre, X[j].t, Y[j].t) * G.sy;
+            if (WRITE_FLOW && ok[j]) reinterpret_cast<f32x2 *>(outflow)[n * HW + (long long)yy[j] * W + xx[j]] = f[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const f32x2 *fp = reinterpret_cast<const f32x2 *>(flow) + n * HW + (long long)yy[j] * W + xx[j];
+            f[j] = NT ? __builtin_nontemporal_load(fp) : *fp;
+        }
+    }
+    float wa[PPT], wb[PPT], wc[PPT], wd[PPT];
+    rgb3 Ia[PPT], Ib[PPT], Ic[PPT], Id[PPT];
+    const rgb3 *b = reinterpret_cast<const rgb3 *>(img) + n * HW;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const float x = (float)xx[j] + f[j].x, y = (float)yy[j] + f[j].y;
+        int x0 = (int)fminf(fmaxf(x, -2.f), (float)W), y0 = (int)fminf(fmaxf(y, -2.f), (float)H);
+        int x1 = x0 + 1, y1 = y0 + 1;
+        x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
+        y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
+        const float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
+        wa[j] = (x1f - x) * (y1f - y); wb[j] = (x1f - x) * (y - y0f);
+        wc[j] = (x - x0f) * (y1f - y); wd[j] = (x - x0f) * (y - y0f);
+        Ia[j] = b[y0 * W + x0]; Ib[j] = b[y1 * W + x0]; Ic[j] = b[y0 * W + x1]; Id[j] = b[y1 * W + x1];
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        rgb3 r;
+        r.r = ((wa[j] * Ia[j].r + wb[j] * Ib[j].r) + wc[j] * Ic[j].r) + wd[j] * Id[j].r;      // tf.add_n order
+        r.g = ((wa[j] * Ia[j].g + wb[j] * Ib[j].g) + wc[j] * Ic[j].g) + wd[j] * Id[j].g;
+        r.b = ((wa[j] * Ia[j].b + wb[j] * Ib[j].b) + wc[j] * Ic[j].b) + wd[j] * Id[j].b;
+        if (STAGE) {
+            const int q = j * 4 + wave;
+            *reinterpret_cast<rgb3 *>(stage + (((q / PPR) * WH + lane / WW) * TW + (q % PPR) * WW + lane % WW) * 3) = r;
+        } else if (ok[j]) {
+            float *o = out + (n * HW + (long long)yy[j] * W + xx[j]) * 3;
+            if (NT) { __builtin_nontemporal_store(r.r, o); __builtin_nontemporal_store(r.g, o + 1); __builtin_nontemporal_store(r.b, o + 2); }
+            else *reinterpret_cast<rgb3 *>(o) = r;
+        }
+    }
+    if (STAGE) {       // W % 4 == 0 (host): a tile row is TW*12 bytes from a 16-byte aligned address; 16-byte stores, dwords at a ragged right edge
+        __syncthreads();
+        constexpr int R4 = TW * 3 / 4;
+        const int vw3 = min(TW, W - tx0) * 3;
+        for (int e = threadIdx.x; e < TH * R4; e += 256) {
+            const int row = e / R4, c4 = e - row * R4;
+            if (ty0 + row >= H || c4 * 4 >= vw3) continue;
+            float *o = out + (n * HW + (long long)(ty0 + row) * W + tx0) * 3 + c4 * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * TW * 3 + c4 * 4);
+            if (c4 * 4 + 4 <= vw3) { if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(o)); else *reinterpret_cast<f32x4 *>(o) = v; }
+            else for (int i = 0; c4 * 4 + i < vw3; ++i) o[i] = v[i];
+        }
+    }
+}
+
+constexpr int WT_WH = 4, WT_WW = 16, WT_TW = 32, WT_PPT = 2, WT_TH = WT_WH * (4 * WT_PPT) / (WT_TW / WT_WW);      // 16 x 32 tile
+
+static bool warp3_ok(const void *img, const void *out, const void *outflow, int B, int H, int W, int C)
+{
+    return C == 3 && (long long)B * H * W < (1ll << 31) && (((uintptr_t)img | (uintptr_t)out | (uintptr_t)outflow) & 15) == 0;
+}
+
+template <bool FUSED, bool WRITE_FLOW>
+static hipError_t launch_warp3(int slot, double alg_bytes, const float *img, const float *flow, float *out, float *outflow, int B, int H,
+                               int W, const GlueParams &G, hipStream_t stream)
+{
+    const int tx = (W + WT_TW - 1) / WT_TW, ty = (H + WT_TH - 1) / WT_TH;
+    const dim3 grid((unsigned)((long long)tx * ty * B)), block(256);
+    if ((W & 3) == 0)
+        return launch_timed(slot, alg_bytes, warp3_tile_kernel<FUSED, WRITE_FLOW, WT_WH, WT_WW, WT_TW, WT_PPT, true, false, true>, grid, block,
+                            stream, img, flow, out, outflow, B, H, W, tx, ty, G);
+    return launch_timed(slot, alg_bytes, warp3_tile_kernel<FUSED, WRITE_FLOW, WT_WH, WT_WW, WT_TW, WT_PPT, true, false, false>, grid, block,
+                        stream, img, flow, out, outflow, B, H, W, tx, ty, G);
+}
+
 hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W, int C, hipStream_t stream)
 {
     const long long total = (long long)B * H * W;
+    if (total == 0) return hipSuccess;
+    if (warp3_ok(img, out, nullptr, B, H, W, C) && (long long)((W + WT_TW - 1) / WT_TW) * ((H + WT_TH - 1) / WT_TH) * B < (1ll << 31))
+        return launch_warp3<false, false>(HBM_SLOT_WARP, 32.0 * total, img, flow, out, nullptr, B, H, W, GlueParams{}, stream);
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (C == 3) warp_flow_kernel<3><<<grid, block, 0, stream>>>(img, flow, out, B, H, W, C);
-    else if (C == 1) warp_flow_kernel<1><<<grid, block, 0, stream>>>(img, flow, out, B, H, W, C);
-    else warp_flow_kernel<0><<<grid, block, 0, stream>>>(img, flow, out, B, H, W, C);
-    return hipGetLastError();
+    const double bytes = (8.0 + 8.0 * C) * total;
+    if (C == 3) return launch_timed(HBM_SLOT_WARP, bytes, warp_flow_kernel<3>, grid, block, stream, img, flow, out, B, H, W, C);
+    if (C == 1) return launch_timed(HBM_SLOT_WARP, bytes, warp_flow_kernel<1>, grid, block, stream, img, flow, out, B, H, W, C);
+    return launch_timed(HBM_SLOT_WARP, bytes, warp_flow_kernel<0>, grid, block, stream, img, flow, out, B, H, W, C);
+}
+
+// main:497-514 as one launch: outflow = glue(flow [B,h,w,2]) at [B,oh,ow,2] (written if `outflow` is given), warped =
+// tf_warp(img [B,oh,ow,3], outflow).  C must be 3 (callers fall back to the two kernels otherwise).
+hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *out, int oh, int ow,
+                                 int C, float pre, float sx, float sy, hipStream_t stream)
+{
+    const long long total = (long long)B * oh * ow;
+    if (total == 0) return hipSuccess;
+    if (!warp3_ok(img, out, outflow, B, oh, ow, C)) return hipErrorInvalidValue;
+    const GlueParams G{h, w, pre, sx, sy, (float)h / (float)oh, (float)w / (float)ow};
+    const double src = 8.0 * B * h * w;                       // the source flow is read once from HBM (its 4 taps per pixel hit in cache)
+    if (outflow) return launch_warp3<true, true>(HBM_SLOT_GLUE_WARP, src + 32.0 * total, img, flow, out, outflow, B, oh, ow, G, stream);
+    return launch_warp3<true, false>(HBM_SLOT_GLUE_WARP, src + 24.0 * total, img, flow, out, nullptr, B, oh, ow, G, stream);
 }
 
 // tf.nn.max_pool(ksize 2, strides 2, SAME) (vgg16.py:51-53): out = ceil(n/2); the window's taps beyond

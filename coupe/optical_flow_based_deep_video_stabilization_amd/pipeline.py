@@ -3,7 +3,7 @@
 from __future__ import annotations
 
 from .model import flownetS_pyramid
-from .warp_flow import flow_to_output_res, resize_images, tf_warp
+from .warp_flow import flow_glue_warp, flow_to_output_res, resize_images, tf_warp
 
 
 def stabilise_originalsize(feats, frame, scope='flownetS', flow_filter=None):
@@ -13,6 +13,9 @@ def stabilise_originalsize(feats, frame, scope='flownetS', flow_filter=None):
     flows = flownetS_pyramid(feats, feats.shape[0], is_train=False, scope=scope)
     Hn, Wn = feats.shape[1], feats.shape[2]
     oh, ow = frame.shape[1], frame.shape[2]
+    if flow_filter is None and frame.shape[3] == 3:          # main:497-514 is one graph: glue + warp in ONE launch
+        outflow, warped = flow_glue_warp(flows['predict_flow2'], frame, Hn, Wn)
+        return flows, outflow, warped
     outflow = flow_to_output_res(flows['predict_flow2'], Hn, Wn, oh, ow)
     return flows, outflow, tf_warp(frame, outflow if flow_filter is None else flow_filter(outflow), oh, ow)
 

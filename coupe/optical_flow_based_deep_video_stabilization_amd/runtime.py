@@ -20,6 +20,25 @@ def stream_ptr() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+HBM_SLOTS = ("warp_flow", "flow_resize_scale", "flow_glue_warp")
+
+
+def hbm_profile(mode: int):
+    """Per-launch dispatch-timestamp events around the HBM-side kernels (tf_warp, flow glue, fused launch):
+    0 = off (records kept), 1 = clear + on, 2 = on again."""
+    _lib.check(_lib.lib().vstab_hbm_profile_enable(int(mode)))
+
+
+def hbm_profile_read():
+    """{slot name: (kernel ms summed, launches, algorithmic bytes summed)}; synchronise the stream first."""
+    out = {}
+    for i, name in enumerate(HBM_SLOTS):
+        ms, n, by = C.c_double(), C.c_int(), C.c_double()
+        _lib.check(_lib.lib().vstab_hbm_profile_read(i, C.byref(ms), C.byref(n), C.byref(by)))
+        out[name] = (ms.value, n.value, by.value)
+    return out
+
+
 class Context:
     """One vstab_ctx per (device, scope): packed weights + cached workspaces."""
 

@@ -73,3 +73,25 @@ def flow_to_output_res(predict_flow2, net_h, net_w, out_h, out_w):
         _lib.check(_lib.lib().vstab_flow_resize_scale(f.data_ptr(), B, h, w, out.data_ptr(), out_h, out_w,
                                                       pre, sx, sy, runtime.stream_ptr()))
     return out
+
+
+def flow_glue_warp(predict_flow2, frame, net_h, net_w, want_outflow=True):
+    """main:497-514 in one launch: (outflow, warped) = (flow_to_output_res(pf2, ...), tf_warp(frame, outflow, oh, ow)) for a
+    3-channel frame [B,oh,ow,3]; bit-identical to the two calls.  With want_outflow=False the output-resolution flow is never
+    written and None is returned in its place."""
+    f = _f32_cuda(predict_flow2, "predict_flow2")
+    img = _f32_cuda(frame, "frame")
+    B, h, w, two = f.shape
+    if two != 2 or img.dim() != 4 or img.shape[0] != B:
+        raise ValueError(f"flow_glue_warp: flow {tuple(f.shape)} / frame {tuple(img.shape)} do not match")
+    _, oh, ow, Cc = img.shape
+    pre = float(np.float32(net_h) / np.float32(h))
+    sx = float(np.float32(ow) / np.float32(net_w))
+    sy = float(np.float32(oh) / np.float32(net_h))
+    outflow = torch.empty((B, oh, ow, 2), dtype=torch.float32, device=f.device) if want_outflow else None
+    out = torch.empty_like(img)
+    with torch.cuda.device(f.device):
+        _lib.check(_lib.lib().vstab_flow_glue_warp(f.data_ptr(), B, h, w, img.data_ptr(),
+                                                   outflow.data_ptr() if want_outflow else None, out.data_ptr(), oh, ow, Cc,
+                                                   pre, sx, sy, runtime.stream_ptr()))
+    return outflow, out

@@ -133,6 +133,22 @@ VSTAB_API int vstab_resize_bilinear(const float *x, int B, int h, int w, int C, 
 VSTAB_API int vstab_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W, int C,
                     void *stream);
 
+/* ---- main:497-514 as ONE launch (evaluate_originalSize builds them as one graph): outflow = the glue of
+ * vstab_flow_resize_scale applied to flow [B,h,w,2], at [B,oh,ow,2]; warped = tf_warp(img [B,oh,ow,3], outflow).
+ * `outflow` may be NULL when the caller does not need the output-resolution flow (it is then never written); when
+ * given it is written once and not re-read.  Bit-identical to vstab_flow_resize_scale followed by vstab_warp_flow.
+ * C must be 3; img/outflow/warped 16-byte aligned; B*oh*ow < 2^31. */
+VSTAB_API int vstab_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *warped,
+                         int oh, int ow, int C, float pre, float sx, float sy, void *stream);
+
+/* ---- instrumentation of the HBM-side kernels (tf_warp, the flow glue, the fused launch): with profiling on every such launch
+ * is bracketed by dispatch-timestamp events on its own stream.  Process-wide; switching it on clears earlier records.
+ * Slots: 0 = vstab_warp_flow, 1 = vstab_flow_resize_scale, 2 = vstab_flow_glue_warp.  Read after synchronising the stream(s):
+ * summed kernel milliseconds, number of launches, summed ALGORITHMIC bytes (warp 32 B/px; glue 8 B per source +
+ * 8 B per output pixel; fused 8 B per source pixel + 32 (flow written) or 24 B per output pixel). */
+VSTAB_API int vstab_hbm_profile_enable(int mode);   /* 0 = off (records kept), 1 = clear + on, 2 = on again (records kept) */
+VSTAB_API int vstab_hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg_bytes_sum);
+
 /* ---- get_pixel_value(img, x, y) main:44-68.  x, y int32 [B,H,W] -> out[b,h,w,:] =
  * img[b, y, x, :].  Indices are clamped into the image instead of faulting. */
 VSTAB_API int vstab_get_pixel_value(const float *img, const int32_t *x, const int32_t *y, float *out, int B,

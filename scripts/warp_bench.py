@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""HBM-side kernels of the path in isolation (W1 tf_warp, G1 flow glue, the fused launch) at BASELINE shapes:
+time per launch from torch events over back-to-back launches, achieved algorithmic GB/s and fraction of 8 TB/s.
+Algorithmic bytes: warp 32 B/px (12 img + 8 flow + 12 out); glue 16 B/px (8 src flow + 8 out);
+fused glue+warp with the output flow written 40 B/px (8 src + 8 outflow + 12 + 12), without 32 B/px."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import coupe.optical_flow_based_deep_video_stabilization_amd as vs   # noqa: E402
+from coupe.optical_flow_based_deep_video_stabilization_amd import runtime   # noqa: E402
+
+PEAK = 8000.0
+
+
+def timeit(fn, iters):
+    """Average KERNEL time (us) from the library's dispatch-timestamp events (not host time: at 512x512 a Python call is
+    slower than the kernel)."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    runtime.hbm_profile(1)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    runtime.hbm_profile(0)
+    ms = sum(v[0] for v in runtime.hbm_profile_read().values())
+    return ms / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--flows", default="smooth,random")
+    ap.add_argument("--shapes", default="8x512x512,16x1080x1920,32x720x1280,1x384x512")
+    args = ap.parse_args()
+    rows = []
+    for sh in args.shapes.split(","):
+        B, H, W = (int(v) for v in sh.split("x"))
+        g = torch.Generator().manual_seed(1)
+        img = torch.rand(B, H, W, 3, generator=g).cuda()
+        px = B * H * W
+        for kind in args.flows.split(","):
+            if kind == "random":        # every pixel's flow independent: neighbouring pixels gather from unrelated cache lines
+                pf2 = (torch.randn(B, H - 2, W - 2, 2, generator=g) * 3).cuda()
+            else:                       # "smooth": a coarse random field upsampled 16x, like a real (or a network's) flow
+                lo = torch.randn(B, 2, max(H // 16, 2), max(W // 16, 2), generator=g) * 6
+                pf2 = torch.nn.functional.interpolate(lo, size=(H - 2, W - 2), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous().cuda()
+            flow = vs.flow_to_output_res(pf2, H, W, H, W)
+            r = {"shape": sh, "pixels": px, "flow": kind}
+            for name, fn, bpp in (
+                    ("warp", lambda: vs.tf_warp(img, flow, H, W), 32),
+                    ("glue", lambda: vs.flow_to_output_res(pf2, H, W, H, W), 16),
+                    ("glue+warp fused (flow written)", lambda: vs.flow_glue_warp(pf2, img, H, W), 40),
+                    ("glue+warp fused (no flow)", lambda: vs.flow_glue_warp(pf2, img, H, W, want_outflow=False), 32)):
+                us = timeit(fn, args.iters)
+                gbs = px * bpp / us * 1e-3
+                r[name] = {"us": round(us, 2), "alg_bytes_per_px": bpp, "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK, 4)}
+                print(f"{sh:>14} {kind:<7} {name:<32} {us:9.2f} us  {gbs:8.1f} GB/s  {gbs / PEAK:.3f}", file=sys.stderr, flush=True)
+            rows.append(r)
+    print(json.dumps(rows))
+
+
+if __name__ == "__main__":
+    main()

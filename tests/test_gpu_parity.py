@@ -57,6 +57,39 @@ def test_warp_nonfinite_flow_does_not_fault():
     assert out.shape == (1, 8, 8, 3)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 37, 53), (2, 64, 96), (3, 31, 1031), (1, 270, 480), (5, 8, 9), (1, 1, 1)])
+def test_warp_tiled_kernel_bit_exact_vs_fp32_oracle(B, H, W):
+    # the 3-channel warp works on 1024-pixel tiles of the flat pixel index (ragged last tile, rows shorter and longer than a
+    # wave pass, tiles that span samples): same fp32 statement sequence as the oracle -> identical bits
+    g = torch.Generator().manual_seed(B * 7919 + H * 31 + W)
+    img = torch.rand(B, H, W, 3, generator=g)
+    flow = torch.randn(B, H, W, 2, generator=g) * 6
+    flow[0, 0, 0] = torch.tensor([-0.5, -0.25])          # extrapolating corner (A.6)
+    flow[-1, -1, -1] = torch.tensor([3.0, 3.0])          # beyond the far edge -> 0
+    out = vs.tf_warp(img.cuda(), flow.cuda(), H, W)
+    ref = vo.tf_warp(img, flow, H, W, torch.float32)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("B,hn,wn,oh,ow", [(2, 64, 64, 64, 64), (1, 70, 90, 96, 120), (3, 64, 96, 37, 53), (1, 48, 64, 135, 240),
+                                           (2, 384, 512, 384, 512)])
+def test_fused_glue_warp_bit_identical(B, hn, wn, oh, ow):
+    # main:497-514 in ONE launch must give the bits of vstab_flow_resize_scale followed by vstab_warp_flow (and the oracle's
+    # fp32 restatement of the two steps), with and without the output-resolution flow being written
+    g = torch.Generator().manual_seed(hn * 131 + ow)
+    pf2 = (torch.randn(B, hn - 2, wn - 2, 2, generator=g) * 4).cuda()
+    frame = torch.rand(B, oh, ow, 3, generator=g).cuda()
+    of_ref = vs.flow_to_output_res(pf2, hn, wn, oh, ow)
+    wp_ref = vs.tf_warp(frame, of_ref, oh, ow)
+    of, wp = vs.flow_glue_warp(pf2, frame, hn, wn)
+    assert torch.equal(of, of_ref) and torch.equal(wp, wp_ref)
+    none, wp2 = vs.flow_glue_warp(pf2, frame, hn, wn, want_outflow=False)
+    assert none is None and torch.equal(wp2, wp_ref)
+    cpu_of = vo.flow_to_output_res(pf2.cpu(), hn, wn, oh, ow).float()
+    assert maxabs(of, cpu_of) <= 2e-5
+    assert torch.equal(wp.cpu(), vo.tf_warp(frame.cpu(), of.cpu(), oh, ow, torch.float32))
+
+
 def test_get_pixel_value():
     img = torch.rand(2, 9, 11, 3)
     x = torch.randint(0, 11, (2, 4, 5), dtype=torch.int32)
