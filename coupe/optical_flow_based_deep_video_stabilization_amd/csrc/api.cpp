@@ -886,7 +886,7 @@ extern "C" int vstab_flow_glue_warp(const float *flow, int B, int h, int w, cons
 {
     if (!flow || !img || !warped) return fail(nullptr, VSTAB_E_STATE, "flow_glue_warp: NULL buffer");
     if (B < 1 || h < 1 || w < 1 || oh < 1 || ow < 1) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: bad shape");
-    if (C != 3) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: C must be 3 (use flow_resize_scale + warp_flow otherwise)");
+    if (C != 3 || w < 2) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: C must be 3 and w >= 2 (use flow_resize_scale + warp_flow otherwise)");
     if ((long long)B * oh * ow >= (1ll << 31)) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: B*oh*ow must be < 2^31");
     if (((uintptr_t)flow & 7) || (((uintptr_t)img | (uintptr_t)outflow | (uintptr_t)warped) & 15))
         return fail(nullptr, VSTAB_E_ALIGN, "flow_glue_warp: flow 8-byte, img/outflow/warped 16-byte alignment");

@@ -13,7 +13,7 @@ def stabilise_originalsize(feats, frame, scope='flownetS', flow_filter=None):
     flows = flownetS_pyramid(feats, feats.shape[0], is_train=False, scope=scope)
     Hn, Wn = feats.shape[1], feats.shape[2]
     oh, ow = frame.shape[1], frame.shape[2]
-    if flow_filter is None and frame.shape[3] == 3:          # main:497-514 is one graph: glue + warp in ONE launch
+    if flow_filter is None and frame.shape[3] == 3 and Wn >= 4:          # main:497-514 is one graph: glue + warp in ONE launch
         outflow, warped = flow_glue_warp(flows['predict_flow2'], frame, Hn, Wn)
         return flows, outflow, warped
     outflow = flow_to_output_res(flows['predict_flow2'], Hn, Wn, oh, ow)
