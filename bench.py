@@ -110,6 +110,7 @@ def main():
                     help="record the per-launch HIP events on every n-th step of the timed region (they cost ~2 %% of a step)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph (torch.cuda.CUDAGraph) and replay it; single GPU, no kernel events")
+    ap.add_argument("--roctx", action="store_true", help="run every layer inside a named roctx range (rocprofv3 --marker-trace)")
     ap.add_argument("--vgg16", action="store_true",
                     help="BASELINE config 5: also run the VGG16 trunk (preprocess + 13 conv + 5 pool) on the warped frames")
     args = ap.parse_args()
@@ -145,6 +146,8 @@ def main():
     feats = torch.rand(B, H, W, Cin, generator=g).cuda()
     frame = torch.rand(B, H, W, 3, generator=g).cuda()
     ctx = runtime.get_context()
+    if args.roctx:
+        runtime.trace_ranges(True)
 
     gather = None
     if (world > 1 or force_dist) and not args.no_gather:

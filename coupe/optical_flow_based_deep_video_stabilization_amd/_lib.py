@@ -36,6 +36,7 @@ EXPORTS = {
     "vstab_resize_bilinear": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]),
     "vstab_warp_flow": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "vstab_flow_glue_warp": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float] * 3 + [C.c_void_p]),
+    "vstab_trace_ranges": (C.c_int, [C.c_int]),
     "vstab_hbm_profile_enable": (C.c_int, [C.c_int]),
     "vstab_hbm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "vstab_get_pixel_value": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
@@ -125,7 +126,11 @@ def lib():
     global _lib
     if _lib is None:
         path = _build.LIB
-        if os.environ.get("VSTAB_NO_BUILD") != "1":
+        if os.environ.get("VSTAB_LIB"):                 # an explicitly chosen build of the same sources (the sanitizer build of the host side)
+            path = os.environ["VSTAB_LIB"]
+            if not os.path.exists(path):
+                raise RuntimeError(f"VSTAB_LIB={path} does not exist")
+        elif os.environ.get("VSTAB_NO_BUILD") != "1":
             path = _build.build()
         elif not os.path.exists(path):
             raise RuntimeError(f"{path} is missing and VSTAB_NO_BUILD=1")

@@ -81,5 +81,51 @@ def _build_locked(verbose: bool) -> str:
     return LIB
 
 
+# ---- sanitizer build of the HOST side (sanitizers run on the CPU build only): pack.cpp and the planning /
+# validation code of the three API files compiled with AddressSanitizer + UndefinedBehaviorSanitizer, linked with the regular
+# objects of the kernels.  tests/test_host_sanitize.py drives it with the vstab_host_* CPU tests.
+ASAN_LIB = os.path.join(HERE, "libvstab_hip_asan.so")
+ASAN_FLAGS = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-O1"]
+
+
+def asan_runtime() -> str:
+    out = subprocess.check_output([hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    if not os.path.isabs(out) or not os.path.exists(out):
+        import glob
+        cands = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+        if not cands:
+            raise RuntimeError("AddressSanitizer runtime of the ROCm clang not found")
+        out = sorted(cands)[-1]
+    return out
+
+
+def build_sanitized(verbose: bool = False) -> str:
+    build()                                             # the kernels' regular objects
+    stamp = ASAN_LIB + ".srchash"
+    want = source_hash() + "+asan"
+    if os.path.exists(ASAN_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return ASAN_LIB
+    obj_dir = os.path.join(HERE, "build")
+    objs = []
+    for s in SOURCES:
+        if s.endswith(".cpp"):
+            o = os.path.join(obj_dir, s + ".asan.o")
+            cmd = [hipcc()] + [f for f in FLAGS if f != "-O3"] + ASAN_FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        else:
+            o = os.path.join(obj_dir, s + ".o")
+            if not os.path.exists(o):                   # build() was satisfied by its stamp but the objects are gone
+                subprocess.check_call([hipcc()] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o])
+        objs.append(o)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan"]
+                          + objs + ["-o", ASAN_LIB + ".tmp"])
+    os.replace(ASAN_LIB + ".tmp", ASAN_LIB)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

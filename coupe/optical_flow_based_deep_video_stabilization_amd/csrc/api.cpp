@@ -21,6 +21,47 @@ int fail(vstab_ctx *ctx, int code, const char *fmt, ...)
     if (ctx) ctx->err = buf;
     return code;
 }
+
+// ------------------------------------------------------------------------- roctx ranges
+#include <dlfcn.h>
+namespace {
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)();
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop = nullptr;
+bool g_trace_on = false;
+}
+
+bool trace_ranges_enable(bool on)
+{
+    if (on && !g_roctx_push) {
+        for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            g_roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+            g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+            if (g_roctx_push && g_roctx_pop) break;
+            g_roctx_push = nullptr; g_roctx_pop = nullptr;
+        }
+    }
+    g_trace_on = on && g_roctx_push != nullptr;
+    return !on || g_trace_on;
+}
+
+TraceRange::TraceRange(const char *name) : active(g_trace_on)
+{
+    if (active) g_roctx_push(name);
+}
+TraceRange::~TraceRange()
+{
+    if (active) g_roctx_pop();
+}
+
+extern "C" int vstab_trace_ranges(int on)
+{
+    if (!trace_ranges_enable(on != 0)) return fail(nullptr, VSTAB_E_STATE, "trace_ranges: no roctx library (librocprofiler-sdk-roctx.so / libroctx64.so) could be loaded");
+    return VSTAB_OK;
+}
 // ------------------------------------------------------------------------- net spec
 namespace {
 
@@ -202,8 +243,11 @@ void fill_wino_gemm(ConvParams &p, int B, int H, int W, int cin, int cout)
 // GEMM issues a few GFLOP (measured: B=8 512x512 every encoder stage gains, 20..96 us; B=1 384x512 (1.6 GFLOP per stage) loses 2..5 %)
 bool wino_applies(int B, int H, int W, int cin, int cout)
 {
-    static const bool wino_on = getenv("VSTAB_NO_WINOGRAD") == nullptr;
-    if (!wino_on || (cin & 31) || (cout & 127)) return false;                  // whole K tiles, 128x64 output tiles
+#ifdef VSTAB_HARNESS
+    static const bool wino_on = getenv("VSTAB_NO_WINOGRAD") == nullptr;       // A/B switch of the tuning harness builds
+    if (!wino_on) return false;
+#endif
+    if ((cin & 31) || (cout & 127)) return false;                  // whole K tiles, 128x64 output tiles
     const long long TH = (H + 1) / 2, TW = (W + 1) / 2;
     if ((long long)B * 16 * TH * TW * std::max(cin, cout) * 4 >= 0x80000000LL) return false;
     return 32.0 * B * TH * TW * cin * cout >= 3.0e9;
@@ -713,8 +757,13 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
 #define EV_A(slot) (ev ? ev[2 * (slot)] : nullptr)
 #define EV_B(slot) (ev ? ev[2 * (slot) + 1] : nullptr)
 
+    static const char *const ENC_RANGE[10] = {"conv1", "conv2", "conv3", "conv3_1", "conv4", "conv4_1", "conv5", "conv5_1", "conv6", "conv6_1"};
+    static const char *const DEC_RANGE[4] = {"deconv5", "deconv4", "deconv3", "deconv2"};
+    static const char *const HEAD_RANGE[4] = {"predict_flow6+upsample6_5", "predict_flow5+upsample5_4", "predict_flow4+upsample4_3", "predict_flow3+upsample3_2"};
+    TraceRange whole_range("flownetS_pyramid");
     // encoder (model.py:807-844)
     for (int i = 0; i < 10; ++i) {
+        TraceRange layer_range(ENC_RANGE[i]);
         ConvParams p = pl.cp[i];
         if (i == 0) {           // first layer: row-window kernel when its alignment conditions hold
             RowWinParams r{};
@@ -762,6 +811,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
     // One head per level: tap-table GEMM (split-K slabs left uncombined), then ONE launch that sums the slabs, gathers
     // predict_flowN, folds the upsampled coarser flow in and writes upsample_flowN into the next concat's flow channels.
     auto predict_head = [&](int l, const float *prev, int ph_, int pw_, float *out) -> int {     // l: 0 = predict6 .. 3 = predict3
+        TraceRange head_range(HEAD_RANGE[l]);
         ConvParams p = pl.cp[15 + l];
         p.in = buf(tab_src[l]); p.out = buf(tab_dst[l]);
         p.wpk = dw + ctx->pred_w[l]; p.bias = dw + ctx->tab_b; p.partial = buf(B_PARTIAL);
@@ -775,6 +825,8 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
     { const int rc = predict_head(0, nullptr, 0, 0, pf6); if (rc != VSTAB_OK) return rc; }
     for (int l = 0; l < 4; ++l) {
         ConvParams p = pl.cp[10 + l];
+        {
+        TraceRange layer_range(DEC_RANGE[l]);
         const int ib = l == 0 ? B_CONV6_1 : cat_buf[l - 1];
         p.in = buf(ib);
         p.out = buf(cat_buf[l]);
@@ -783,11 +835,13 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         p.partial = buf(B_PARTIAL);
         HIP_TRY(ctx, launch_conv(p, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l)));
         ctx->prof_kernel[10 + l] = conv_kernel_name(pl.tile[10 + l], true);
+        }
         const int ph = pl.eh[lvl_enc[l]], pw = pl.ew[lvl_enc[l]];          // coarser level
         if (l < 3) { const int rc = predict_head(l + 1, pfs[l], ph, pw, pfs[l + 1]); if (rc != VSTAB_OK) return rc; }
     }
     // full-resolution head (model.py:882-887)
     {
+        TraceRange layer_range("predict_flow2");
         ConvParams p = pl.cp[14];
         p.in = buf(B_CONCAT2); p.out = buf(B_T);
         p.wpk = dw + ctx->tab_w; p.bias = dw + ctx->tab_b; p.partial = nullptr;
@@ -877,6 +931,7 @@ extern "C" int vstab_warp_flow(const float *img, const float *flow, float *out, 
     if (!img || !flow || !out) return fail(nullptr, VSTAB_E_STATE, "warp_flow: NULL buffer");
     if (B < 1 || H < 1 || W < 1 || C < 1) return fail(nullptr, VSTAB_E_SHAPE, "warp_flow: bad shape");
     if ((uintptr_t)flow & 7) return fail(nullptr, VSTAB_E_ALIGN, "warp_flow: flow must be 8-byte aligned");
+    TraceRange range("tf_warp");
     HIP_TRY(nullptr, launch_warp_flow(img, flow, out, B, H, W, C, (hipStream_t)stream));
     return VSTAB_OK;
 }
@@ -890,6 +945,7 @@ extern "C" int vstab_flow_glue_warp(const float *flow, int B, int h, int w, cons
     if ((long long)B * oh * ow >= (1ll << 31)) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: B*oh*ow must be < 2^31");
     if (((uintptr_t)flow & 7) || (((uintptr_t)img | (uintptr_t)outflow | (uintptr_t)warped) & 15))
         return fail(nullptr, VSTAB_E_ALIGN, "flow_glue_warp: flow 8-byte, img/outflow/warped 16-byte alignment");
+    TraceRange range("flow_glue+tf_warp");
     HIP_TRY(nullptr, launch_flow_glue_warp(flow, B, h, w, img, outflow, warped, oh, ow, C, pre, sx, sy, (hipStream_t)stream));
     return VSTAB_OK;
 }
@@ -1127,8 +1183,7 @@ extern "C" int vstab_vgg16_forward(vstab_ctx *ctx, const float *input, int B, in
             if (!fill_plain_conv(p, tile, vec, bc, h, w, VGG[l].cin, VGG[l].cin, 3, 1, 1, VGG[l].cout, VGG[l].cout, 0, 2))
                 return fail(ctx, VSTAB_E_SHAPE, "vgg16_forward: layer %s does not fit", VGG[l].name);
             float *dst = outs[o] + (size_t)b0 * v.h[o] * v.w[o] * v.c[o];
-            static const bool rgb_kernel = getenv("VSTAB_NO_RGB_CONV") == nullptr;           // A/B switch for tuning runs
-            if (l == 0 && rgb_kernel) {
+            if (l == 0) {
                 HIP_TRY(ctx, launch_conv3x3_rgb(cur, bc, h, w, ctx->vgg_weights + ctx->vgg_raw0, ctx->vgg_weights + ctx->vgg_b[0], VGG[0].cout, 1, dst, stream));
             } else if (v.wino[l] && wino_applies(bc, h, w, VGG[l].cin, VGG[l].cout)) {      // (a short last chunk may fall below the break-even)
                 ConvParams q;

@@ -54,6 +54,18 @@ int fail(vstab_ctx *ctx, int code, const char *fmt, ...);
 
 void vstab_nldf_free(void *nldf);     // nldf_api.cpp
 
+// ---- roctx ranges (rocprofv3 --marker-trace reads as the network).  Off by default; vstab_trace_ranges(1)
+// resolves roctxRangePushA / roctxRangePop from librocprofiler-sdk-roctx.so (or libroctx64.so) with dlopen -- no link-time
+// dependency -- and every layer of the forward schedules then runs inside a named range.
+bool trace_ranges_enable(bool on);      // false: no roctx library could be loaded
+struct TraceRange {
+    explicit TraceRange(const char *name);
+    ~TraceRange();
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+    bool active;
+};
+
 // ---- helpers defined in api.cpp
 void choose_split(vstab::ConvParams &p, int BN, int BM = 128);
 vstab::ConvTile choose_tile_split(vstab::ConvParams &p, vstab::ConvTile tile, bool vec4);

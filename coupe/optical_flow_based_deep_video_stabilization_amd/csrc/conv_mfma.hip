@@ -478,8 +478,8 @@ template <int BM, int BN>
 static size_t conv_lds_bytes()
 {
     size_t n = (size_t)(2 * BM * 32 + 2 * BN * 32) * 4 + (size_t)BM * 20;
-#ifdef VSTAB_ABL
-    if (const char *e = getenv("VSTAB_LDS_PAD")) n += (size_t)atoi(e);     // occupancy experiments
+#ifdef VSTAB_HARNESS
+    if (const char *e = getenv("VSTAB_LDS_PAD")) n += (size_t)atoi(e);     // occupancy experiments (tools/conv_bench only)
 #endif
     return n;
 }
@@ -491,10 +491,12 @@ hipError_t conv_set_attributes()
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)conv_lds_bytes<BM, BN>());                                            \
     if (e != hipSuccess) return e;
+#ifdef VSTAB_HARNESS      // register-staged forms of the 16-byte-gather kernels: A/B material of tools/conv_bench, not in the product library
     VSTAB_SET((conv_mfma_kernel<128, 128, 2, 2, true>), 128, 128)
     VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, true>), 128, 64)
-    VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, false>), 128, 64)
     VSTAB_SET((conv_mfma_kernel<128, 32, 4, 1, true>), 128, 32)
+#endif
+    VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, false>), 128, 64)
     VSTAB_SET((conv_mfma_kernel<128, 128, 2, 2, true, true>), 128, 128)
     VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, true, true>), 128, 64)
     VSTAB_SET((conv_mfma_kernel<128, 32, 4, 1, true, true>), 128, 32)
@@ -505,8 +507,12 @@ hipError_t conv_set_attributes()
 
 static bool lds_dma_enabled()
 {
-    static const bool on = getenv("VSTAB_NO_LDS_DMA") == nullptr;     // A/B switch for tuning runs
+#ifdef VSTAB_HARNESS
+    static const bool on = getenv("VSTAB_NO_LDS_DMA") == nullptr;     // A/B switch of tools/conv_bench
     return on;
+#else
+    return true;          // the product library has one operand-staging path per tile: LDS-DMA
+#endif
 }
 
 bool conv_uses_lds_dma(ConvTile tile, bool vec4)
@@ -517,9 +523,13 @@ bool conv_uses_lds_dma(ConvTile tile, bool vec4)
 hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
                        bool combine)
 {
-    static const int no_remap = getenv("VSTAB_NO_XCD_REMAP") != nullptr;      // A/B switch for tuning runs
     ConvParams p = p_in;
+#ifdef VSTAB_HARNESS
+    static const int no_remap = getenv("VSTAB_NO_XCD_REMAP") != nullptr;      // A/B switch of tools/conv_bench
     p.no_remap = no_remap;
+#else
+    p.no_remap = 0;
+#endif
     const int BM = tile == TILE_64x128 ? 64 : 128;
     const int BN = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : (tile == TILE_128x64 ? 64 : 32);
     if (p.in_bytes >= 0x80000000u || p.w_bytes >= 0x80000000u) return hipErrorInvalidValue;
@@ -547,14 +557,16 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
         VSTAB_LAUNCH((conv_mfma_kernel<128, 32, 4, 1, true, true>), (conv_lds_bytes<128, 32>()));
     else if (tile == TILE_64x128 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<64, 128, 1, 4, true, true>), (conv_lds_bytes<64, 128>()));
+#ifdef VSTAB_HARNESS
     else if (tile == TILE_128x128 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 128, 2, 2, true>), (conv_lds_bytes<128, 128>()));
     else if (tile == TILE_128x64 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 64, 2, 2, true>), (conv_lds_bytes<128, 64>()));
-    else if (tile == TILE_128x64 && !vec4)
-        VSTAB_LAUNCH((conv_mfma_kernel<128, 64, 2, 2, false>), (conv_lds_bytes<128, 64>()));
     else if (tile == TILE_128x32 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 32, 4, 1, true>), (conv_lds_bytes<128, 32>()));
+#endif
+    else if (tile == TILE_128x64 && !vec4)       // dword gathers (27-channel rows that are not 16-byte friendly): tests/test_gpu_parity.py, C_in = 27 at odd widths
+        VSTAB_LAUNCH((conv_mfma_kernel<128, 64, 2, 2, false>), (conv_lds_bytes<128, 64>()));
     else
         return hipErrorInvalidValue;
 #undef VSTAB_LAUNCH

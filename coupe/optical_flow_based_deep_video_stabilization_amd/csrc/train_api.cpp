@@ -215,7 +215,11 @@ bool dgrad_plan(int B, int Ho, int Wo, int cs_g, int cout, int k, int stride, in
                 ++d.nsub;
             }
         if (d.nsub == 0) return false;
-        static const bool sublaunch = getenv("VSTAB_DGRAD_SUBLAUNCH") != nullptr;       // A/B switch: always one launch per phase
+#ifdef VSTAB_HARNESS
+        static const bool sublaunch = getenv("VSTAB_DGRAD_SUBLAUNCH") != nullptr;       // A/B switch of the tuning harness: always one launch per phase
+#else
+        constexpr bool sublaunch = false;
+#endif
         long long tiles_all = 0;
         for (int s = 0; s < d.nsub; ++s) tiles_all += (long long)((d.sp[s].ph[0].M + 127) / 128) * (npad / BN);
         if (!sublaunch && tiles_all <= 256) {

@@ -20,6 +20,11 @@ def stream_ptr() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def trace_ranges(on: bool):
+    """roctx ranges per layer (rocprofv3 --marker-trace); raises if no roctx library is installed."""
+    _lib.check(_lib.lib().vstab_trace_ranges(int(bool(on))))
+
+
 HBM_SLOTS = ("warp_flow", "flow_resize_scale", "flow_glue_warp")
 
 

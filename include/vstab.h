@@ -141,6 +141,12 @@ VSTAB_API int vstab_warp_flow(const float *img, const float *flow, float *out, i
 VSTAB_API int vstab_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *warped,
                          int oh, int ow, int C, float pre, float sx, float sy, void *stream);
 
+/* ---- roctx ranges: with on = 1 every layer of vstab_flownets_forward (conv1 .. conv6_1, predict_flowN+upsample, deconvN,
+ * predict_flow2) and the glue/warp launches run inside a named roctx range, so a `rocprofv3 --marker-trace --kernel-trace`
+ * timeline reads as the network (model.py:807-887).  The roctx library is loaded with dlopen on first use; VSTAB_E_STATE if
+ * none is installed.  Process-wide, off by default. */
+VSTAB_API int vstab_trace_ranges(int on);
+
 /* ---- instrumentation of the HBM-side kernels (tf_warp, the flow glue, the fused launch): with profiling on every such launch
  * is bracketed by dispatch-timestamp events on its own stream.  Process-wide; switching it on clears earlier records.
  * Slots: 0 = vstab_warp_flow, 1 = vstab_flow_resize_scale, 2 = vstab_flow_glue_warp.  Read after synchronising the stream(s):

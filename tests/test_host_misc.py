@@ -80,3 +80,18 @@ def test_xcd_remap_is_a_bijection_and_bands_the_tiles(grid):
     ranges.sort()
     assert ranges[0][0] == 0 and ranges[-1][1] == T and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
     assert L.vstab_host_xcd_remap(4, 4, 4, 64, xyz) != 0                # out of range
+
+
+def test_instrumentation_entry_points_without_gpu():
+    """roctx ranges resolve their library lazily; the HBM-side profile can be switched and read with nothing recorded."""
+    import ctypes as C
+    from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
+    L = _lib.lib()
+    assert L.vstab_trace_ranges(1) in (0, -6)          # VSTAB_OK, or VSTAB_E_STATE when no roctx library is installed
+    assert L.vstab_trace_ranges(0) == 0
+    assert L.vstab_hbm_profile_enable(1) == 0 and L.vstab_hbm_profile_enable(0) == 0
+    ms, n, by = C.c_double(-1), C.c_int(-1), C.c_double(-1)
+    assert L.vstab_hbm_profile_read(2, C.byref(ms), C.byref(n), C.byref(by)) == 0
+    assert (ms.value, n.value, by.value) == (0.0, 0, 0.0)
+    assert L.vstab_hbm_profile_read(7, C.byref(ms), C.byref(n), C.byref(by)) < 0
+    assert L.vstab_hbm_profile_enable(5) < 0
