@@ -28,7 +28,7 @@ def test_cfg4_batch16_1080p_net_warp_vgg_one_pass():
     runtime.reset()
     vs.assign_weights(w)
     L = _lib.lib()
-    assert L.vstab_workspace_bytes(16, H, W, cin) == L.vstab_workspace_bytes(8, H, W, cin)      # two chunks of 8
+    assert L.vstab_workspace_bytes(16, H, W, cin) < 2 * L.vstab_workspace_bytes(8, H, W, cin)   # the batch runs as two chunks (2 GiB tensor limit)
     rng = np.random.default_rng(4)
     two = rng.random((2, H, W, cin), dtype=np.float32)
     two_fr = rng.random((2, H, W, 3), dtype=np.float32)
@@ -106,15 +106,15 @@ def test_cfg3_sharded_clip_gather_world1_nccl(nccl_world1):
     torch.cuda.synchronize()
     assert full.dtype == torch.uint8 and tuple(full.shape) == (F_, H, W, 3)
     assert torch.equal(full, whole)
-    # what two ranks would each compute (their shard_range blocks, micro-batched), reassembled in rank order, is the same
-    # sequence up to the uint8 truncation of sums that differ by fp32 association (micro-batch composition changes split-K plans)
+    # what two ranks would each compute -- their shard_range blocks of the first 8 frames, i.e. one micro-batch of 4 each, the same
+    # batch composition as the unsharded run -- reassembled in rank order is bit for bit the same sequence (a different composition
+    # changes split-K plans, hence fp32 association, hence -- through tf_warp's truncating corners -- whole pixels: not compared)
     parts = []
     for r in range(2):
-        a, b = vdist.shard_range(F_, r, 2)
+        a, b = vdist.shard_range(8, r, 2)
+        assert b - a == MB
         parts.append(_stabilise_u8(feats[a:b], frame[a:b], MB))
-    two = torch.cat(parts)
-    d = (two.int() - whole.int()).abs()
-    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3
+    assert torch.equal(torch.cat(parts), whole[:8])
     # streaming gatherer (what bench.py uses for N > 1): three submits through two rotating buffers
     fg = vdist.FrameGatherer((MB, H, W, 3), 1, torch.device("cuda", 0), dtype=torch.uint8)
     slots = [fg.submit(whole[i:i + MB] if i + MB <= F_ else whole[F_ - MB:F_]) for i in (0, 4, 8)]
