@@ -28,7 +28,17 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--phases", action="store_true", help="also time forward / loss+backward / Adam separately (adds syncs)")
+    ap.add_argument("--gpus", type=int, default=1, help="data-parallel replicas to start when not already under a launcher")
     args = ap.parse_args()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "vstab_launch", os.path.join(ROOT, "coupe", "optical_flow_based_deep_video_stabilization_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    rc = launch.maybe_self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus,
+                                  force=os.environ.get("VSTAB_FORCE_DIST") == "1")     # child job; nothing here touches the GPU
+    if rc is not None:
+        raise SystemExit(rc)
     if not torch.cuda.is_available():
         raise SystemExit("bench_train.py needs a GPU")
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -84,7 +94,7 @@ def main():
         return
     print(json.dumps({
         "metric": f"training samples/sec @{H}x{W}", "value": round(B * world / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-        "scaling": "weak",
+        "scaling": "weak", "vs_baseline": None,
         "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": "f32",
         "data": "synthetic (uniform [0,1) frames, seeded He-normal weights)", "final_loss": float(loss),
         "approx_tflops": round(3.0 * gf * B * world / dt / 1e3, 2), "phases": phases,

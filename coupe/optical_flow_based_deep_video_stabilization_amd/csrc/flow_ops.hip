@@ -4,6 +4,8 @@
 // of fp32 roundings the reference's TF graph performs; dot products use explicit fmaf.
 #include "vstab_internal.h"
 #include <hip/hip_ext.h>
+#include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <vector>
 
@@ -284,6 +286,74 @@ __global__ __launch_bounds__(256) void pf2_kernel(const float *__restrict__ T, i
     reinterpret_cast<f32x2 *>(pf2)[idx] = o;
 }
 
+// Tiled form: a workgroup owns a 16 x 64 tile of output pixels.  The nearest-neighbour map is monotone, so the source pixels the
+// tile's 3x3 taps can reach are a small rectangle of the tap table (about (16+2)/4+2 rows x (64+2)/4+2 columns): it is copied
+// into LDS once (the 18 used floats of each 128-byte table row; the zero-padding ring as zeros) and every output pixel then takes
+// its nine taps as 8-byte LDS reads instead of nine 8-byte global gathers -- the direct kernel spent its time in the L1 tag pipe
+// (nine lookups per pixel) with the table itself L2-resident.  Same sums in the same (dy, dx) order; a skipped out-of-image tap
+// is now an added +0.0f.
+constexpr int PF2_TH = 16, PF2_TW = 64, PF2_PPT = 4, PF2_CAP = 320;      // CAP: window pixels held in LDS (23 KB)
+__global__ __launch_bounds__(256) void pf2_tile_kernel(const float *__restrict__ T, int B, int h2, int w2,
+                                                       const float *__restrict__ bias2, const float *__restrict__ pf3,
+                                                       int h3, int w3, float *__restrict__ pf2, int H, int W,
+                                                       float nsy, float nsx, float usy, float usx, int tiles_x, int tiles_y)
+{
+    __shared__ __attribute__((aligned(8))) float tab[PF2_CAP * 18];
+    const int oh = H - 2, ow = W - 2;
+    unsigned bx, by, bz;
+    xcd_remap_calc(gridDim.x, 1, 1, blockIdx.x, bx, by, bz);
+    const int tpi = tiles_x * tiles_y;
+    const int n = (int)bx / tpi, trem = (int)bx - n * tpi;
+    const int ty0 = (trem / tiles_x) * PF2_TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * PF2_TW;
+    // source window (indices into the UNPADDED concat2 grid, so -1 and h2 / w2 are the zero ring)
+    const int r_lo = nearest_ac(ty0, nsy, h2 + 2) - 1, r_hi = nearest_ac(min(ty0 + PF2_TH - 1, oh - 1) + 2, nsy, h2 + 2) - 1;
+    const int c_lo = nearest_ac(tx0, nsx, w2 + 2) - 1, c_hi = nearest_ac(min(tx0 + PF2_TW - 1, ow - 1) + 2, nsx, w2 + 2) - 1;
+    const int wcols = c_hi - c_lo + 1, npx = (r_hi - r_lo + 1) * wcols;       // npx <= PF2_CAP: checked on the host
+    const float *Tn = T + (size_t)n * h2 * w2 * 32;
+    const float inv = 1.0f / (float)wcols;
+    for (int u = threadIdx.x; u < npx * 9; u += 256) {
+        const int px = u / 9, t = u - px * 9;
+        const int wr = (int)(((float)px + 0.5f) * inv), wc = px - wr * wcols;
+        const int sy = r_lo + wr, sx = c_lo + wc;
+        f32x2 v = {0.f, 0.f};
+        if ((unsigned)sy < (unsigned)h2 && (unsigned)sx < (unsigned)w2) v = *reinterpret_cast<const f32x2 *>(Tn + ((size_t)sy * w2 + sx) * 32 + t * 2);
+        *reinterpret_cast<f32x2 *>(tab + px * 18 + t * 2) = v;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float b0 = bias2[0], b1 = bias2[1];
+#pragma unroll
+    for (int j = 0; j < PF2_PPT; ++j) {
+        const int y = ty0 + j * 4 + (lane >> 4), x = tx0 + wave * 16 + (lane & 15);
+        if (y >= oh || x >= ow) continue;
+        int ry[3], rx[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            ry[d] = (nearest_ac(y + d, nsy, h2 + 2) - 1 - r_lo) * wcols;
+            rx[d] = nearest_ac(x + d, nsx, w2 + 2) - 1 - c_lo;
+        }
+        float a0 = b0, a1 = b1;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const f32x2 t = *reinterpret_cast<const f32x2 *>(tab + (ry[dy] + rx[dx]) * 18 + (dy * 3 + dx) * 2);
+                a0 += t.x;
+                a1 += t.y;
+            }
+        const f32x2 u = sample_flow_legacy(pf3, n, h3, w3, y, x, usy, usx);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a0 += u.x; a1 += u.y; }
+        f32x2 o; o.x = a0; o.y = a1;
+        reinterpret_cast<f32x2 *>(pf2)[((size_t)n * oh + y) * ow + x] = o;
+    }
+}
+
+static int nearest_ac_host(int i, float scale, int n_in)
+{
+    return std::min((int)roundf((float)i * scale), n_in - 1);
+}
+
 hipError_t launch_pf2(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3,
                       float *pf2, int H, int W, hipStream_t stream)
 {
@@ -291,6 +361,19 @@ hipError_t launch_pf2(const float *T, int B, int h2, int w2, const float *bias2,
     const float nsy = H > 1 ? (float)(h2 + 2 - 1) / (float)(H - 1) : 0.f;
     const float nsx = W > 1 ? (float)(w2 + 2 - 1) / (float)(W - 1) : 0.f;
     const float usy = (float)h3 / (float)(H - 2), usx = (float)w3 / (float)(W - 2);
+    const int oh = H - 2, ow = W - 2;
+    const int tiles_x = (ow + PF2_TW - 1) / PF2_TW, tiles_y = (oh + PF2_TH - 1) / PF2_TH;
+    // largest source window of any tile (the device evaluates the same fp32 map): rows and columns separately
+    int rows_max = 0, cols_max = 0;
+    for (int t = 0; t < tiles_y; ++t)
+        rows_max = std::max(rows_max, nearest_ac_host(std::min(t * PF2_TH + PF2_TH - 1, oh - 1) + 2, nsy, h2 + 2) - nearest_ac_host(t * PF2_TH, nsy, h2 + 2) + 1);
+    for (int t = 0; t < tiles_x; ++t)
+        cols_max = std::max(cols_max, nearest_ac_host(std::min(t * PF2_TW + PF2_TW - 1, ow - 1) + 2, nsx, w2 + 2) - nearest_ac_host(t * PF2_TW, nsx, w2 + 2) + 1);
+    if (rows_max * cols_max <= PF2_CAP && (long long)tiles_x * tiles_y * B < (1ll << 31)) {
+        pf2_tile_kernel<<<dim3((unsigned)(tiles_x * tiles_y * B)), dim3(256), 0, stream>>>(T, B, h2, w2, bias2, pf3, h3, w3, pf2, H, W, nsy, nsx,
+                                                                                        usy, usx, tiles_x, tiles_y);
+        return hipGetLastError();
+    }
     pf2_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(T, B, h2, w2, bias2, pf3, h3, w3, pf2, H, W,
                                                                              nsy, nsx, usy, usx);
     return hipGetLastError();
