@@ -775,11 +775,12 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
             r.s_in = ENC[0].s; r.off_y = -ENC[0].p;
             r.e_off = -ENC[0].p * Cin - rowwin_lead(-ENC[0].p, Cin);
             r.w_a = ((r.e_off % 4) + 4) % 4;
-            r.WLEN = round_up(r.s_in * Cin * 127 + r.w_a + r.SEGP, 4);
+            r.MB = rowwin_mb(B, p.Ho, p.Wo);
+            r.WLEN = round_up(r.s_in * Cin * (64 * r.MB - 1) + r.w_a + r.SEGP, 4);
             r.Ho = p.Ho; r.Wo = p.Wo; r.Cs_out = p.Cs_out; r.c_off = 0; r.N = p.N; r.Npad = p.Npad; r.act = 1;
             if (in_bytes < 0x80000000LL && rowwin_applicable(r)) {
                 HIP_TRY(ctx, launch_conv_rowwin(r, stream, EV_A(0), EV_B(0)));
-                ctx->prof_kernel[0] = "conv_rowwin_kernel<7>";
+                ctx->prof_kernel[0] = r.MB == 2 ? "conv_rowwin_kernel<7, 2>" : "conv_rowwin_kernel<4, 1>";
                 continue;
             }
         }
@@ -857,7 +858,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
 
 static std::string conv_kernel_name(ConvTile t, bool vec4)
 {
-    const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : (t == TILE_64x128 ? "64, 128, 1, 4" : "128, 32, 4, 1"));
+    const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : (t == TILE_64x128 ? "64, 128, 1, 4" : (t == TILE_64x64 ? "64, 64, 2, 2" : "128, 32, 4, 1")));
     const bool dma = conv_uses_lds_dma(t, vec4);
     return std::string("conv_mfma_kernel<") + shape + (vec4 ? ", true" : ", false") + (dma ? ", true>" : ", false>");
 }

@@ -33,20 +33,23 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NWIN4>   // float4 loads per thread per window
+// MB = 32-pixel blocks per wave: 2 -> 128 output pixels per workgroup (wave tile 64 x 32); 1 -> 64 pixels (wave tile 32 x 32) for
+// launches that would otherwise put fewer than two workgroups on a CU (one sample at 384x512: 384 workgroups on 256 CUs run as
+// two uneven rounds, 91 us; 768 half-size ones are all resident at once)
+template <int NWIN4, int MB>   // float4 loads per thread per window
 __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *win = reinterpret_cast<float *>(smem);           // [2][WLEN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                // 2x2 waves, wave tile 64 (pixels) x 32 (channels)
+    const int wm = wave >> 1, wn = wave & 1;                // 2x2 waves, wave tile 32*MB (pixels) x 32 (channels)
     const int li = lane & 31, lh = lane >> 5;
     // XCD-aware order: grid = (row, x tile, sample) so that a remapped XCD range is a band of consecutive output rows, whose
     // 7-row input windows overlap by five rows
     unsigned bx_, by_, bz_;
     xcd_remap(bx_, by_, bz_);
-    const int oy = (int)bx_, ox0 = (int)by_ * 128, n = (int)bz_;
+    const int oy = (int)bx_, ox0 = (int)by_ * (64 * MB), n = (int)bz_;
     const int pix_step = p.s_in * p.Cs_in;
     const int row_floats = p.Wi * p.Cs_in;
     const int g0 = pix_step * ox0 + p.e_off - p.w_a;       // window start, floats from the row start (multiple of 4)
@@ -88,15 +91,15 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
         for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const f32x4 *>(s + q * 8);
     };
 
-    f32x16 acc[2];
+    f32x16 acc[MB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     const int kpr = p.SEGP >> 5;                       // K-tiles per filter row
     // A operand address inside the window: pix_step*m + w_a + 32*kc + 4*r + 2*h
-    const int a_off0 = pix_step * (wm * 64 + li) + p.w_a + 2 * lh;
+    const int a_off0 = pix_step * (wm * 32 * MB + li) + p.w_a + 2 * lh;
     const int a_off1 = a_off0 + pix_step * 32;
 
     // one K-tile: 16 ds_read_b64 + 32 MFMAs; the B fragments are already in registers
@@ -105,13 +108,14 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const f32x2 a0 = *reinterpret_cast<const f32x2 *>(wa0 + 4 * r);
-            const f32x2 a1 = *reinterpret_cast<const f32x2 *>(wa1 + 4 * r);
+            f32x2 a1 = a0;
+            if (MB == 2) a1 = *reinterpret_cast<const f32x2 *>(wa1 + 4 * r);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int s = 2 * r + j;
                 const float bv = b[s >> 2][s & 3];
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bv, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bv, acc[1], 0, 0, 0);
+                if (MB == 2) acc[MB - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bv, acc[MB - 1], 0, 0, 0);
             }
         }
     };
@@ -159,10 +163,10 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
     if (col < p.N) {
         const float bv = p.bias[col];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ox = ox0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ox = ox0 + wm * 32 * MB + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (ox < p.Wo) {
                     float v = acc[mb][r] + bv;
                     if (p.act) v = fmaxf(v, (p.act == 1 ? 0.1f : 0.0f) * v);
@@ -176,23 +180,32 @@ bool rowwin_applicable(const RowWinParams &p)
 {
     const int pix_step = p.s_in * p.Cs_in;
     return (pix_step % 2 == 0) && ((p.Wi * p.Cs_in) % 4 == 0) && (((uintptr_t)p.in & 15) == 0) && p.N <= 64 &&
-           p.Npad == 64 && p.WLEN <= 7 * 1024 && (p.WLEN % 4) == 0 && p.in_bytes < 0x80000000u;
+           p.Npad == 64 && (p.MB == 1 || p.MB == 2) && p.WLEN <= (p.MB == 2 ? 7 : 4) * 1024 && (p.WLEN % 4) == 0 &&
+           p.in_bytes < 0x80000000u;
 }
 
 hipError_t rowwin_set_attributes()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rowwin_kernel<7>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * 1024 * 4);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rowwin_kernel<7, 2>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * 1024 * 4);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(conv_rowwin_kernel<4, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 1024 * 4);
 }
 
 hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (!rowwin_applicable(p)) return hipErrorInvalidValue;
-    dim3 grid(p.Ho, (p.Wo + 127) / 128, p.B), block(256);       // (row, x tile, sample): see the XCD remap in the kernel
-    if (ev_start && ev_stop)      // timestamps of the kernel's own dispatch packet, no marker packets (see conv_mfma.hip)
-        hipExtLaunchKernelGGL(conv_rowwin_kernel<7>, grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, p);
-    else
-        conv_rowwin_kernel<7><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(p);
+    const int tile = 64 * p.MB;
+    dim3 grid(p.Ho, (p.Wo + tile - 1) / tile, p.B), block(256);       // (row, x tile, sample): see the XCD remap in the kernel
+    const bool timed = ev_start && ev_stop;      // timestamps of the kernel's own dispatch packet, no marker packets (see conv_mfma.hip)
+    if (p.MB == 2) {
+        if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<7, 2>), grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, p);
+        else conv_rowwin_kernel<7, 2><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(p);
+    } else {
+        if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<4, 1>), grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, p);
+        else conv_rowwin_kernel<4, 1><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(p);
+    }
     return hipGetLastError();
 }
 

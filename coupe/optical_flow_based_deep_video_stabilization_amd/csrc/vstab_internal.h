@@ -94,7 +94,7 @@ struct ConvParams {
     ConvPhase ph[16];       // 4 transposed-conv phases, or the 16 positions of a Winograd-domain GEMM
 };
 
-enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 = 3 };
+enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 = 3, TILE_64x64 = 4 };
 
 // Launch the implicit-GEMM kernel (and the split-K combine when p.ksplit > 1).
 // ev_start/ev_stop (optional) are recorded immediately around the GEMM kernel itself.
@@ -122,7 +122,11 @@ struct RowWinParams {
     int WLEN;               // window length in floats (multiple of 4)
     int Ho, Wo, Cs_out, c_off;
     int N, Npad, act;
+    int MB;                 // 2: 128-pixel tiles; 1: 64-pixel tiles (small launches)
 };
+// tile height of the row-window kernel for a launch of Ho x Wo x B output pixels: 64-pixel tiles while 128-pixel ones would not
+// give every CU two workgroups
+inline int rowwin_mb(int B, int Ho, int Wo) { return (long long)B * Ho * ((Wo + 127) / 128) < 512 ? 1 : 2; }
 bool rowwin_applicable(const RowWinParams &p);
 hipError_t rowwin_set_attributes();
 hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEvent_t ev_start = nullptr,

@@ -1,11 +1,12 @@
 #!/bin/bash
-# builds tools/conv_bench (tuning harness) next to the library objects
+# builds the tuning harnesses under tools/ (not part of the product): conv_bench with the VSTAB_HARNESS switches and ablations, warp_bench
 set -e
 cd "$(dirname "$0")/.."
 P=coupe/optical_flow_based_deep_video_stabilization_amd
 python $P/build.py >/dev/null
-for abl in 0 1 5; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DVSTAB_HARNESS -DVSTAB_ABL=$abl tools/conv_bench.hip $P/csrc/conv_mfma.hip $P/csrc/conv_rowwin.hip $P/csrc/pack.cpp $P/csrc/api.cpp $P/csrc/flow_ops.hip $P/csrc/sampler_ops.hip $P/csrc/nldf_ops.hip $P/csrc/clip_ops.hip $P/csrc/nldf_api.cpp -o tools/conv_bench_abl$abl 2>/tmp/bt_$abl.log &
+SRCS=$(python -c "from coupe.optical_flow_based_deep_video_stabilization_amd import build; print(' '.join('$P/csrc/' + s for s in build.SOURCES))")
+for abl in ${ABLS:-0 1 5}; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DVSTAB_HARNESS -DVSTAB_ABL=$abl tools/conv_bench.hip $SRCS -o tools/conv_bench_abl$abl 2>/tmp/bt_$abl.log &
 done
 wait
 echo built tools/conv_bench_abl*

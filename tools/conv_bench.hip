@@ -23,7 +23,7 @@ int main(int argc, char **argv)
     p.N = v[15]; p.Npad = v[16]; p.act = v[17]; p.nphase = v[18]; p.ksplit = v[19]; p.Mmax = v[20];
     int tile = v[21]; const bool vec4 = v[22];
     const int KT = p.KH * p.NSEG * p.SEGP / 32;
-    if (tile_o >= 0) { tile = tile_o; const int BN = (tile == 0 || tile == 3) ? 128 : (tile == 1 ? 64 : 32); p.Npad = round_up(p.N, BN); }
+    if (tile_o >= 0) { tile = tile_o; const int BN = (tile == 0 || tile == 3) ? 128 : ((tile == 1 || tile == 4) ? 64 : 32); p.Npad = round_up(p.N, BN); }
     if (ks_o >= 1) p.ksplit = ks_o;
     double macs = 0;
     for (int k = 0; k < p.nphase; ++k) {
@@ -56,7 +56,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < iters; ++i) CK(launch_conv(p, (ConvTile)tile, vec4, 0));
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
-    const int BN = (tile == 0 || tile == 3) ? 128 : (tile == 1 ? 64 : 32), BM = tile == 3 ? 64 : 128;
+    const int BN = (tile == 0 || tile == 3) ? 128 : ((tile == 1 || tile == 4) ? 64 : 32), BM = (tile == 3 || tile == 4) ? 64 : 128;
     const long long blocks = (long long)((p.Mmax + BM - 1) / BM) * (p.Npad / BN) * p.nphase * p.ksplit;
     printf("layer %2d tile %d ksplit %2d blocks %6lld KT %4d  %8.2f us  %7.1f TF(issued)  frac %.3f\n", layer, tile, p.ksplit, blocks, KT,
            ms * 1e3, 2 * macs / (ms * 1e-3) / 1e12, 2 * macs / (ms * 1e-3) / 1e12 / 157.3);
