@@ -296,8 +296,19 @@ def main():
             kernels = {"flow_glue_warp": "warp3_tile_kernel<true, true, 4, 16, 32, 2, true, false, " + ("true" if W % 4 == 0 else "false") + ">",
                        "warp_flow": "warp3_tile_kernel<false, false, ...>", "flow_resize_scale": "flow_resize_scale_kernel"}
             gbs = by / (ms_sum * 1e-3) / 1e9
+            h_traffic, h_src = None, "not measured by this run"
+            try:     # static, like roofline.traffic: the newest committed PMC pass of this workload (cfg1) or of B=16 1080p
+                import glob
+                tag = {(8, 512, 512, 27): "pmc_r*.json", (16, 1080, 1920, 27): "pmc1080_r*.json"}.get((B, H, W, Cin))
+                pj = sorted(glob.glob(os.path.join(ROOT, "profiles", tag))) if tag else []
+                if pj:
+                    h_traffic = json.load(open(pj[-1])).get(kernels[name], {}).get("hbm_bytes_per_launch_corrected")
+                    if h_traffic is not None:
+                        h_src = "static: profiles/" + os.path.basename(pj[-1]) + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of the same command)"
+            except Exception:
+                h_traffic, h_src = None, "not measured by this run"
             roofline_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": "not measured by this run",
+                            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": h_traffic, "traffic_source": h_src,
                             "kernel": kernels[name], "entry_point": "vstab_" + name, "launches": nl,
                             "avg_launch_us": round(ms_sum / nl * 1e3, 2), "alg_bytes_per_launch": by / nl,
                             "alg_bytes_per_output_pixel": round(by / nl / (B * H * W), 2),
