@@ -25,4 +25,9 @@ def test_bench_prints_one_contract_line():
     assert abs(d["value"] - 8 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-3
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert 0.3 < rf["frac"] < 1.0 and rf["kernel"].startswith("conv_")
+    assert 0.3 < rf["frac"] < 1.0 and rf["kernel"].startswith("conv_") and "traffic_source" in rf
+    assert d["metric"].endswith("@512x512") and "roofline_hbm" in d
+    rh = d["roofline_hbm"]                                   # the glue + warp launch against the HBM peak
+    assert rh["bound"] == "hbm" and rh["unit"] == "GB/s" and rh["peak"] == 8000.0 and abs(rh["frac"] - rh["achieved"] / rh["peak"]) < 1e-3
+    assert 0.1 < rh["frac"] < 1.0 and rh["entry_point"] == "vstab_flow_glue_warp" and rh["launches"] >= 1
+    assert abs(rh["alg_bytes_per_output_pixel"] - 40.0) < 0.2

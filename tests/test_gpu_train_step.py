@@ -31,6 +31,30 @@ def test_network_backward_matches_autograd(winograd):
     tr.wino_min_flops = 0.0 if winograd else 1e30          # force / forbid the Winograd form of the 3x3 stride-1 stages
     flows = tr.forward(feats.cuda())
 
+    # The activation pattern itself (the gradient check below feeds the implementation's own leaky-relu
+    # sides to the oracle): against the fp64 oracle run on ITS OWN pattern, an element may sit on the other side of the kink
+    # only if its value is within rounding distance of zero, and only a handful may at all.
+    masks = tr.lrelu_masks()
+    with torch.no_grad():
+        _, own = vo.flownetS_pyramid(feats, w, torch.float64, return_internals=True, is_train=True)
+    enc_names = [e[0] for e in train_step.ENC]
+    for name in enc_names + ["deconv5", "deconv4", "deconv3", "deconv2"]:
+        if name in enc_names:
+            y = own[f"conv{name}"]
+            if name in ("2", "3_1", "4_1", "5_1"):             # these are stored inside the concat buffers too; same tensor
+                pass
+            m = masks[name]
+        else:
+            cat = own["concat" + name[-1]]                         # [skip | deconvN | upsampled flow]
+            skip = {"5": 512, "4": 512, "3": 256, "2": 128}[name[-1]]
+            y = cat[..., skip:cat.shape[3] - 2]
+            m = masks[name + "_bn"]
+        flips = (y > 0) != m
+        nflip = int(flips.sum())
+        assert nflip <= max(4, int(2e-4 * y.numel())), (name, nflip, y.numel())
+        if nflip:
+            assert float(y[flips].abs().max()) <= 2e-4 * max(1.0, float(y.abs().max())), (name, float(y[flips].abs().max()))
+
     Wt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=("moving_" not in k)) for k, v in w.items()}
     stats = {}
     out = vo.flownetS_pyramid(feats, Wt, is_train=True, batch_stats=stats, lrelu_masks=tr.lrelu_masks())
