@@ -1,0 +1,49 @@
+"""Randomised shapes and flows for the tiled warp and the fused glue + warp launch (hypothesis): every drawn case must be
+bit-identical to the fp32 oracle restatement of main:70-130 / main:497-498 -- tiles hanging over the right and bottom edge,
+images smaller than one 16x32 tile, widths that are not a multiple of 4 (12-byte store path), flows landing exactly on the
+discontinuities of SURVEY.md A.6 (x = -1, 0, W-1, integers) and far outside the image."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+import coupe.optical_flow_based_deep_video_stabilization_amd as vs
+from oracle import vstab_oracle as vo
+
+pytestmark = pytest.mark.gpu
+SPECIAL = np.array([0.0, -1.0, 1.0, -0.5, 0.5, -0.999999, 2.0, -2.0, 1e-7, -1e-7, 37.25, -63.75, 1e6, -1e6], dtype=np.float32)
+
+
+def _flow(rng, B, H, W, scale):
+    f = (rng.standard_normal((B, H, W, 2)) * scale).astype(np.float32)
+    k = max(1, (B * H * W) // 7)
+    idx = rng.integers(0, B * H * W, size=k)
+    f.reshape(-1, 2)[idx] = SPECIAL[rng.integers(0, len(SPECIAL), size=(k, 2))]
+    # pixels whose sample point lands exactly on the far edge / on integers
+    f[:, :, -1, 0] = 0.0
+    f[:, -1, :, 1] = 0.0
+    return f
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(B=st.integers(1, 3), H=st.integers(1, 70), W=st.integers(1, 150), scale=st.sampled_from([0.3, 3.0, 40.0]), seed=st.integers(0, 2**16))
+def test_warp_any_shape_bit_exact(B, H, W, scale, seed):
+    rng = np.random.default_rng(seed)
+    img = torch.from_numpy(rng.random((B, H, W, 3), dtype=np.float32))
+    flow = torch.from_numpy(_flow(rng, B, H, W, scale))
+    out = vs.tf_warp(img.cuda(), flow.cuda(), H, W)
+    assert torch.equal(out.cpu(), vo.tf_warp(img, flow, H, W, torch.float32))
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(B=st.integers(1, 2), hn=st.integers(6, 60), wn=st.integers(6, 90), oh=st.integers(1, 70), ow=st.integers(1, 130),
+       scale=st.sampled_from([0.5, 6.0]), seed=st.integers(0, 2**16))
+def test_fused_glue_warp_any_shape(B, hn, wn, oh, ow, scale, seed):
+    rng = np.random.default_rng(seed)
+    pf2 = torch.from_numpy((rng.standard_normal((B, hn - 2, wn - 2, 2)) * scale).astype(np.float32)).cuda()
+    frame = torch.from_numpy(rng.random((B, oh, ow, 3), dtype=np.float32)).cuda()
+    of_ref = vs.flow_to_output_res(pf2, hn, wn, oh, ow)               # the stand-alone glue kernel (checked against the oracle below)
+    of, wp = vs.flow_glue_warp(pf2, frame, hn, wn)
+    assert torch.equal(of, of_ref)
+    assert float((of.cpu() - vo.flow_to_output_res(pf2.cpu(), hn, wn, oh, ow).float()).abs().max()) <= 2e-5 * max(1.0, scale * 4)
+    assert torch.equal(wp.cpu(), vo.tf_warp(frame.cpu(), of.cpu(), oh, ow, torch.float32))
