@@ -34,6 +34,7 @@ EXPORTS = {
     "vstab_flow_resize_scale": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] + [C.c_int] * 2 +
                                 [C.c_float] * 3 + [C.c_void_p]),
     "vstab_resize_bilinear": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]),
+    "vstab_resize_bilinear_slice3": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]),
     "vstab_warp_flow": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "vstab_flow_glue_warp": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float] * 3 + [C.c_void_p]),
     "vstab_trace_ranges": (C.c_int, [C.c_int]),

@@ -135,7 +135,7 @@ class NativeClipStabiliser:
 
     def step(self, frame_bgr_u8: torch.Tensor) -> torch.Tensor:
         from .model import flownetS_pyramid
-        from .warp_flow import resize_images, tf_warp
+        from .warp_flow import resize_images_slice3, tf_warp
         f = _u8(frame_bgr_u8, "frame")
         if f.shape[0] != self.n:
             raise ValueError(f"frame must hold {self.n} clips, got {f.shape[0]}")
@@ -151,7 +151,7 @@ class NativeClipStabiliser:
         of = flows['predict_flow2']
         flow = self.flow_filter(of) if self.flow_filter is not None else of
         fh, fw = self.net_h - 2, self.net_w - 2
-        unstab = resize_images(self.feats[..., 24:27].contiguous(), (fh, fw))                           # main:806
+        unstab = resize_images_slice3(self.feats, 24, (fh, fw))                                          # main:806
         warped = tf_warp(unstab, flow, fh, fw)                                                          # main:807
         out = torch.empty((self.n, self.net_h, self.net_w, 3), dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):

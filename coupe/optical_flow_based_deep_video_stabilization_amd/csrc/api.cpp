@@ -927,6 +927,18 @@ extern "C" int vstab_resize_bilinear(const float *x, int B, int h, int w, int C,
     return VSTAB_OK;
 }
 
+extern "C" int vstab_resize_bilinear_slice3(const float *x, int B, int h, int w, int Cs, int c_off, float *out, int oh, int ow, void *stream)
+{
+    if (!x || !out) return fail(nullptr, VSTAB_E_STATE, "resize_bilinear_slice3: NULL buffer");
+    if (B < 1 || h < 1 || w < 1 || oh < 1 || ow < 1 || Cs < 3 || c_off < 0 || c_off + 3 > Cs)
+        return fail(nullptr, VSTAB_E_SHAPE, "resize_bilinear_slice3: bad shape");
+    if ((uintptr_t)out & 15) return fail(nullptr, VSTAB_E_ALIGN, "resize_bilinear_slice3: out must be 16-byte aligned");
+    const hipError_t e = launch_resize_bilinear_slice3(x, B, h, w, Cs, c_off, out, oh, ow, (hipStream_t)stream);
+    if (e == hipErrorNotSupported) return fail(nullptr, VSTAB_E_SHAPE, "resize_bilinear_slice3: problem too large");
+    HIP_TRY(nullptr, e);
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W, int C, void *stream)
 {
     if (!img || !flow || !out) return fail(nullptr, VSTAB_E_STATE, "warp_flow: NULL buffer");

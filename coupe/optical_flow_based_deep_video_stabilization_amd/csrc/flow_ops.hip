@@ -401,10 +401,19 @@ __global__ __launch_bounds__(256) void flow_resize_scale_kernel(const float *__r
     reinterpret_cast<f32x2 *>(out)[idx] = o;
 }
 
+// tiled forms (defined next to the warp's tile kernel below); they return hipErrorNotSupported when a shape is not theirs
+static hipError_t launch_glue_tile(const float *flow, int B, int h, int w, float *out, int oh, int ow, float pre, float sx, float sy,
+                                   hipStream_t stream);
+static hipError_t launch_resize3_tile(const float *x, int B, int h, int w, int Cs, int c_off, float *out, int oh, int ow, hipStream_t stream);
+
 hipError_t launch_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow, float pre, float sx,
                                     float sy, hipStream_t stream)
 {
     const long long total = (long long)B * oh * ow;
+    {
+        const hipError_t e = launch_glue_tile(flow, B, h, w, out, oh, ow, pre, sx, sy, stream);
+        if (e != hipErrorNotSupported) return e;
+    }
     // same size: TF returns the tensor unchanged; scale 1.0 gives lo = i, t = 0 -> identical values
     const float ry = (float)h / (float)oh, rx = (float)w / (float)ow;
     return launch_timed(HBM_SLOT_GLUE, 8.0 * B * h * w + 8.0 * total, flow_resize_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
@@ -435,6 +444,10 @@ hipError_t launch_resize_bilinear(const float *x, int B, int h, int w, int C, fl
     const long long total = (long long)B * oh * ow * C;
     if (h == oh && w == ow)
         return hipMemcpyAsync(out, x, sizeof(float) * total, hipMemcpyDeviceToDevice, stream);
+    if (C == 3) {
+        const hipError_t e = launch_resize3_tile(x, B, h, w, 3, 0, out, oh, ow, stream);
+        if (e != hipErrorNotSupported) return e;
+    }
     resize_bilinear_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(
         x, B, h, w, C, out, oh, ow, (float)h / (float)oh, (float)w / (float)ow);
     return hipGetLastError();
@@ -649,6 +662,157 @@ hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const f
     const double src = 8.0 * B * h * w;                       // the source flow is read once from HBM (its 4 taps per pixel hit in cache)
     if (outflow) return launch_warp3<true, true>(HBM_SLOT_GLUE_WARP, src + 32.0 * total, img, flow, out, outflow, B, oh, ow, G, stream);
     return launch_warp3<true, false>(HBM_SLOT_GLUE_WARP, src + 24.0 * total, img, flow, out, nullptr, B, oh, ow, G, stream);
+}
+
+// ---------------------------------------------------------------------------------
+// The stand-alone glue (main:497-498, for callers that filter the flow between glue and warp) and the 3-channel legacy-bilinear
+// resize (main:806: the unstable frame -- channels 24:27 of the 27-channel stack, read in place through `Cs` / `c_off` -- to
+// the flow grid; main:202-203) on the warp's tile mapping: 16 x 32 pixel tiles, 4 x 16 wave patches, the left/right taps of a
+// source row fetched as neighbours, rows leaving through LDS as 16-byte stores.  Same statements as flow_resize_scale_kernel /
+// resize_bilinear_kernel: bit-identical (tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------
+template <bool STAGE>
+__global__ __launch_bounds__(256) void glue_tile_kernel(const float *__restrict__ flow, float *__restrict__ out, int B, int oh, int ow,
+                                                        int tiles_x, int tiles_y, GlueParams G)
+{
+    constexpr int TW = WT_TW, TH = WT_TH, PPT = WT_PPT, WW = WT_WW, WH = WT_WH, PPR = TW / WW;
+    __shared__ __attribute__((aligned(16))) float stage[STAGE ? TH * TW * 2 : 4];
+    unsigned bx, by, bz;
+    xcd_remap_calc(gridDim.x, 1, 1, blockIdx.x, bx, by, bz);
+    const int tpi = tiles_x * tiles_y;
+    const int n = (int)bx / tpi, trem = (int)bx - n * tpi;
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const f32x2 *b = reinterpret_cast<const f32x2 *>(flow) + (size_t)n * G.h * G.w;
+    flow2 top[PPT], bot[PPT];
+    Lerp Y[PPT], X[PPT];
+    int yy[PPT], xx[PPT], xb[PPT];
+    bool ok[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int q = j * 4 + wave;
+        const int y = ty0 + (q / PPR) * WH + lane / WW, x = tx0 + (q % PPR) * WW + lane % WW;
+        ok[j] = y < oh && x < ow;
+        yy[j] = min(y, oh - 1); xx[j] = min(x, ow - 1);
+        Y[j] = legacy_coord(yy[j], G.ry, G.h); X[j] = legacy_coord(xx[j], G.rx, G.w);
+        xb[j] = min(X[j].lo, G.w - 2);
+        top[j] = *reinterpret_cast<const flow2 *>(b + Y[j].lo * G.w + xb[j]);
+        bot[j] = *reinterpret_cast<const flow2 *>(b + Y[j].hi * G.w + xb[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const bool l1 = X[j].lo != xb[j], h1 = X[j].hi != xb[j];
+        const f32x2 tl = l1 ? top[j].b : top[j].a, tr = h1 ? top[j].b : top[j].a, bl = l1 ? bot[j].b : bot[j].a, br = h1 ? bot[j].b : bot[j].a;
+        f32x2 o;
+        o.x = lerp2(tl.x * G.pre, tr.x * G.pre, bl.x * G.pre, br.x * G.pre, X[j].t, Y[j].t) * G.sx;
+        o.y = lerp2(tl.y * G.pre, tr.y * G.pre, bl.y * G.pre, br.y * G.pre, X[j].t, Y[j].t) * G.sy;
+        if (STAGE) {
+            const int q = j * 4 + wave;
+            *reinterpret_cast<f32x2 *>(stage + (((q / PPR) * WH + lane / WW) * TW + (q % PPR) * WW + lane % WW) * 2) = o;
+        } else if (ok[j]) {
+            reinterpret_cast<f32x2 *>(out)[((size_t)n * oh + yy[j]) * ow + xx[j]] = o;
+        }
+    }
+    if (STAGE) {           // ow even (host): a tile row is 256 bytes from a 16-byte aligned address
+        __syncthreads();
+        constexpr int R4 = TW * 2 / 4;
+        const int vw2 = min(TW, ow - tx0) * 2;
+        for (int e = threadIdx.x; e < TH * R4; e += 256) {
+            const int row = e / R4, c4 = e - row * R4;
+            if (ty0 + row >= oh || c4 * 4 >= vw2) continue;
+            float *o = out + (((size_t)n * oh + ty0 + row) * ow + tx0) * 2 + c4 * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * TW * 2 + c4 * 4);
+            if (c4 * 4 + 4 <= vw2) *reinterpret_cast<f32x4 *>(o) = v;
+            else { o[0] = v[0]; o[1] = v[1]; }
+        }
+    }
+}
+
+static hipError_t launch_glue_tile(const float *flow, int B, int h, int w, float *out, int oh, int ow, float pre, float sx, float sy,
+                                   hipStream_t stream)
+{
+    const long long tiles = (long long)((ow + WT_TW - 1) / WT_TW) * ((oh + WT_TH - 1) / WT_TH) * B;
+    if (w < 2 || tiles >= (1ll << 31) || (long long)B * oh * ow >= (1ll << 31) || ((uintptr_t)out & 15)) return hipErrorNotSupported;
+    const GlueParams G{h, w, pre, sx, sy, (float)h / (float)oh, (float)w / (float)ow};
+    const int tx = (ow + WT_TW - 1) / WT_TW, ty = (oh + WT_TH - 1) / WT_TH;
+    const double bytes = 8.0 * B * h * w + 8.0 * B * oh * ow;
+    if ((ow & 1) == 0)
+        return launch_timed(HBM_SLOT_GLUE, bytes, glue_tile_kernel<true>, dim3((unsigned)tiles), dim3(256), stream, flow, out, B, oh, ow, tx, ty, G);
+    return launch_timed(HBM_SLOT_GLUE, bytes, glue_tile_kernel<false>, dim3((unsigned)tiles), dim3(256), stream, flow, out, B, oh, ow, tx, ty, G);
+}
+
+template <bool STAGE>
+__global__ __launch_bounds__(256) void resize3_tile_kernel(const float *__restrict__ x, int B, int h, int w, int Cs, int c_off,
+                                                           float *__restrict__ out, int oh, int ow, float ry, float rx, int tiles_x,
+                                                           int tiles_y)
+{
+    constexpr int TW = WT_TW, TH = WT_TH, PPT = WT_PPT, WW = WT_WW, WH = WT_WH, PPR = TW / WW;
+    __shared__ __attribute__((aligned(16))) float stage[STAGE ? TH * TW * 3 : 4];
+    unsigned bx, by, bz;
+    xcd_remap_calc(gridDim.x, 1, 1, blockIdx.x, bx, by, bz);
+    const int tpi = tiles_x * tiles_y;
+    const int n = (int)bx / tpi, trem = (int)bx - n * tpi;
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *b = x + (size_t)n * h * w * Cs + c_off;
+    rgb3 tl[PPT], tr[PPT], bl[PPT], br[PPT];
+    Lerp Y[PPT], X[PPT];
+    int yy[PPT], xx[PPT];
+    bool ok[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int q = j * 4 + wave;
+        const int y = ty0 + (q / PPR) * WH + lane / WW, xo = tx0 + (q % PPR) * WW + lane % WW;
+        ok[j] = y < oh && xo < ow;
+        yy[j] = min(y, oh - 1); xx[j] = min(xo, ow - 1);
+        Y[j] = legacy_coord(yy[j], ry, h); X[j] = legacy_coord(xx[j], rx, w);
+        tl[j] = *reinterpret_cast<const rgb3 *>(b + ((size_t)Y[j].lo * w + X[j].lo) * Cs); tr[j] = *reinterpret_cast<const rgb3 *>(b + ((size_t)Y[j].lo * w + X[j].hi) * Cs);
+        bl[j] = *reinterpret_cast<const rgb3 *>(b + ((size_t)Y[j].hi * w + X[j].lo) * Cs); br[j] = *reinterpret_cast<const rgb3 *>(b + ((size_t)Y[j].hi * w + X[j].hi) * Cs);
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        rgb3 o;
+        o.r = lerp2(tl[j].r, tr[j].r, bl[j].r, br[j].r, X[j].t, Y[j].t);
+        o.g = lerp2(tl[j].g, tr[j].g, bl[j].g, br[j].g, X[j].t, Y[j].t);
+        o.b = lerp2(tl[j].b, tr[j].b, bl[j].b, br[j].b, X[j].t, Y[j].t);
+        if (STAGE) {
+            const int q = j * 4 + wave;
+            *reinterpret_cast<rgb3 *>(stage + (((q / PPR) * WH + lane / WW) * TW + (q % PPR) * WW + lane % WW) * 3) = o;
+        } else if (ok[j]) {
+            reinterpret_cast<rgb3 *>(out)[((size_t)n * oh + yy[j]) * ow + xx[j]] = o;
+        }
+    }
+    if (STAGE) {           // ow % 4 == 0 (host)
+        __syncthreads();
+        constexpr int R4 = TW * 3 / 4;
+        const int vw3 = min(TW, ow - tx0) * 3;
+        for (int e = threadIdx.x; e < TH * R4; e += 256) {
+            const int row = e / R4, c4 = e - row * R4;
+            if (ty0 + row >= oh || c4 * 4 >= vw3) continue;
+            float *o = out + (((size_t)n * oh + ty0 + row) * ow + tx0) * 3 + c4 * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * TW * 3 + c4 * 4);
+            if (c4 * 4 + 4 <= vw3) *reinterpret_cast<f32x4 *>(o) = v;
+            else for (int i = 0; c4 * 4 + i < vw3; ++i) o[i] = v[i];
+        }
+    }
+}
+
+static hipError_t launch_resize3_tile(const float *x, int B, int h, int w, int Cs, int c_off, float *out, int oh, int ow, hipStream_t stream)
+{
+    const long long tiles = (long long)((ow + WT_TW - 1) / WT_TW) * ((oh + WT_TH - 1) / WT_TH) * B;
+    if (tiles >= (1ll << 31) || (long long)B * oh * ow >= (1ll << 31) || ((uintptr_t)out & 15) || c_off < 0 || c_off + 3 > Cs)
+        return hipErrorNotSupported;
+    const int tx = (ow + WT_TW - 1) / WT_TW, ty = (oh + WT_TH - 1) / WT_TH;
+    const float ry = (float)h / (float)oh, rx = (float)w / (float)ow;
+    if ((ow & 3) == 0) resize3_tile_kernel<true><<<dim3((unsigned)tiles), dim3(256), 0, stream>>>(x, B, h, w, Cs, c_off, out, oh, ow, ry, rx, tx, ty);
+    else resize3_tile_kernel<false><<<dim3((unsigned)tiles), dim3(256), 0, stream>>>(x, B, h, w, Cs, c_off, out, oh, ow, ry, rx, tx, ty);
+    return hipGetLastError();
+}
+
+// main:806 without the intermediate copy of the three channels: out [B,oh,ow,3] = resize_images(x[..., c_off:c_off+3], [oh, ow])
+hipError_t launch_resize_bilinear_slice3(const float *x, int B, int h, int w, int Cs, int c_off, float *out, int oh, int ow, hipStream_t stream)
+{
+    return launch_resize3_tile(x, B, h, w, Cs, c_off, out, oh, ow, stream);
 }
 
 // tf.nn.max_pool(ksize 2, strides 2, SAME) (vgg16.py:51-53): out = ceil(n/2); the window's taps beyond

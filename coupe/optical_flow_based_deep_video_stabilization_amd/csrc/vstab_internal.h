@@ -175,6 +175,8 @@ hipError_t launch_flow_resize_scale(const float *flow, int B, int h, int w, floa
                                     int ow, float pre, float sx, float sy, hipStream_t stream);
 hipError_t launch_resize_bilinear(const float *x, int B, int h, int w, int C, float *out, int oh,
                                   int ow, hipStream_t stream);
+hipError_t launch_resize_bilinear_slice3(const float *x, int B, int h, int w, int Cs, int c_off, float *out, int oh, int ow,
+                                         hipStream_t stream);
 hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W,
                             int C, hipStream_t stream);
 // per-launch timing of the HBM-side kernels (flow_ops.hip): slots of vstab_hbm_profile_read

@@ -3,7 +3,7 @@
 from __future__ import annotations
 
 from .model import flownetS_pyramid
-from .warp_flow import flow_glue_warp, flow_to_output_res, resize_images, tf_warp
+from .warp_flow import flow_glue_warp, flow_to_output_res, resize_images, resize_images_slice3, tf_warp
 
 
 def stabilise_originalsize(feats, frame, scope='flownetS', flow_filter=None):
@@ -25,6 +25,6 @@ def stabilise_native(feats, scope='flownetS'):
     (H-2)x(W-2), by predict_flow2."""
     flows = flownetS_pyramid(feats, feats.shape[0], is_train=False, scope=scope)
     H, W = feats.shape[1], feats.shape[2]
-    cur = feats[..., 24:27] if feats.shape[3] >= 27 else feats[..., -3:]
-    unstab = resize_images(cur.contiguous(), (H - 2, W - 2))
+    c_off = 24 if feats.shape[3] >= 27 else feats.shape[3] - 3
+    unstab = resize_images_slice3(feats, c_off, (H - 2, W - 2))            # main:806, read in place from the 27-channel stack
     return flows, tf_warp(unstab, flows['predict_flow2'], H - 2, W - 2)

@@ -58,6 +58,21 @@ def resize_images(x, size):
     return out
 
 
+def resize_images_slice3(x, c_off, size):
+    """resize_images(x[..., c_off:c_off+3], size) read in place from the Cs-channel tensor (main:806: the unstable frame is
+    channels 24:27 of the input stack) -- no intermediate 3-channel copy; bit-identical to resize_images of that copy."""
+    x = _f32_cuda(x, "x")
+    B, h, w, Cs = x.shape
+    oh, ow = int(size[0]), int(size[1])
+    if (h, w) == (oh, ow):
+        return x[..., c_off:c_off + 3].contiguous()
+    out = torch.empty((B, oh, ow, 3), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().vstab_resize_bilinear_slice3(x.data_ptr(), B, h, w, Cs, int(c_off), out.data_ptr(), oh, ow,
+                                                           runtime.stream_ptr()))
+    return out
+
+
 def flow_to_output_res(predict_flow2, net_h, net_w, out_h, out_w):
     """main:497-498 with 384 -> net_h, 512 -> net_w:
     resize_images(pf2 * net_h / pf2.shape[1], [out_h, out_w]); x *= out_w/net_w; y *= out_h/net_h."""

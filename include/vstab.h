@@ -128,6 +128,12 @@ VSTAB_API int vstab_flow_resize_scale(const float *flow, int B, int h, int w, fl
 VSTAB_API int vstab_resize_bilinear(const float *x, int B, int h, int w, int C, float *out, int oh, int ow,
                           void *stream);
 
+/* ---- main:806 without an intermediate copy: out [B,oh,ow,3] = tf.image.resize_images(x[..., c_off:c_off+3], [oh, ow]) for an
+ * NHWC tensor x with Cs channels per pixel (the unstable frame is channels 24:27 of the 27-channel input stack).  Legacy
+ * bilinear as vstab_resize_bilinear (bit-identical to it on a contiguous 3-channel copy).  out 16-byte aligned. */
+VSTAB_API int vstab_resize_bilinear_slice3(const float *x, int B, int h, int w, int Cs, int c_off, float *out, int oh, int ow,
+                                 void *stream);
+
 /* ---- tf_warp(img, flow, H, W) main:70-130.  img [B,H,W,C], flow [B,H,W,2] (x, y),
  * out [B,H,W,C]; truncating corners, clipped indices, weights from the clipped corners. */
 VSTAB_API int vstab_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W, int C,

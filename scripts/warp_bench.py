@@ -62,6 +62,30 @@ def main():
                 r[name] = {"us": round(us, 2), "alg_bytes_per_px": bpp, "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK, 4)}
                 print(f"{sh:>14} {kind:<7} {name:<32} {us:9.2f} us  {gbs:8.1f} GB/s  {gbs / PEAK:.3f}", file=sys.stderr, flush=True)
             rows.append(r)
+        # G2 (main:806): the unstable frame resized to the flow grid.  (a) from a contiguous 3-channel tensor: 12 B read + 12 B written
+        # per pixel; (b) in place from channels 24:27 of the 27-channel stack, as stabilise_native does: every 128-byte line of the
+        # stack is touched, so the bytes that move are 108 + 12 per pixel.  Stream events over back-to-back launches.
+        def ev_time(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / args.iters * 1e3
+        us = ev_time(lambda: vs.resize_images(img, (H - 2, W - 2)))
+        gbs = px * 24 / us * 1e-3
+        rows.append({"shape": sh, "resize3 contiguous (G2)": {"us": round(us, 2), "bytes_per_px": 24, "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK, 4)}})
+        print(f"{sh:>14} {'-':<7} {'resize of a 3-channel frame (G2)':<32} {us:9.2f} us  {gbs:8.1f} GB/s  {gbs / PEAK:.3f}", file=sys.stderr, flush=True)
+        if B * H * W * 27 * 4 < 8e9:
+            stack = torch.rand(B, H, W, 27, generator=g).cuda()
+            us = ev_time(lambda: vs.resize_images_slice3(stack, 24, (H - 2, W - 2)))
+            gbs = px * 120 / us * 1e-3
+            rows.append({"shape": sh, "resize 24:27 of the stack in place (G2)": {"us": round(us, 2), "bytes_per_px": 120, "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK, 4)}})
+            print(f"{sh:>14} {'-':<7} {'resize 24:27 of the stack':<32} {us:9.2f} us  {gbs:8.1f} GB/s  {gbs / PEAK:.3f} (120 B/px moved)", file=sys.stderr, flush=True)
+            del stack
     print(json.dumps(rows))
 
 

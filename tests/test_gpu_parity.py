@@ -106,7 +106,18 @@ def test_resize_images_vs_oracle(h, w, oh, ow):
     assert maxabs(out, ref) <= 1e-6
 
 
-@pytest.mark.parametrize("hn,wn,oh,ow", [(384, 512, 384, 512), (64, 64, 64, 64), (70, 90, 96, 120), (64, 96, 32, 48)])
+@pytest.mark.parametrize("B,h,w,cs,c_off,oh,ow", [(2, 64, 96, 27, 24, 62, 94), (1, 48, 64, 27, 24, 46, 62), (3, 33, 41, 6, 3, 70, 52),
+                                                  (1, 20, 24, 3, 0, 37, 53), (2, 40, 40, 5, 1, 20, 13)])
+def test_resize_slice3_in_place_bit_identical(B, h, w, cs, c_off, oh, ow):
+    # main:806 reads the unstable frame (channels 24:27) straight out of the 27-channel stack: same bits as resizing a copy
+    x = torch.rand(B, h, w, cs, generator=torch.Generator().manual_seed(h * w + cs)).cuda()
+    got = vs.resize_images_slice3(x, c_off, (oh, ow))
+    ref = vs.resize_images(x[..., c_off:c_off + 3].contiguous(), (oh, ow))
+    assert torch.equal(got, ref)
+    assert maxabs(got, vo.resize_bilinear_legacy(x[..., c_off:c_off + 3].cpu(), oh, ow)) <= 1e-6
+
+
+@pytest.mark.parametrize("hn,wn,oh,ow", [(384, 512, 384, 512), (64, 64, 64, 64), (70, 90, 96, 120), (64, 96, 32, 48), (50, 70, 37, 53)])
 def test_flow_glue_vs_oracle(hn, wn, oh, ow):
     pf2 = torch.randn(2, hn - 2, wn - 2, 2) * 5
     out = vs.flow_to_output_res(pf2.cuda(), hn, wn, oh, ow)
