@@ -193,37 +193,27 @@ def main():
         eager_step = step
         step = lambda: (graph.replay(), graph_out)[1]
 
-    for _ in range(args.warmup):
-        step()
-    if gather is not None:
-        gather.drain()
-    torch.cuda.synchronize()
+    from coupe.optical_flow_based_deep_video_stabilization_amd import benchloop
     use_events = not args.no_kernel_events
-    ctx.profile(use_events)
-    runtime.hbm_profile(1 if use_events else 0)     # dispatch-timestamp events around the glue+warp launch too
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
     ev_every = max(1, args.event_every)
     n_event_steps = 0
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if use_events:
+
+    def profilers_on():
+        ctx.profile(use_events)
+        runtime.hbm_profile(1 if use_events else 0)     # dispatch-timestamp events around the glue+warp launch too
+
+    def timed_step(k):
+        nonlocal n_event_steps
+        if use_events and k >= 0:
             on = (k % ev_every == 0)
             ctx.profile_set(on)
             runtime.hbm_profile(2 if on else 0)
             n_event_steps += int(on)
-        out = step()
-    if gather is not None:
-        gather.drain()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return step()
+
+    # W warm-up steps, then exactly K steps between barrier + synchronize pairs; elapsed = max over ranks (benchloop.py)
+    elapsed, out = benchloop.timed_region(timed_step, args.steps, args.warmup, torch.cuda.synchronize, dist=dist,
+                                          drain=gather.drain if gather is not None else None, before_timed=profilers_on)
 
     # ---- roofline of the dominant kernel (implicit-GEMM conv on the fp32 MFMA).  Every conv-like
     # launch is bracketed by HIP events on its own stream inside the C library; launches are grouped
@@ -317,8 +307,7 @@ def main():
             if rank == 0:
                 log(f"{name:<18}{ms_sum / nl:>9.4f} ms  {by / nl / 1e6:>9.1f} MB  {gbs:>8.1f} GB/s  frac {gbs / HBM_PEAK_GBS:.3f} of 8 TB/s")
 
-    samples = world * B * args.steps
-    value = samples / elapsed
+    value = benchloop.aggregate_value(B, world, args.steps, elapsed)
     res = {
         "metric": f"stabilised frame-pairs/sec @{H}x{W}",
         "value": round(value, 2),

@@ -120,3 +120,51 @@ def test_grad_bucket_without_process_group_is_a_noop():
     assert b.allreduce_range_start(0, 6) is None
     vd.GradBucket.allreduce_finish([None])
     assert b.span("x", "x") == (0, b.flat.numel())
+
+
+def _bench_worker(rank, world, port, q):
+    """The timed region of bench.py (benchloop.timed_region) under a 2-rank gloo group: a slow rank sets the elapsed time
+    for everyone, every rank runs exactly K timed steps after W warm-ups, and the overlapped gatherer is drained inside."""
+    import time
+    from coupe.optical_flow_based_deep_video_stabilization_amd import benchloop
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = vd.FrameGatherer((2, 4, 4, 3), world, "cpu", dtype=torch.uint8)
+        calls = []
+
+        def step(k):
+            calls.append(k)
+            time.sleep(0.002 * (1 + 4 * rank))                  # rank 1 is 5x slower
+            g.submit(torch.full((2, 4, 4, 3), rank * 16 + (k & 7), dtype=torch.uint8))
+            return k
+
+        flags = []
+        elapsed, last = benchloop.timed_region(step, steps=6, warmup=2, sync=lambda: None, dist=dist, drain=g.drain,
+                                               before_timed=lambda: flags.append(len(calls)), device="cpu")
+        ok = calls == [-1, -1, 0, 1, 2, 3, 4, 5] and flags == [2] and last == 5
+        ok = ok and elapsed >= 6 * 0.002 * (1 + 4 * (world - 1)) * 0.9      # the slowest rank's time, on every rank
+        ok = ok and all(p is None for p in g.pending)                        # drained
+        r = g.result((g.count - 1) % g.depth).view(world, 2, 4, 4, 3)
+        ok = ok and all(int(r[k].max()) == k * 16 + 5 for k in range(world))
+        val = benchloop.aggregate_value(8, world, 6, elapsed)
+        q.put((rank, bool(ok), round(elapsed, 4), val))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_timed_region_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[:2] for r in res] == [(0, True), (1, True)]
+    assert res[0][2] == res[1][2]                               # both ranks report the same (max) elapsed time
+    assert abs(res[0][3] - 2 * 8 * 6 / res[0][2]) <= 2e-3 * res[0][3]   # whole-job units / slowest rank's time (elapsed was rounded)
