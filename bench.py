@@ -171,12 +171,20 @@ def main():
 
     nstep = [0]
 
+    dbg = [] if os.environ.get("VSTAB_BENCH_DEBUG") else None
+
     def step():
+        t0 = time.perf_counter()
         flows, outflow, warped = vs.stabilise_originalsize(feats, frame)
+        t1 = time.perf_counter()
         if vgg is not None:
             vgg.build(vvgg.preprocess(warped))
         if gather is not None:
-            gather.submit(quantise(warped) if quantise is not None else warped)
+            q = quantise(warped) if quantise is not None else warped
+            t2 = time.perf_counter()
+            gather.submit(q)
+            if dbg is not None:
+                dbg.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
         nstep[0] += 1
         return flows, outflow, warped
 
@@ -214,6 +222,10 @@ def main():
     # W warm-up steps, then exactly K steps between barrier + synchronize pairs; elapsed = max over ranks (benchloop.py)
     elapsed, out = benchloop.timed_region(timed_step, args.steps, args.warmup, torch.cuda.synchronize, dist=dist,
                                           drain=gather.drain if gather is not None else None, before_timed=profilers_on)
+
+    if dbg:
+        for i, r in enumerate(dbg[-args.steps:]):
+            log(f"step {i:3d} host ms: path {r[0] * 1e3:7.3f}  quantise {r[1] * 1e3:7.3f}  submit {r[2] * 1e3:7.3f}")
 
     # ---- roofline of the dominant kernel (implicit-GEMM conv on the fp32 MFMA).  Every conv-like
     # launch is bracketed by HIP events on its own stream inside the C library; launches are grouped
