@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--cin", type=int, default=27)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of warped frames (N>1)")
+    ap.add_argument("--gather-schedule", choices=("allgather", "direct"), default="allgather",
+                    help="reassembly over RCCL: one all-gather per step, or world-1 point-to-point pushes per rank (all xGMI links at once)")
     ap.add_argument("--gather-fp32", action="store_true",
                     help="all-gather the fp32 warped frames instead of the uint8 video frames the reference writes (main:630)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
@@ -152,7 +154,7 @@ def main():
     gather = None
     if (world > 1 or force_dist) and not args.no_gather:
         gather = vdist.FrameGatherer((B, H, W, 3), world, torch.device("cuda", local_rank),
-                                     dtype=torch.float32 if args.gather_fp32 else torch.uint8)
+                                     dtype=torch.float32 if args.gather_fp32 else torch.uint8, schedule=args.gather_schedule)
     quantise = None
     if gather is not None and not args.gather_fp32:
         import ctypes as C
@@ -337,7 +339,7 @@ def main():
                                f"(5 flows) + flow resize/scale + tf_warp at {H}x{W}",
                    "batch_per_gpu": B, "height": H, "width": W, "cin": Cin,
                    "gflop_per_sample": round(netspec.gflop_per_sample(H, W, Cin), 2),
-                   "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL") if gather is not None else False,
+                   "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL, schedule " + args.gather_schedule) if gather is not None else False,
                    "vgg16_trunk": bool(args.vgg16)},
         "roofline": roofline,
         "roofline_hbm": roofline_hbm,

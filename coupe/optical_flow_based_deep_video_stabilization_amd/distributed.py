@@ -48,13 +48,32 @@ def gather_sequence(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     return torch.cat([out[r, :sizes[r]] for r in range(world)])
 
 
+class _Works:
+    """A list of point-to-point requests waited for as one."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class FrameGatherer:
     """Overlapped reassembly for a stream of equally sized per-rank batches: submit() starts an
     asynchronous all-gather of this step's frames into one of `depth` rotating buffers and
     returns at once; the collective runs beside the next step's kernels.  result(k) / drain()
     wait.  Buffers: [world, *shape]; rank r's frames land at index r (block partition)."""
 
-    def __init__(self, shape, world: int, device, dtype=torch.float32, depth: int = 2, group=None):
+    def __init__(self, shape, world: int, device, dtype=torch.float32, depth: int = 2, group=None, schedule: str = "allgather"):
+        """schedule = "allgather": one `all_gather_into_tensor` per step (RCCL picks ring / direct itself).
+        schedule = "direct": every rank pushes its frames straight to each of its world-1 peers with point-to-point sends and
+        posts the matching receives into its own gather buffer (`batch_isend_irecv`) -- on a fully connected xGMI hive the
+        world-1 transfers of a rank use world-1 different links at once, where a ring moves (world-1)/world of the data over ONE
+        link per rank (~140 ms vs ~20 ms for cfg3's 3.1 GB per rank).  Same result, bit for bit."""
+        if schedule not in ("allgather", "direct"):
+            raise ValueError("schedule must be 'allgather' or 'direct'")
+        self.schedule = schedule
         self.world, self.depth, self.group = world, depth, group
         self.bufs = [torch.empty((world,) + tuple(shape), dtype=dtype, device=device) for _ in range(depth)]
         self.pending: List[Optional[tuple]] = [None] * depth
@@ -71,8 +90,18 @@ class FrameGatherer:
         slot = self.count % self.depth
         self._wait(slot)
         buf = self.bufs[slot]
-        work = dist.all_gather_into_tensor(buf.view((-1,) + tuple(buf.shape[2:])), frames.contiguous(),
-                                           group=self.group, async_op=True)
+        frames = frames.contiguous()
+        if self.schedule == "direct" and self.world > 1:
+            rank = dist.get_rank(self.group)
+            buf[rank].copy_(frames)                  # own shard: a local copy on the current stream
+            ops = []
+            for d in range(1, self.world):           # peer order staggered by rank so that no two ranks start on the same target
+                dst, src = (rank + d) % self.world, (rank - d) % self.world
+                ops.append(dist.P2POp(dist.isend, frames, dst, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[src], src, group=self.group))
+            work = _Works(dist.batch_isend_irecv(ops))
+        else:
+            work = dist.all_gather_into_tensor(buf.view((-1,) + tuple(buf.shape[2:])), frames, group=self.group, async_op=True)
         self.pending[slot] = (work, frames)          # keep `frames` alive until the collective is done
         self.count += 1
         return slot

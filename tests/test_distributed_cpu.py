@@ -168,3 +168,39 @@ def test_bench_timed_region_two_ranks():
     assert [r[:2] for r in res] == [(0, True), (1, True)]
     assert res[0][2] == res[1][2]                               # both ranks report the same (max) elapsed time
     assert abs(res[0][3] - 2 * 8 * 6 / res[0][2]) <= 2e-3 * res[0][3]   # whole-job units / slowest rank's time (elapsed was rounded)
+
+
+def _direct_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        ga = vd.FrameGatherer((3, 5, 7, 3), world, "cpu", dtype=torch.uint8, schedule="allgather")
+        gd = vd.FrameGatherer((3, 5, 7, 3), world, "cpu", dtype=torch.uint8, schedule="direct")
+        for step in range(4):                                   # more steps than buffers: slots are reused
+            fr = torch.randint(0, 256, (3, 5, 7, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(100 * step + rank))
+            sa, sd = ga.submit(fr), gd.submit(fr.clone())
+            ra, rd = ga.result(sa).clone(), gd.result(sd).clone()
+            ok = ok and torch.equal(ra, rd)
+            for r in range(world):                              # rank r's frames sit at index r
+                exp = torch.randint(0, 256, (3, 5, 7, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(100 * step + r))
+                ok = ok and torch.equal(rd.view(world, 3, 5, 7, 3)[r], exp)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_peer_schedule_equals_allgather(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]
