@@ -1,0 +1,47 @@
+"""Randomised input sizes for the whole network (hypothesis): every drawn (B, H, W, C_in) the size rule of SURVEY.md 8a-note-1
+admits must give the five flows within 1e-3 of the fp64 oracle and the fused glue + warp bit-identical to the fp32 oracle on the
+GPU's own flow -- odd level sizes, widths that are not multiples of the kernels' tiles (row-window tiles of 64 / 128 pixels, 16x64
+predict_flow2 tiles, 16x32 warp tiles), one-sample launches (64-pixel first-layer tiles) and C_in = 6."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, assume, given, settings, strategies as st
+
+import coupe.optical_flow_based_deep_video_stabilization_amd as vs
+from coupe.optical_flow_based_deep_video_stabilization_amd import netspec, runtime, weights as wts
+from oracle import vstab_oracle as vo
+
+pytestmark = pytest.mark.gpu
+_W = {}
+
+
+def _weights(cin, rb):
+    key = (cin, rb)
+    if key not in _W:
+        _W[key] = wts.synthetic_weights(seed=21 + cin, cin=cin, random_bn=rb, flow_gain=1.5)
+    return _W[key]
+
+
+@settings(max_examples=14, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
+@given(B=st.integers(1, 3), H=st.integers(33, 150), W=st.integers(33, 200), cin=st.sampled_from([27, 27, 6]),
+       rb=st.booleans(), oh=st.integers(20, 160), ow=st.integers(20, 220), seed=st.integers(0, 2**16))
+def test_network_any_admissible_size(B, H, W, cin, rb, oh, ow, seed):
+    try:
+        netspec.sizes_for(H, W)
+    except ValueError:
+        assume(False)
+    w = _weights(cin, rb)
+    runtime.reset()
+    vs.assign_weights(w)
+    rng = np.random.default_rng(seed)
+    feats = rng.random((B, H, W, cin), dtype=np.float32)
+    frame = rng.random((B, oh, ow, 3), dtype=np.float32)
+    flows, outflow, warped = vs.stabilise_originalsize(torch.from_numpy(feats).cuda(), torch.from_numpy(frame).cuda())
+    torch.cuda.synchronize()
+    ref = vo.flownetS_pyramid(feats, w, torch.float64)
+    for k in vo.FLOW_KEYS:
+        err = float((flows[k].double().cpu() - ref[k]).abs().max())
+        assert err <= 1e-3, (k, err, (B, H, W, cin))
+    of_ref = vo.flow_to_output_res(flows["predict_flow2"].cpu(), H, W, oh, ow)
+    assert float((outflow.cpu() - of_ref.float()).abs().max()) <= 2e-5 * max(1.0, float(of_ref.abs().max()))
+    assert torch.equal(warped.cpu(), vo.tf_warp(torch.from_numpy(frame), outflow.cpu(), oh, ow, torch.float32))
