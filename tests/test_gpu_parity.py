@@ -100,10 +100,11 @@ def test_get_pixel_value():
 
 @pytest.mark.parametrize("h,w,oh,ow", [(6, 8, 12, 16), (24, 32, 48, 64), (48, 64, 382, 510), (17, 30, 34, 60), (12, 12, 12, 12), (40, 40, 20, 13)])
 def test_resize_images_vs_oracle(h, w, oh, ow):
-    x = torch.rand(2, h, w, 3)
-    out = vs.resize_images(x.cuda(), (oh, ow))
-    ref = vo.resize_bilinear_legacy(x, oh, ow)
-    assert maxabs(out, ref) <= 1e-6
+    for C in (3, 2, 5):                      # 3 channels: the tiled kernel; other counts: the one-element-per-thread kernel
+        x = torch.rand(2, h, w, C)
+        out = vs.resize_images(x.cuda(), (oh, ow))
+        ref = vo.resize_bilinear_legacy(x, oh, ow)
+        assert maxabs(out, ref) <= 1e-6, C
 
 
 @pytest.mark.parametrize("B,h,w,cs,c_off,oh,ow", [(2, 64, 96, 27, 24, 62, 94), (1, 48, 64, 27, 24, 46, 62), (3, 33, 41, 6, 3, 70, 52),
@@ -117,7 +118,8 @@ def test_resize_slice3_in_place_bit_identical(B, h, w, cs, c_off, oh, ow):
     assert maxabs(got, vo.resize_bilinear_legacy(x[..., c_off:c_off + 3].cpu(), oh, ow)) <= 1e-6
 
 
-@pytest.mark.parametrize("hn,wn,oh,ow", [(384, 512, 384, 512), (64, 64, 64, 64), (70, 90, 96, 120), (64, 96, 32, 48), (50, 70, 37, 53)])
+@pytest.mark.parametrize("hn,wn,oh,ow", [(384, 512, 384, 512), (64, 64, 64, 64), (70, 90, 96, 120), (64, 96, 32, 48), (50, 70, 37, 53),
+                                         (12, 3, 9, 5)])      # a one-column flow: the tiled kernel's paired taps do not apply
 def test_flow_glue_vs_oracle(hn, wn, oh, ow):
     pf2 = torch.randn(2, hn - 2, wn - 2, 2) * 5
     out = vs.flow_to_output_res(pf2.cuda(), hn, wn, oh, ow)
@@ -233,3 +235,46 @@ def test_errors_through_the_abi():
         vs.flownetS_pyramid(torch.zeros(1, 2, 2, 27, device="cuda"), 1)       # too small
     with pytest.raises(ValueError):
         vs.tf_warp(torch.zeros(1, 4, 4, 3, device="cuda"), torch.zeros(1, 4, 5, 2, device="cuda"), 4, 4)
+
+
+# ------------------------------------------------------------------------- predict_flow2 gather (K9 / F8) on its own
+def _pf2_reference(T, bias2, pf3, H, W):
+    """pf2[y,x,o] = b[o] + sum_{dy,dx} T[ny(y+dy)-1, nx(x+dx)-1][3dy+dx][o] over the in-image taps, then eight sequential adds of
+    the legacy-bilinear upsampled pf3 (model.py:882-887; index map SURVEY.md A.4), in fp32 and in the kernel's order."""
+    B, h2, w2, _ = T.shape
+    iy = vo.nearest_align_corners_index(h2 + 2, H) - 1
+    ix = vo.nearest_align_corners_index(w2 + 2, W) - 1
+    oh, ow = H - 2, W - 2
+    acc = torch.from_numpy(np.asarray(bias2, np.float32)).view(1, 1, 1, 2).expand(B, oh, ow, 2).clone()
+    Tp = torch.zeros(B, h2 + 2, w2 + 2, 32)
+    Tp[:, 1:-1, 1:-1] = T                                      # zero ring: a skipped tap adds +0.0
+    for dy in range(3):
+        for dx in range(3):
+            ys = torch.from_numpy(iy[dy:dy + oh] + 1)
+            xs = torch.from_numpy(ix[dx:dx + ow] + 1)
+            t = Tp[:, ys][:, :, xs][..., (3 * dy + dx) * 2:(3 * dy + dx) * 2 + 2]
+            acc = acc + t
+    up = vo.resize_bilinear_legacy(pf3, oh, ow)
+    for _ in range(8):
+        acc = acc + up
+    return acc
+
+
+@pytest.mark.parametrize("B,h2,w2,H,W", [(2, 24, 32, 96, 128),        # the network's own geometry: LDS-staged window per 16x64 tile
+                                         (1, 13, 17, 50, 66),         # odd sizes, ragged tiles
+                                         (1, 64, 64, 34, 34),         # downsampling head: the tile's window exceeds the LDS budget ->
+                                         (2, 40, 90, 20, 70)])        # ... the direct-gather kernel runs instead
+def test_pf2_gather_tiled_and_direct_kernels(B, h2, w2, H, W):
+    import ctypes as C
+    from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
+    g = torch.Generator().manual_seed(h2 * 100 + W)
+    T = torch.randn(B, h2, w2, 32, generator=g)
+    h3, w3 = (h2 + 1) // 2, (w2 + 1) // 2
+    pf3 = torch.randn(B, h3, w3, 2, generator=g) * 3
+    bias2 = torch.tensor([0.25, -0.5])
+    out = torch.empty(B, H - 2, W - 2, 2, device="cuda")
+    Td, pd, bd = T.cuda(), pf3.cuda(), bias2.cuda()
+    _lib.check(_lib.lib().vstab_pf2_from_taps(Td.data_ptr(), B, h2, w2, bd.data_ptr(), pd.data_ptr(), h3, w3, out.data_ptr(), H, W,
+                                              runtime.stream_ptr()))
+    ref = _pf2_reference(T, bias2.numpy(), pf3, H, W)
+    assert maxabs(out, ref) <= 1e-5 * max(1.0, float(ref.abs().max()))
