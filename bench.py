@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of warped frames (N>1)")
     ap.add_argument("--gather-schedule", choices=("allgather", "direct"), default="allgather",
                     help="reassembly over RCCL: one all-gather per step, or world-1 point-to-point pushes per rank (all xGMI links at once)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend; gloo (frames gathered through host memory, ranks may share one GPU) only rehearses the "
+                         "N>1 control flow on a one-GPU box -- its numbers mean nothing")
     ap.add_argument("--gather-fp32", action="store_true",
                     help="all-gather the fp32 warped frames instead of the uint8 video frames the reference writes (main:630)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
@@ -130,13 +133,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())       # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("VSTAB_FORCE_DIST") == "1"      # rehearse the RCCL path with one rank
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import coupe.optical_flow_based_deep_video_stabilization_amd as vs
     from coupe.optical_flow_based_deep_video_stabilization_amd import runtime, netspec
@@ -153,7 +161,7 @@ def main():
 
     gather = None
     if (world > 1 or force_dist) and not args.no_gather:
-        gather = vdist.FrameGatherer((B, H, W, 3), world, torch.device("cuda", local_rank),
+        gather = vdist.FrameGatherer((B, H, W, 3), world, torch.device("cpu") if args.backend == "gloo" else torch.device("cuda", local_rank),
                                      dtype=torch.float32 if args.gather_fp32 else torch.uint8, schedule=args.gather_schedule)
     quantise = None
     if gather is not None and not args.gather_fp32:
@@ -184,7 +192,7 @@ def main():
         if gather is not None:
             q = quantise(warped) if quantise is not None else warped
             t2 = time.perf_counter()
-            gather.submit(q)
+            gather.submit(q.cpu() if args.backend == "gloo" else q)
             if dbg is not None:
                 dbg.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
         nstep[0] += 1
@@ -223,7 +231,8 @@ def main():
 
     # W warm-up steps, then exactly K steps between barrier + synchronize pairs; elapsed = max over ranks (benchloop.py)
     elapsed, out = benchloop.timed_region(timed_step, args.steps, args.warmup, torch.cuda.synchronize, dist=dist,
-                                          drain=gather.drain if gather is not None else None, before_timed=profilers_on)
+                                          drain=gather.drain if gather is not None else None, before_timed=profilers_on,
+                                          device="cpu" if args.backend == "gloo" else "cuda")
 
     if dbg:
         for i, r in enumerate(dbg[-args.steps:]):

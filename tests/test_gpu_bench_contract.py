@@ -31,3 +31,19 @@ def test_bench_prints_one_contract_line():
     assert rh["bound"] == "hbm" and rh["unit"] == "GB/s" and rh["peak"] == 8000.0 and abs(rh["frac"] - rh["achieved"] / rh["peak"]) < 1e-3
     assert 0.1 < rh["frac"] < 1.0 and rh["entry_point"] == "vstab_flow_glue_warp" and rh["launches"] >= 1
     assert abs(rh["alg_bytes_per_output_pixel"] - 40.0) < 0.2
+
+
+def test_bench_self_launches_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` without a launcher: the parent starts two ranks as a child job, they run the HIP path side by
+    side (sharing this box's one GPU, frames reassembled through gloo / host memory: --backend gloo is a control-flow rehearsal,
+    its throughput means nothing) and rank 0 alone prints the line, with the whole job's aggregate."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--batch", "2", "--height", "128", "--width", "128"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "self-launch:" in r.stderr and "--nproc-per-node=2" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3          # both ranks' samples / max-over-ranks time
+    assert "schedule allgather" in d["config"]["all_gather"]
