@@ -378,7 +378,11 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         p.Ho = p.Hi; p.Wo = p.Wi; p.Cs_out = 32; p.c_off = 0;
         p.N = 32; p.Npad = 32; p.act = 0; p.nphase = 1; p.ksplit = 1;
         p.ph[0].Hg = p.Hi; p.ph[0].Wg = p.Wi; p.ph[0].M = B * p.Hi * p.Wi; p.Mmax = p.ph[0].M;
-        pl.tile[14] = TILE_128x32; pl.vec4[14] = true;
+        // 256-row tiles while they still fill the chip once (B=8 512^2: 512 workgroups, two per CU: 42 -> 36 us); more rows per
+        // workgroup amortise the 7-K-tile loop's prologue.  Larger launches keep 128 rows (four workgroups per CU: B=16 1080p
+        // 516 vs 542 us), smaller ones would leave CUs idle
+        const long long t256 = ((long long)B * pl.eh[1] * pl.ew[1] + 255) / 256;
+        pl.tile[14] = (t256 >= 256 && t256 <= 640) ? TILE_256x32 : TILE_128x32; pl.vec4[14] = true;
         set_ranges(p);
     }
     // ---- predict6..3 tap tables: 1x1 conv of the level's (concat) tensor -> 18 (pad 32) columns
@@ -858,7 +862,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
 
 static std::string conv_kernel_name(ConvTile t, bool vec4)
 {
-    const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : (t == TILE_64x128 ? "64, 128, 1, 4" : (t == TILE_64x64 ? "64, 64, 2, 2" : "128, 32, 4, 1")));
+    const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : (t == TILE_64x128 ? "64, 128, 1, 4" : (t == TILE_64x64 ? "64, 64, 2, 2" : (t == TILE_256x32 ? "256, 32, 4, 1" : "128, 32, 4, 1"))));
     const bool dma = conv_uses_lds_dma(t, vec4);
     return std::string("conv_mfma_kernel<") + shape + (vec4 ? ", true" : ", false") + (dma ? ", true>" : ", false>");
 }

@@ -501,6 +501,7 @@ hipError_t conv_set_attributes()
     VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, true, true>), 128, 64)
     VSTAB_SET((conv_mfma_kernel<128, 32, 4, 1, true, true>), 128, 32)
     VSTAB_SET((conv_mfma_kernel<64, 128, 1, 4, true, true>), 64, 128)
+    VSTAB_SET((conv_mfma_kernel<256, 32, 4, 1, true, true>), 256, 32)
 #ifdef VSTAB_HARNESS
     VSTAB_SET((conv_mfma_kernel<64, 64, 2, 2, true, true>), 64, 64)
 #endif
@@ -533,7 +534,7 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
 #else
     p.no_remap = 0;
 #endif
-    const int BM = (tile == TILE_64x128 || tile == TILE_64x64) ? 64 : 128;
+    const int BM = (tile == TILE_64x128 || tile == TILE_64x64) ? 64 : (tile == TILE_256x32 ? 256 : 128);
     const int BN = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : ((tile == TILE_128x64 || tile == TILE_64x64) ? 64 : 32);
     if (p.in_bytes >= 0x80000000u || p.w_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.Npad % BN != 0 || p.SEGP % 32 != 0 || p.SEGP < p.SEG || p.NSEG < 1 || p.ksplit < 1 || p.nphase < 1 || p.nphase > 16)
@@ -560,6 +561,8 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
         VSTAB_LAUNCH((conv_mfma_kernel<128, 32, 4, 1, true, true>), (conv_lds_bytes<128, 32>()));
     else if (tile == TILE_64x128 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<64, 128, 1, 4, true, true>), (conv_lds_bytes<64, 128>()));
+    else if (tile == TILE_256x32 && vec4)
+        VSTAB_LAUNCH((conv_mfma_kernel<256, 32, 4, 1, true, true>), (conv_lds_bytes<256, 32>()));
 #ifdef VSTAB_HARNESS      // measured for one-sample launches (scripts/sweep_b1.sh: 3-8 % per layer), not worth a fifth product instantiation
     else if (tile == TILE_64x64 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<64, 64, 2, 2, true, true>), (conv_lds_bytes<64, 64>()));

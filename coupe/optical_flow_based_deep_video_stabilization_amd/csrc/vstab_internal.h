@@ -94,7 +94,7 @@ struct ConvParams {
     ConvPhase ph[16];       // 4 transposed-conv phases, or the 16 positions of a Winograd-domain GEMM
 };
 
-enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 = 3, TILE_64x64 = 4 };
+enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 = 3, TILE_64x64 = 4, TILE_256x32 = 5 };
 
 // Launch the implicit-GEMM kernel (and the split-K combine when p.ksplit > 1).
 // ev_start/ev_stop (optional) are recorded immediately around the GEMM kernel itself.
