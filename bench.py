@@ -303,6 +303,7 @@ def main():
     if use_events:
         runtime.hbm_profile(0)
         hp = runtime.hbm_profile_read()
+        pf2_row = hp.pop("pf2_gather", None)
         name = max(hp, key=lambda k: hp[k][0])
         ms_sum, nl, by = hp[name]
         if nl > 0 and ms_sum > 0:
@@ -327,6 +328,12 @@ def main():
                             "alg_bytes_per_output_pixel": round(by / nl / (B * H * W), 2),
                             "note": "limit is the L1 tag pipe (12-byte gathers), not HBM: profiles/README.md, r02 warp study; "
                                     "flows of a random-weight network on noise frames move neighbouring sample points ~0.6 px apart per pixel"}
+            if pf2_row and pf2_row[1] > 0 and pf2_row[0] > 0:        # K9: LDS / L2-bound gather; its compulsory bytes against the same peak
+                pms, pn, pby = pf2_row
+                pg = pby / (pms * 1e-3) / 1e9
+                roofline_hbm["other_rows"] = [{"row": "K9 predict_flow2 gather (pf2_tile_kernel; not HBM-bound: nine LDS taps per pixel)",
+                                               "launches": pn, "avg_launch_us": round(pms / pn * 1e3, 2), "alg_bytes_per_launch": pby / pn,
+                                               "achieved": round(pg, 1), "unit": "GB/s", "frac": round(pg / HBM_PEAK_GBS, 4)}]
             if rank == 0:
                 log(f"{name:<18}{ms_sum / nl:>9.4f} ms  {by / nl / 1e6:>9.1f} MB  {gbs:>8.1f} GB/s  frac {gbs / HBM_PEAK_GBS:.3f} of 8 TB/s")
 

@@ -369,14 +369,14 @@ hipError_t launch_pf2(const float *T, int B, int h2, int w2, const float *bias2,
         rows_max = std::max(rows_max, nearest_ac_host(std::min(t * PF2_TH + PF2_TH - 1, oh - 1) + 2, nsy, h2 + 2) - nearest_ac_host(t * PF2_TH, nsy, h2 + 2) + 1);
     for (int t = 0; t < tiles_x; ++t)
         cols_max = std::max(cols_max, nearest_ac_host(std::min(t * PF2_TW + PF2_TW - 1, ow - 1) + 2, nsx, w2 + 2) - nearest_ac_host(t * PF2_TW, nsx, w2 + 2) + 1);
-    if (rows_max * cols_max <= PF2_CAP && (long long)tiles_x * tiles_y * B < (1ll << 31)) {
-        pf2_tile_kernel<<<dim3((unsigned)(tiles_x * tiles_y * B)), dim3(256), 0, stream>>>(T, B, h2, w2, bias2, pf3, h3, w3, pf2, H, W, nsy, nsx,
-                                                                                        usy, usx, tiles_x, tiles_y);
-        return hipGetLastError();
-    }
-    pf2_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(T, B, h2, w2, bias2, pf3, h3, w3, pf2, H, W,
-                                                                             nsy, nsx, usy, usx);
-    return hipGetLastError();
+    // compulsory traffic (K9 is LDS / L2-bound, reported against the HBM bound of these bytes): the 128-byte table rows
+    // and the coarser flow read once, 8 bytes written per output pixel
+    const double alg_bytes = 128.0 * B * h2 * w2 + 8.0 * B * h3 * w3 + 8.0 * total;
+    if (rows_max * cols_max <= PF2_CAP && (long long)tiles_x * tiles_y * B < (1ll << 31))
+        return launch_timed(HBM_SLOT_PF2, alg_bytes, pf2_tile_kernel, dim3((unsigned)(tiles_x * tiles_y * B)), dim3(256), stream, T, B, h2, w2,
+                            bias2, pf3, h3, w3, pf2, H, W, nsy, nsx, usy, usx, tiles_x, tiles_y);
+    return launch_timed(HBM_SLOT_PF2, alg_bytes, pf2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, T, B, h2, w2, bias2, pf3,
+                        h3, w3, pf2, H, W, nsy, nsx, usy, usx);
 }
 
 // ---------------------------------------------------------------------------------

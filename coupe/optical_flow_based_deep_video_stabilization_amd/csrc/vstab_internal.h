@@ -180,7 +180,7 @@ hipError_t launch_resize_bilinear_slice3(const float *x, int B, int h, int w, in
 hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W,
                             int C, hipStream_t stream);
 // per-launch timing of the HBM-side kernels (flow_ops.hip): slots of vstab_hbm_profile_read
-enum { HBM_SLOT_WARP = 0, HBM_SLOT_GLUE = 1, HBM_SLOT_GLUE_WARP = 2, HBM_SLOTS = 3 };
+enum { HBM_SLOT_WARP = 0, HBM_SLOT_GLUE = 1, HBM_SLOT_GLUE_WARP = 2, HBM_SLOT_PF2 = 3, HBM_SLOTS = 4 };
 void hbm_profile_enable(int mode);
 hipError_t hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg_bytes_sum);
 hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *out, int oh, int ow,

@@ -155,7 +155,8 @@ VSTAB_API int vstab_trace_ranges(int on);
 
 /* ---- instrumentation of the HBM-side kernels (tf_warp, the flow glue, the fused launch): with profiling on every such launch
  * is bracketed by dispatch-timestamp events on its own stream.  Process-wide; switching it on clears earlier records.
- * Slots: 0 = vstab_warp_flow, 1 = vstab_flow_resize_scale, 2 = vstab_flow_glue_warp.  Read after synchronising the stream(s):
+ * Slots: 0 = vstab_warp_flow, 1 = vstab_flow_resize_scale, 2 = vstab_flow_glue_warp, 3 = the predict_flow2 gather inside
+ * vstab_flownets_forward / vstab_pf2_from_taps (128 B per tap-table row + 8 B per coarser-flow and output pixel).  Read after synchronising the stream(s):
  * summed kernel milliseconds, number of launches, summed ALGORITHMIC bytes (warp 32 B/px; glue 8 B per source +
  * 8 B per output pixel; fused 8 B per source pixel + 32 (flow written) or 24 B per output pixel). */
 VSTAB_API int vstab_hbm_profile_enable(int mode);   /* 0 = off (records kept), 1 = clear + on, 2 = on again (records kept) */

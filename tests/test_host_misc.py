@@ -93,5 +93,5 @@ def test_instrumentation_entry_points_without_gpu():
     ms, n, by = C.c_double(-1), C.c_int(-1), C.c_double(-1)
     assert L.vstab_hbm_profile_read(2, C.byref(ms), C.byref(n), C.byref(by)) == 0
     assert (ms.value, n.value, by.value) == (0.0, 0, 0.0)
-    assert L.vstab_hbm_profile_read(7, C.byref(ms), C.byref(n), C.byref(by)) < 0
+    assert L.vstab_hbm_profile_read(3, C.byref(ms), C.byref(n), C.byref(by)) == 0 and L.vstab_hbm_profile_read(7, C.byref(ms), C.byref(n), C.byref(by)) < 0
     assert L.vstab_hbm_profile_enable(5) < 0
