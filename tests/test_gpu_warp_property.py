@@ -25,7 +25,7 @@ def _flow(rng, B, H, W, scale):
     return f
 
 
-@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 @given(B=st.integers(1, 3), H=st.integers(1, 70), W=st.integers(1, 150), scale=st.sampled_from([0.3, 3.0, 40.0]), seed=st.integers(0, 2**16))
 def test_warp_any_shape_bit_exact(B, H, W, scale, seed):
     rng = np.random.default_rng(seed)
@@ -35,7 +35,7 @@ def test_warp_any_shape_bit_exact(B, H, W, scale, seed):
     assert torch.equal(out.cpu(), vo.tf_warp(img, flow, H, W, torch.float32))
 
 
-@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 @given(B=st.integers(1, 2), hn=st.integers(6, 60), wn=st.integers(6, 90), oh=st.integers(1, 70), ow=st.integers(1, 130),
        scale=st.sampled_from([0.5, 6.0]), seed=st.integers(0, 2**16))
 def test_fused_glue_warp_any_shape(B, hn, wn, oh, ow, scale, seed):
