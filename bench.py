@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend; gloo (frames gathered through host memory, ranks may share one GPU) only rehearses the "
                          "N>1 control flow on a one-GPU box -- its numbers mean nothing")
+    ap.add_argument("--gather-every", type=int, default=4,
+                    help="uint8 reassembly: stage this many steps' frames and gather them with ONE collective (fewer, larger collectives; "
+                         "the same bytes, all of them inside the timed region)")
     ap.add_argument("--gather-fp32", action="store_true",
                     help="all-gather the fp32 warped frames instead of the uint8 video frames the reference writes (main:630)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
@@ -160,19 +163,49 @@ def main():
         runtime.trace_ranges(True)
 
     gather = None
+    G = max(1, args.gather_every) if not args.gather_fp32 else 1       # steps per collective
+    gdev = torch.device("cpu") if args.backend == "gloo" else torch.device("cuda", local_rank)
+    gdtype = torch.float32 if args.gather_fp32 else torch.uint8
     if (world > 1 or force_dist) and not args.no_gather:
-        gather = vdist.FrameGatherer((B, H, W, 3), world, torch.device("cpu") if args.backend == "gloo" else torch.device("cuda", local_rank),
-                                     dtype=torch.float32 if args.gather_fp32 else torch.uint8, schedule=args.gather_schedule)
+        gather = vdist.FrameGatherer((G * B, H, W, 3), world, gdev, dtype=gdtype, schedule=args.gather_schedule)
     quantise = None
+    group = {"g": 0, "slot": 0, "tails": {}}          # steps staged in the current group, its staging slot, gatherers for short tails
     if gather is not None and not args.gather_fp32:
         import ctypes as C
         from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
-        u8 = [torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        u8 = [torch.empty((G, B, H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
 
         def quantise(warped):           # np.uint8(cvtColor(warped*255)) as the reference's writer does (main:625,630)
-            slot = gather.reserve()     # the collective that last read u8[slot] has completed
-            _lib.check(_lib.lib().vstab_quantise_output(warped.data_ptr(), B * H * W, u8[slot].data_ptr(), runtime.stream_ptr()))
-            return u8[slot]
+            if group["g"] == 0:
+                group["slot"] = gather.reserve()     # the collective that last read this staging buffer has completed
+            dst = u8[group["slot"]][group["g"]]
+            _lib.check(_lib.lib().vstab_quantise_output(warped.data_ptr(), B * H * W, dst.data_ptr(), runtime.stream_ptr()))
+            return dst
+
+    def submit_group(frames_of_step):
+        """Stage one step's frames; every G-th step starts ONE all-gather of the whole group (overlapped with the next steps)."""
+        if quantise is None:                          # fp32 frames: one collective per step
+            gather.submit(frames_of_step.cpu() if args.backend == "gloo" else frames_of_step)
+            return
+        group["g"] += 1
+        if group["g"] == G:
+            buf = u8[group["slot"]].view(G * B, H, W, 3)
+            gather.submit(buf.cpu() if args.backend == "gloo" else buf)
+            group["g"] = 0
+
+    def flush_and_drain():
+        """Gather a group the step count left unfinished (one smaller collective), then wait for everything in flight."""
+        g = group["g"]
+        if gather is not None and quantise is not None and g > 0:
+            tail = group["tails"].get(g)
+            if tail is None:
+                tail = group["tails"][g] = vdist.FrameGatherer((g * B, H, W, 3), world, gdev, dtype=gdtype, schedule=args.gather_schedule)
+            buf = u8[group["slot"]][:g].reshape(g * B, H, W, 3)
+            tail.submit(buf.cpu() if args.backend == "gloo" else buf)
+            tail.drain()
+            group["g"] = 0
+        if gather is not None:
+            gather.drain()
 
     vgg = None
     if args.vgg16:
@@ -192,7 +225,7 @@ def main():
         if gather is not None:
             q = quantise(warped) if quantise is not None else warped
             t2 = time.perf_counter()
-            gather.submit(q.cpu() if args.backend == "gloo" else q)
+            submit_group(q)
             if dbg is not None:
                 dbg.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
         nstep[0] += 1
@@ -231,7 +264,7 @@ def main():
 
     # W warm-up steps, then exactly K steps between barrier + synchronize pairs; elapsed = max over ranks (benchloop.py)
     elapsed, out = benchloop.timed_region(timed_step, args.steps, args.warmup, torch.cuda.synchronize, dist=dist,
-                                          drain=gather.drain if gather is not None else None, before_timed=profilers_on,
+                                          drain=flush_and_drain if gather is not None else None, before_timed=profilers_on,
                                           device="cpu" if args.backend == "gloo" else "cuda")
 
     if dbg:
@@ -355,7 +388,7 @@ def main():
                                f"(5 flows) + flow resize/scale + tf_warp at {H}x{W}",
                    "batch_per_gpu": B, "height": H, "width": W, "cin": Cin,
                    "gflop_per_sample": round(netspec.gflop_per_sample(H, W, Cin), 2),
-                   "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL, schedule " + args.gather_schedule) if gather is not None else False,
+                   "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL, schedule " + args.gather_schedule + f", one collective per {G} step(s)") if gather is not None else False,
                    "vgg16_trunk": bool(args.vgg16)},
         "roofline": roofline,
         "roofline_hbm": roofline_hbm,
