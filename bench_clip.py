@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[3]: an F-frame 1080p synthetic clip sharded across the GPUs of one node,
-reassembled with ONE RCCL all-gather of the stabilised uint8 frames.
+reassembled over RCCL: every finished micro-batch is all-gathered into its place of the full clip while the next one is computed
+(`distributed.SequenceGatherer`).
 
 Teacher-forced: every frame's 27-channel input stack is given (synthetic), so frames are independent
 samples and the clip shards by contiguous blocks (the autoregressive real-video mode does
@@ -65,14 +66,25 @@ def main():
     g = torch.Generator().manual_seed(2000 + rank)
     feats = torch.rand(MB, H, W, Cin, generator=g).cuda()            # one synthetic micro-batch, reused
     frame = torch.rand(MB, H, W, 3, generator=g).cuda()
-    shard = torch.empty((n_local, H, W, 3), dtype=torch.uint8, device="cuda")
     L = _lib.lib()
+    seq = vdist.SequenceGatherer(F_, (H, W, 3), torch.uint8, torch.device("cuda", local_rank)) if use_dist else None
+    shard = torch.empty((n_local, H, W, 3), dtype=torch.uint8, device="cuda")
+    common = seq.common if seq is not None else n_local
 
     def run_shard():
-        for b0 in range(0, n_local, MB):
-            bc = min(MB, n_local - b0)
+        """Micro-batches of this rank's shard through the HIP path; every finished micro-batch of the part all shards have in
+        common is all-gathered into its place of the full clip at once, beside the next micro-batch's kernels."""
+        def compute(b0, bc):
             _, _, warped = vs.stabilise_originalsize(feats[:bc], frame[:bc])
             _lib.check(L.vstab_quantise_output(warped.data_ptr(), bc * H * W, shard[b0:b0 + bc].data_ptr(), runtime.stream_ptr()))
+
+        for b0 in range(0, common, MB):
+            bc = min(MB, common - b0)
+            compute(b0, bc)
+            if seq is not None:
+                seq.submit(shard[b0:b0 + bc], b0)
+        if n_local > common:                    # a block partition gives some ranks one item more: it goes through finish()
+            compute(common, n_local - common)
 
     # warm-up: one micro-batch (kernels loaded, workspaces allocated)
     vs.stabilise_originalsize(feats, frame)
@@ -82,10 +94,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_shard()
+    t_issue = time.perf_counter() - t0
+    full = seq.finish(shard[common:]) if seq is not None else shard
     torch.cuda.synchronize()
-    t_compute = time.perf_counter() - t0
-    full = vdist.gather_sequence(shard, F_) if use_dist else shard
-    torch.cuda.synchronize()
+    t_compute = time.perf_counter() - t0          # compute with the reassembly overlapped; what is left of it shows in `elapsed`
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -99,9 +111,9 @@ def main():
             "metric": f"stabilised frames/sec, {F_}-frame {H}x{W} clip sharded over {world} GPU(s), all-gather reassembly",
             "value": round(F_ / elapsed, 2), "unit": "frames/s", "n_gpus": world, "higher_is_better": True,
             "scaling": "strong", "dtype": "f32", "data": "synthetic, teacher-forced history",
-            "seconds_total": round(elapsed, 4), "seconds_compute": round(t_compute, 4),
-            "seconds_gather": round(elapsed - t_compute, 4),
-            "config": {"workload": f"{F_} frames {H}x{W}x{Cin}, micro-batch {MB}, uint8 frames gathered",
+            "seconds_total": round(elapsed, 4), "seconds_compute_and_overlapped_gather": round(t_compute, 4),
+            "seconds_host_issue": round(t_issue, 4),
+            "config": {"workload": f"{F_} frames {H}x{W}x{Cin}, micro-batch {MB}, uint8 frames all-gathered per micro-batch, overlapped with compute",
                        "gathered_bytes": int(F_) * H * W * 3}}), flush=True)
     if use_dist:
         dist.destroy_process_group()

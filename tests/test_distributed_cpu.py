@@ -204,3 +204,41 @@ def test_direct_peer_schedule_equals_allgather(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(r, True) for r in range(world)]
+
+
+def _seq_worker(rank, world, port, n_total, mb, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = (torch.arange(n_total * 12, dtype=torch.float32).view(n_total, 3, 4) * 0.5).to(torch.uint8)      # "frames"
+        lo, hi = vd.shard_range(n_total, rank, world)
+        sg = vd.SequenceGatherer(n_total, (3, 4), torch.uint8, "cpu")
+        for b0 in range(0, sg.common, mb):                       # micro-batches of the common part, gathered as they finish
+            bc = min(mb, sg.common - b0)
+            sg.submit(full[lo + b0:lo + b0 + bc].clone(), b0)
+        out = sg.finish(full[lo + sg.common:hi].clone())
+        ok = torch.equal(out, full)
+        try:
+            sg.submit(torch.zeros(1, 3, 4, dtype=torch.uint8), sg.common)      # beyond the common part
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,mb", [(2, 9, 2), (3, 10, 3), (2, 8, 8), (3, 2, 4)])
+def test_sequence_gatherer_overlapped_reassembly(world, n_total, mb):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seq_worker, args=(r, world, port, n_total, mb, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]

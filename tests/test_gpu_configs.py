@@ -115,6 +115,13 @@ def test_cfg3_sharded_clip_gather_world1_nccl(nccl_world1):
         assert b - a == MB
         parts.append(_stabilise_u8(feats[a:b], frame[a:b], MB))
     assert torch.equal(torch.cat(parts), whole[:8])
+    # overlapped reassembly (what bench_clip.py does): every micro-batch all-gathered into its place of the full clip as it finishes
+    sg = vdist.SequenceGatherer(F_, (H, W, 3), torch.uint8, torch.device("cuda", 0))
+    assert sg.common == F_
+    for b0 in range(0, F_, MB):
+        bc = min(MB, F_ - b0)
+        sg.submit(whole[b0:b0 + bc], b0)
+    assert torch.equal(sg.finish(), whole)
     # streaming gatherer (what bench.py uses for N > 1): three submits through two rotating buffers
     fg = vdist.FrameGatherer((MB, H, W, 3), 1, torch.device("cuda", 0), dtype=torch.uint8)
     slots = [fg.submit(whole[i:i + MB] if i + MB <= F_ else whole[F_ - MB:F_]) for i in (0, 4, 8)]
