@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--cin", type=int, default=27)
     ap.add_argument("--micro-batch", type=int, default=8)
     ap.add_argument("--gpus", type=int, default=1, help="ranks to start when not already under a launcher")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="gloo: ranks may share one GPU and frames are reassembled through host memory -- a rehearsal of the N>1 control "
+                         "flow (ragged shards, overlapped gather) on a one-GPU box; its numbers mean nothing")
     args = ap.parse_args()
     import importlib.util
     spec = importlib.util.spec_from_file_location(
@@ -48,13 +51,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench_clip.py needs a GPU")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or os.environ.get("VSTAB_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import coupe.optical_flow_based_deep_video_stabilization_amd as vs
     from coupe.optical_flow_based_deep_video_stabilization_amd import _lib, runtime, distributed as vdist
@@ -67,7 +75,8 @@ def main():
     feats = torch.rand(MB, H, W, Cin, generator=g).cuda()            # one synthetic micro-batch, reused
     frame = torch.rand(MB, H, W, 3, generator=g).cuda()
     L = _lib.lib()
-    seq = vdist.SequenceGatherer(F_, (H, W, 3), torch.uint8, torch.device("cuda", local_rank)) if use_dist else None
+    host = args.backend == "gloo"
+    seq = vdist.SequenceGatherer(F_, (H, W, 3), torch.uint8, torch.device("cpu") if host else torch.device("cuda", local_rank)) if use_dist else None
     shard = torch.empty((n_local, H, W, 3), dtype=torch.uint8, device="cuda")
     common = seq.common if seq is not None else n_local
 
@@ -82,7 +91,7 @@ def main():
             bc = min(MB, common - b0)
             compute(b0, bc)
             if seq is not None:
-                seq.submit(shard[b0:b0 + bc], b0)
+                seq.submit(shard[b0:b0 + bc].cpu() if host else shard[b0:b0 + bc], b0)
         if n_local > common:                    # a block partition gives some ranks one item more: it goes through finish()
             compute(common, n_local - common)
 
@@ -95,14 +104,14 @@ def main():
     t0 = time.perf_counter()
     run_shard()
     t_issue = time.perf_counter() - t0
-    full = seq.finish(shard[common:]) if seq is not None else shard
+    full = seq.finish(shard[common:].cpu() if host else shard[common:]) if seq is not None else shard
     torch.cuda.synchronize()
     t_compute = time.perf_counter() - t0          # compute with the reassembly overlapped; what is left of it shows in `elapsed`
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed, t_compute], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, t_compute], dtype=torch.float64, device="cpu" if host else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_compute = float(t[0]), float(t[1])
     assert full.shape[0] == F_

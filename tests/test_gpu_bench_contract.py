@@ -47,3 +47,15 @@ def test_bench_self_launches_two_ranks_rehearsal():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3          # both ranks' samples / max-over-ranks time
     assert "schedule allgather" in d["config"]["all_gather"]
+
+
+def test_bench_clip_two_ranks_ragged_rehearsal():
+    """BASELINE configs[3] control flow with two self-launched ranks sharing this box's GPU (gloo, host-memory reassembly): 9 frames ->
+    shards of 5 and 4, micro-batches of 2, the common part gathered per micro-batch, rank 0's fifth frame through finish()."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_clip.py"), "--gpus", "2", "--backend", "gloo", "--frames", "9",
+                        "--height", "128", "--width", "160", "--micro-batch", "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gathered_bytes"] == 9 * 128 * 160 * 3
