@@ -783,6 +783,21 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
             r.WLEN = round_up(r.s_in * Cin * (64 * r.MB - 1) + r.w_a + r.SEGP, 4);
             r.Ho = p.Ho; r.Wo = p.Wo; r.Cs_out = p.Cs_out; r.c_off = 0; r.N = p.N; r.Npad = p.Npad; r.act = 1;
             if (in_bytes < 0x80000000LL && rowwin_applicable(r)) {
+                const int rem = p.Wo % 128;
+                if (r.MB == 2 && p.Wo > 128 && rem >= 1 && rem <= 64) {
+                    // 128 k + (1..64) columns: k full tiles, then the rest as ONE 64-pixel tile (second launch; events span both)
+                    RowWinParams t = r;
+                    r.ntile_x = p.Wo / 128;
+                    t.MB = 1; t.ox_base = r.ntile_x * 128; t.ntile_x = 1;
+                    t.WLEN = round_up(t.s_in * Cin * 63 + t.w_a + t.SEGP, 4);
+                    if (rowwin_applicable(t)) {
+                        HIP_TRY(ctx, launch_conv_rowwin(r, stream, EV_A(0), nullptr));
+                        HIP_TRY(ctx, launch_conv_rowwin(t, stream, nullptr, EV_B(0)));
+                        ctx->prof_kernel[0] = "conv_rowwin_kernel<7, 2> + <4, 1> tail";
+                        continue;
+                    }
+                    r.ntile_x = 0;
+                }
                 HIP_TRY(ctx, launch_conv_rowwin(r, stream, EV_A(0), EV_B(0)));
                 ctx->prof_kernel[0] = r.MB == 2 ? "conv_rowwin_kernel<7, 2>" : "conv_rowwin_kernel<4, 1>";
                 continue;

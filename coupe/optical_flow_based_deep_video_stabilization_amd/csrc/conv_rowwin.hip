@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
     // 7-row input windows overlap by five rows
     unsigned bx_, by_, bz_;
     xcd_remap(bx_, by_, bz_);
-    const int oy = (int)bx_, ox0 = (int)by_ * (64 * MB), n = (int)bz_;
+    const int oy = (int)bx_, ox0 = p.ox_base + (int)by_ * (64 * MB), n = (int)bz_;
     const int pix_step = p.s_in * p.Cs_in;
     const int row_floats = p.Wi * p.Cs_in;
     const int g0 = pix_step * ox0 + p.e_off - p.w_a;       // window start, floats from the row start (multiple of 4)
@@ -197,8 +197,11 @@ hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEven
 {
     if (!rowwin_applicable(p)) return hipErrorInvalidValue;
     const int tile = 64 * p.MB;
-    dim3 grid(p.Ho, (p.Wo + tile - 1) / tile, p.B), block(256);       // (row, x tile, sample): see the XCD remap in the kernel
-    const bool timed = ev_start && ev_stop;      // timestamps of the kernel's own dispatch packet, no marker packets (see conv_mfma.hip)
+    if (p.ox_base < 0 || p.ox_base >= p.Wo || (p.ox_base & 1) || p.ntile_x < 0) return hipErrorInvalidValue;
+    const int ntx = p.ntile_x > 0 ? p.ntile_x : (p.Wo - p.ox_base + tile - 1) / tile;       // x tiles of THIS launch
+    dim3 grid(p.Ho, ntx, p.B), block(256);       // (row, x tile, sample): see the XCD remap in the kernel
+    const bool timed = ev_start || ev_stop;      // timestamps of the kernel's own dispatch packet, no marker packets (see conv_mfma.hip); a
+                                                 // launch that is one half of a pair carries only the start or only the stop event
     if (p.MB == 2) {
         if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<7, 2>), grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, p);
         else conv_rowwin_kernel<7, 2><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(p);

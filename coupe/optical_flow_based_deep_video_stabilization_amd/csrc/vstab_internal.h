@@ -123,6 +123,9 @@ struct RowWinParams {
     int Ho, Wo, Cs_out, c_off;
     int N, Npad, act;
     int MB;                 // 2: 128-pixel tiles; 1: 64-pixel tiles (small launches)
+    int ox_base, ntile_x;   // first output column and number of x tiles of this launch (0 tiles = up to the row end): a row whose length
+                            // is 128 k + (1..64) runs as k 128-pixel tiles plus ONE 64-pixel tile in a second launch instead of a
+                            // half-empty 128-pixel one (Wo = 960 at 1080p: 6 % of the first layer's MFMA work)
 };
 // tile height of the row-window kernel for a launch of Ho x Wo x B output pixels: 64-pixel tiles while 128-pixel ones would not
 // give every CU two workgroups
