@@ -42,7 +42,7 @@ EXPORTS = {
     "vstab_hbm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "vstab_get_pixel_value": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
     "vstab_st_transform": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "vstab_st_bilinear_interp": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "vstab_st_bilinear_interp": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_st_meshgrid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vstab_homography_warp": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vstab_vec2mtrx": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvstab_hip.so")
 SOURCES = ("conv_mfma.hip", "conv_rowwin.hip", "flow_ops.hip", "sampler_ops.hip", "nldf_ops.hip", "clip_ops.hip", "train_ops.hip", "wgrad_mfma.hip", "winograd_ops.hip", "homography_ops.hip", "pack.cpp", "api.cpp", "nldf_api.cpp", "train_api.cpp")
-HEADERS = ("vstab_internal.h", "api_internal.h", os.path.join("..", "..", "..", "include", "vstab.h"))
+HEADERS = ("vstab_internal.h", "api_internal.h", "hbm_profile.h", os.path.join("..", "..", "..", "include", "vstab.h"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-result"]
 
@@ -106,6 +106,7 @@ def build_sanitized(verbose: bool = False) -> str:
     if os.path.exists(ASAN_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return ASAN_LIB
     obj_dir = os.path.join(HERE, "build")
+    os.makedirs(obj_dir, exist_ok=True)                 # build() may have been satisfied by its stamp alone
     objs = []
     for s in SOURCES:
         if s.endswith(".cpp"):

@@ -1018,11 +1018,12 @@ extern "C" int vstab_st_transform(const float *img, int B, int H, int W, int C, 
 }
 
 extern "C" int vstab_st_bilinear_interp(const float *img, int B, int H, int W, int C, const float *x, const float *y,
-                                        int npix, float *out, void *stream)
+                                        int oh, int ow, float *out, void *stream)
 {
     if (!img || !x || !y || !out) return fail(nullptr, VSTAB_E_STATE, "st_bilinear_interp: NULL buffer");
-    if (B < 1 || H < 1 || W < 1 || C < 1 || npix < 1) return fail(nullptr, VSTAB_E_SHAPE, "st_bilinear_interp: bad shape");
-    HIP_TRY(nullptr, launch_st_interp(img, B, H, W, C, x, y, npix, out, (hipStream_t)stream));
+    if (B < 1 || H < 1 || W < 1 || C < 1 || oh < 1 || ow < 1 || (long long)oh * ow > 0x7fffffffLL)
+        return fail(nullptr, VSTAB_E_SHAPE, "st_bilinear_interp: bad shape");
+    HIP_TRY(nullptr, launch_st_interp(img, B, H, W, C, x, y, oh, ow, out, (hipStream_t)stream));
     return VSTAB_OK;
 }
 

@@ -3,7 +3,7 @@
 // Built with -ffp-contract=off so that the lerp / weight arithmetic is the same sequence
 // of fp32 roundings the reference's TF graph performs; dot products use explicit fmaf.
 #include "vstab_internal.h"
-#include <hip/hip_ext.h>
+#include "hbm_profile.h"
 #include <algorithm>
 #include <cmath>
 #include <mutex>
@@ -14,9 +14,7 @@ namespace vstab {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// ---- optional per-launch timing of the HBM-side kernels (bench.py's roofline_hbm block): when switched on, a launch goes through
-// hipExtLaunchKernelGGL, which stamps the kernel's own start/stop into two events on the launch stream (the same mechanism as the
-// conv launches' profile slots); off (the default) it is a plain launch.  Process-wide, instrumentation only.
+// ---- records of the optional per-launch timing of the HBM-side kernels (hbm_profile.h has the launch wrapper)
 struct HbmProfState {
     std::mutex mu;
     bool on = false;
@@ -55,25 +53,20 @@ hipError_t hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg
     return hipSuccess;
 }
 
-template <typename... KArgs, typename... Args>
-static hipError_t launch_timed(int slot, double alg_bytes, void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, Args... args)
+hipError_t hbm_profile_begin(int slot, double alg_bytes, hipEvent_t *a, hipEvent_t *b)
 {
     HbmProfState &P = hbm_prof();
-    if (P.on) {
-        HbmProfState::Rec r;
-        hipError_t e = hipEventCreate(&r.a);
-        if (e != hipSuccess) return e;
-        e = hipEventCreate(&r.b);
-        if (e != hipSuccess) return e;
-        {
-            std::lock_guard<std::mutex> g(P.mu);
-            P.recs[slot].push_back(r); P.bytes[slot] += alg_bytes;
-        }
-        hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, r.a, r.b, 0, static_cast<KArgs>(args)...);
-    } else {
-        kernel<<<grid, block, 0, stream>>>(static_cast<KArgs>(args)...);
-    }
-    return hipGetLastError();
+    *a = *b = nullptr;
+    if (!P.on) return hipSuccess;
+    HbmProfState::Rec r;
+    hipError_t e = hipEventCreate(&r.a);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&r.b);
+    if (e != hipSuccess) { (void)hipEventDestroy(r.a); return e; }
+    std::lock_guard<std::mutex> g(P.mu);
+    P.recs[slot].push_back(r); P.bytes[slot] += alg_bytes;
+    *a = r.a; *b = r.b;
+    return hipSuccess;
 }
 
 // ---- legacy TF bilinear (ResizeBilinear, align_corners=False, no half-pixel centres):

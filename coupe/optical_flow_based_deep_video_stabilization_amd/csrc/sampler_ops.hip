@@ -1,10 +1,15 @@
-// Secondary samplers named by the reference's spatial_transformer.py and warp.py (SURVEY.md 8a rows
-// S1-S3).  All are HBM/latency-bound 4-tap gathers: one thread per output pixel, coordinates
-// generated in-kernel (no grid tensor is materialised), coalesced stores.
+// Samplers named by the reference's spatial_transformer.py and warp.py (BASELINE configs[2]'s
+// "spatial_transformer warp").  HBM-bound 4-tap gathers, coordinates generated in-kernel (no grid tensor is materialised).
+// 3-channel frames run on st3_tile_kernel (2-D tiles, source window staged in LDS by aligned 16-byte loads, rows leaving as
+// 16-byte stores); other channel counts on the one-thread-per-pixel kernels.
 // -ffp-contract=off keeps the weight arithmetic the reference's op-by-op fp32 sequence.
 #include "vstab_internal.h"
+#include "hbm_profile.h"
+#include <cstdlib>
 
 namespace vstab {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // tf.linspace(-1, 1, n)[i] in fp32 (start + i*step, step = 2/(n-1); a single point is -1)
 __device__ __forceinline__ float lin11(int i, int n)
@@ -137,6 +142,251 @@ __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__res
     (void)wUL; (void)wUR; (void)wBL; (void)wBR;
 }
 
+// ---------------------------------------------------------------------------------
+// 3-channel frames: all three sampler families on one tile kernel (24 B/px algorithmic: 12 gathered + 12 written, + 8 with
+// explicit coordinates).
+//   FAM_ST_THETA  Affine/ProjectiveTransformer.transform   (spatial_transformer.py:400-452, 539-608)
+//   FAM_ST_COORDS bilinear_interp with explicit x, y       (spatial_transformer.py:902-964)
+//   FAM_HOMOG     warp.transformImage / transformCropImage (warp.py:46-129)
+// A direct gather of 12-byte pixels is bound by the L1 tag pipe, not by HBM (profiles/README.md, "r02 warp study": a 12-byte
+// pixel per lane is 1.75 64-byte lookups per four lanes and a pixel has four corners).  tf_warp has to live with that -- its
+// sample points come from a flow field, and finding their bounding box costs a dependent memory round trip.  Here the sample
+// points are pure arithmetic on the pixel index (or one coalesced load), so the workgroup
+//   1. computes the four taps of its 16 x 32 output pixels (2 per thread, 4 x 16 wave patches) and reduces their bounding box
+//      (DPP wave reductions, one LDS exchange),
+//   2. copies that window of the source into LDS with ALIGNED 16-byte loads (one lookup per 64 bytes; the window starts at a
+//      column that is a multiple of 4 pixels = 48 bytes, rows are W*12 bytes with W % 4 == 0),
+//   3. takes the four corners of every pixel from LDS (row pitch = 16 mod 32 floats: the two rows a 32-lane group reads fall
+//      on disjoint banks),
+//   4. re-uses the LDS for the finished tile and writes it as 16-byte stores of whole 384-byte rows.
+// A window that does not fit (strong minification, a projective map whose z changes sign inside the tile) falls back to direct
+// 3-dword gathers for that tile (workgroup-uniform); W % 4 != 0 or unaligned bases use the direct form throughout.  The
+// arithmetic is st_sample_pixel's / homography_warp_kernel's statement for statement: bit-identical results.
+// ---------------------------------------------------------------------------------
+enum { FAM_ST_THETA = 0, FAM_ST_COORDS = 1, FAM_HOMOG = 2 };
+struct __attribute__((packed, aligned(4))) rgb3 { float r, g, b; };
+struct StSrc { const float *theta; const float *x; const float *y; int tdim; };    // theta [B,tdim] (M [B,9] for FAM_HOMOG) or x, y [B*oh*ow]
+
+constexpr int ST_TW = 32, ST_TH = 16, ST_PPT = 2, ST_WW = 16, ST_WH = 4, ST_PPR = ST_TW / ST_WW;
+constexpr int ST_LDS = 6144;            // floats (24 KB): the source window, then the finished tile (16*32*3 = 1536)
+static_assert(ST_WH * (4 * ST_PPT) / ST_PPR == ST_TH && ST_TH * ST_TW * 3 <= ST_LDS, "tile shape");
+
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    // inclusive DPP scan (row_shr 1,2,4,8; row_bcast 15 into rows 1,3; row_bcast 31 into rows 2,3): lane 63 holds the result
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
+
+// the four taps of one output pixel: image coordinates clamped into the image (what is addressed), validity per axis (what
+// counts: an invalid tap reads as zero) and the blend weights (ST: w00, w01, w10, w11; homography: xr, yr)
+struct Taps { int xa, xb, ya, yb; bool vxa, vxb, vya, vyb; float w0, w1, w2, w3; };
+
+__device__ __forceinline__ Taps st_taps(float xn, float yn, int H, int W)          // st_sample_pixel's arithmetic
+{
+    const float wf = (float)W, hf = (float)H;
+    float x = (xn + 1.0f) / 2.0f * (wf - 1.0f);
+    float y = (yn + 1.0f) / 2.0f * (hf - 1.0f);
+    x = fminf(fmaxf(x, -1.0f), wf - 1.0f + 1.0f);
+    y = fminf(fmaxf(y, -1.0f), hf - 1.0f + 1.0f);
+    x += 1.0f;
+    y += 1.0f;
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = (int)fminf(x1f, wf - 1.0f + 2.0f), y1 = (int)fminf(y1f, hf - 1.0f + 2.0f);
+    Taps t;
+    t.w0 = (x1f - x) * (y1f - y); t.w1 = (x - x0f) * (y1f - y);
+    t.w2 = (x1f - x) * (y - y0f); t.w3 = (x - x0f) * (y - y0f);
+    t.vxa = x0 >= 1 && x0 <= W; t.vxb = x1 >= 1 && x1 <= W; t.vya = y0 >= 1 && y0 <= H; t.vyb = y1 >= 1 && y1 <= H;
+    t.xa = min(max(x0 - 1, 0), W - 1); t.xb = min(max(x1 - 1, 0), W - 1);
+    t.ya = min(max(y0 - 1, 0), H - 1); t.yb = min(max(y1 - 1, 0), H - 1);
+    return t;
+}
+
+__device__ __forceinline__ Taps homog_taps(const float *__restrict__ m, int ox, int oy, int oh, int ow, int Hi, int Wi)   // homography_warp_kernel's
+{
+    const float X = ow > 1 ? (float)(-1.0 + (double)ox * (2.0 / (double)(ow - 1))) : -1.0f;
+    const float Y = oh > 1 ? (float)(-1.0 + (double)oy * (2.0 / (double)(oh - 1))) : -1.0f;
+    const float xh = (m[0] * X + m[1] * Y) + m[2];
+    const float yh = (m[3] * X + m[4] * Y) + m[5];
+    const float zh = (m[6] * X + m[7] * Y) + m[8];
+    const float xw = xh / (zh + 1e-8f), yw = yh / (zh + 1e-8f);
+    const float xf = floorf(xw), xc = ceilf(xw), yf = floorf(yw), yc = ceilf(yw);
+    const float lim = 1.0e9f;
+    const int xfi = (int)fminf(fmaxf(xf, -lim), lim), xci = (int)fminf(fmaxf(xc, -lim), lim);
+    const int yfi = (int)fminf(fmaxf(yf, -lim), lim), yci = (int)fminf(fmaxf(yc, -lim), lim);
+    Taps t;
+    t.w0 = xw - xf; t.w1 = yw - yf; t.w2 = 0.f; t.w3 = 0.f;
+    t.vxa = xfi >= 0 && xfi < Wi; t.vxb = xci >= 0 && xci < Wi; t.vya = yfi >= 0 && yfi < Hi; t.vyb = yci >= 0 && yci < Hi;
+    t.xa = min(max(xfi, 0), Wi - 1); t.xb = min(max(xci, 0), Wi - 1);
+    t.ya = min(max(yfi, 0), Hi - 1); t.yb = min(max(yci, 0), Hi - 1);
+    return t;
+}
+
+template <int FAM>
+__device__ __forceinline__ float st_blend(const Taps &t, float I00, float I01, float I10, float I11)
+{
+    if (FAM == FAM_HOMOG) {
+        const float xr = t.w0, yr = t.w1;        // image*(1-Xratio)*(1-Yratio) evaluates left to right
+        return (((I00 * (1.0f - xr)) * (1.0f - yr) + (I01 * xr) * (1.0f - yr)) + (I10 * (1.0f - xr)) * yr) + (I11 * xr) * yr;
+    }
+    return ((t.w0 * I00 + t.w1 * I01) + t.w2 * I10) + t.w3 * I11;      // tf.add_n order
+}
+
+template <int FAM, bool WINDOW, bool STAGE>
+__global__ __launch_bounds__(256) void st3_tile_kernel(const float *__restrict__ img, int B, int H, int W, StSrc S,
+                                                       float *__restrict__ out, int oh, int ow, int tiles_x, int tiles_y)
+{
+    constexpr int TW = ST_TW, TH = ST_TH, PPT = ST_PPT, WW = ST_WW, WH = ST_WH, PPR = ST_PPR;
+    __shared__ __attribute__((aligned(16))) float lds[WINDOW ? ST_LDS : (STAGE ? ST_TH * ST_TW * 3 : 4)];
+    __shared__ int red[4][4];
+    unsigned bx, by, bz;
+    xcd_remap_calc(gridDim.x, 1, 1, blockIdx.x, bx, by, bz);
+    const int tpi = tiles_x * tiles_y;
+    const int n = (int)bx / tpi, trem = (int)bx - n * tpi;
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int HW = H * W;                              // 3 B H W < 2^31 (host)
+
+    Taps t[PPT];
+    int yy[PPT], xx[PPT];
+    bool ok[PPT];
+    float th[9];
+    if (FAM != FAM_ST_COORDS) {
+        const float *tp = S.theta + (long long)n * S.tdim;       // wave-uniform: scalar loads
+#pragma unroll
+        for (int k = 0; k < 9; ++k) th[k] = k < S.tdim ? tp[k] : 1.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int q = j * 4 + wave;
+        const int y = ty0 + (q / PPR) * WH + lane / WW, x = tx0 + (q % PPR) * WW + lane % WW;
+        ok[j] = y < oh && x < ow;
+        yy[j] = min(y, oh - 1); xx[j] = min(x, ow - 1);          // a pixel beyond the output repeats an edge pixel of this tile (not stored)
+        if (FAM == FAM_ST_THETA) {
+            const float xt = lin11(xx[j], ow), yt = lin11(yy[j], oh);
+            float xs = (th[0] * xt + th[1] * yt) + th[2];
+            float ys = (th[3] * xt + th[4] * yt) + th[5];
+            if (S.tdim == 8) {
+                float zs = (th[6] * xt + th[7] * yt) + 1.0f;
+                if (zs == 0.0f) zs = zs + 1e-8f;
+                xs = xs / zs;
+                ys = ys / zs;
+            }
+            t[j] = st_taps(xs, ys, H, W);
+        } else if (FAM == FAM_ST_COORDS) {
+            const long long i = ((long long)n * oh + yy[j]) * ow + xx[j];
+            t[j] = st_taps(S.x[i], S.y[i], H, W);
+        } else {
+            t[j] = homog_taps(th, xx[j], yy[j], oh, ow, H, W);
+        }
+    }
+    const rgb3 *b = reinterpret_cast<const rgb3 *>(img) + (long long)n * HW;
+    rgb3 I00[PPT], I01[PPT], I10[PPT], I11[PPT];
+    bool windowed = false;
+    if (WINDOW) {
+        int mnx = t[0].xa, mxx = t[0].xb, mny = t[0].ya, mxy = t[0].yb;
+#pragma unroll
+        for (int j = 1; j < PPT; ++j) { mnx = min(mnx, t[j].xa); mxx = max(mxx, t[j].xb); mny = min(mny, t[j].ya); mxy = max(mxy, t[j].yb); }
+        {
+            const int a = wave_min_i32(mnx), c = wave_max_i32(mxx), d = wave_min_i32(mny), e = wave_max_i32(mxy);
+            if (lane == 0) { red[wave][0] = a; red[wave][1] = c; red[wave][2] = d; red[wave][3] = e; }
+        }
+        __syncthreads();
+        const int X0 = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0])) & ~3;     // multiple of 4 pixels = 48 bytes
+        const int X1 = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+        const int Y0 = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
+        const int Y1 = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+        const int n4 = ((X1 - X0 + 1) * 3 + 3) >> 2, wh = Y1 - Y0 + 1;                     // float4s per window row, rows
+        const int P = ((n4 * 4 + 15) & ~31) + 16;                                         // row pitch in floats: >= 4 n4, = 16 mod 32
+        windowed = wh * P <= ST_LDS;                                                       // workgroup-uniform
+        if (windowed) {
+            // half a wave per window row (windows are ~28 float4 wide), four rows of loads in flight per thread
+            const long long total = (long long)B * HW * 3;
+            const long long base = ((long long)n * HW + (long long)Y0 * W + X0) * 3;        // multiple of 4 floats
+            const int rsub = wave * 2 + (lane >> 5), l32 = lane & 31;
+            for (int r0 = rsub; r0 < wh; r0 += 32)
+                for (int c4 = l32; c4 < n4; c4 += 32) {
+                    f32x4 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = r0 + 8 * k;
+                        const long long off = base + (long long)r * W * 3 + c4 * 4;
+                        v[k] = (r < wh && off + 4 <= total) ? *reinterpret_cast<const f32x4 *>(img + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (r0 + 8 * k < wh) *reinterpret_cast<f32x4 *>(lds + (r0 + 8 * k) * P + c4 * 4) = v[k];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int ra = (t[j].ya - Y0) * P - X0 * 3, rb = (t[j].yb - Y0) * P - X0 * 3;
+                I00[j] = *reinterpret_cast<const rgb3 *>(lds + ra + t[j].xa * 3); I01[j] = *reinterpret_cast<const rgb3 *>(lds + ra + t[j].xb * 3);
+                I10[j] = *reinterpret_cast<const rgb3 *>(lds + rb + t[j].xa * 3); I11[j] = *reinterpret_cast<const rgb3 *>(lds + rb + t[j].xb * 3);
+            }
+        }
+    }
+    if (!windowed) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            I00[j] = b[t[j].ya * W + t[j].xa]; I01[j] = b[t[j].ya * W + t[j].xb];
+            I10[j] = b[t[j].yb * W + t[j].xa]; I11[j] = b[t[j].yb * W + t[j].xb];
+        }
+    }
+    if (WINDOW && STAGE) __syncthreads();              // every corner has been read: the window becomes the store stage
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const bool v00 = t[j].vxa && t[j].vya, v01 = t[j].vxb && t[j].vya, v10 = t[j].vxa && t[j].vyb, v11 = t[j].vxb && t[j].vyb;
+        rgb3 r;
+        r.r = st_blend<FAM>(t[j], v00 ? I00[j].r : 0.f, v01 ? I01[j].r : 0.f, v10 ? I10[j].r : 0.f, v11 ? I11[j].r : 0.f);
+        r.g = st_blend<FAM>(t[j], v00 ? I00[j].g : 0.f, v01 ? I01[j].g : 0.f, v10 ? I10[j].g : 0.f, v11 ? I11[j].g : 0.f);
+        r.b = st_blend<FAM>(t[j], v00 ? I00[j].b : 0.f, v01 ? I01[j].b : 0.f, v10 ? I10[j].b : 0.f, v11 ? I11[j].b : 0.f);
+        if (STAGE) {
+            const int q = j * 4 + wave;
+            *reinterpret_cast<rgb3 *>(lds + (((q / PPR) * WH + lane / WW) * TW + (q % PPR) * WW + lane % WW) * 3) = r;
+        } else if (ok[j]) {
+            reinterpret_cast<rgb3 *>(out)[((long long)n * oh + yy[j]) * ow + xx[j]] = r;
+        }
+    }
+    if (STAGE) {       // ow % 4 == 0 (host): a tile row is TW*12 bytes from a 16-byte aligned address
+        __syncthreads();
+        constexpr int R4 = TW * 3 / 4;
+        const int vw3 = min(TW, ow - tx0) * 3;
+        for (int e = threadIdx.x; e < TH * R4; e += 256) {
+            const int row = e / R4, c4 = e - row * R4;
+            if (ty0 + row >= oh || c4 * 4 >= vw3) continue;
+            float *o = out + (((long long)n * oh + ty0 + row) * ow + tx0) * 3 + c4 * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(lds + row * TW * 3 + c4 * 4);
+            if (c4 * 4 + 4 <= vw3) *reinterpret_cast<f32x4 *>(o) = v;
+            else for (int i = 0; c4 * 4 + i < vw3; ++i) o[i] = v[i];
+        }
+    }
+}
+
+// picks the instantiation for a 3-channel launch; hipErrorNotSupported when the shape is not the tile kernel's
+template <int FAM>
+static hipError_t launch_st3(int slot, const float *img, int B, int H, int W, const StSrc &S, float *out, int oh, int ow, hipStream_t stream)
+{
+    const long long tx = (ow + ST_TW - 1) / ST_TW, ty = (oh + ST_TH - 1) / ST_TH, tiles = tx * ty * B;
+    if (tiles >= (1ll << 31) || (long long)B * H * W * 3 >= (1ll << 31) || (long long)B * oh * ow * 3 >= (1ll << 31)) return hipErrorNotSupported;
+    const bool window = (W & 3) == 0 && ((uintptr_t)img & 15) == 0 && !getenv("VSTAB_ST_NO_WINDOW");
+    const bool stage = (ow & 3) == 0 && ((uintptr_t)out & 15) == 0;
+    const double bytes = (FAM == FAM_ST_COORDS ? 32.0 : 24.0) * B * oh * ow;       // every output pixel reads ~one source pixel, writes one (+ x, y)
+    const dim3 grid((unsigned)tiles), block(256);
+#define ST3_GO(WIN, STG) launch_timed(slot, bytes, st3_tile_kernel<FAM, WIN, STG>, grid, block, stream, img, B, H, W, S, out, oh, ow, (int)tx, (int)ty)
+    if (window) return stage ? ST3_GO(true, true) : ST3_GO(true, false);
+    return stage ? ST3_GO(false, true) : ST3_GO(false, false);
+#undef ST3_GO
+}
+
 // warp.vec2mtrx (warp.py:25-43): sl(3) / affine generator -> matrix exponential by Taylor series,
 // pMtrx = sum_{i=0}^{warpApprox-1} A^i / i!   (fp32, one thread per batch element)
 __global__ void vec2mtrx_kernel(const float *__restrict__ p, int B, int dim, int approx, float *__restrict__ out)
@@ -166,10 +416,15 @@ __global__ void vec2mtrx_kernel(const float *__restrict__ p, int B, int dim, int
     for (int k = 0; k < 9; ++k) out[(long long)n * 9 + k] = P[k];
 }
 
-hipError_t launch_st_interp(const float *img, int B, int H, int W, int C, const float *x, const float *y, int npix, float *out,
+hipError_t launch_st_interp(const float *img, int B, int H, int W, int C, const float *x, const float *y, int oh, int ow, float *out,
                             hipStream_t stream)
 {
+    const int npix = oh * ow;
     const long long total = (long long)B * npix;
+    if (C == 3) {
+        const hipError_t e = launch_st3<FAM_ST_COORDS>(HBM_SLOT_ST, img, B, H, W, StSrc{nullptr, x, y, 0}, out, oh, ow, stream);
+        if (e != hipErrorNotSupported) return e;
+    }
     st_interp_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, B, H, W, C, x, y, npix, out);
     return hipGetLastError();
 }
@@ -178,6 +433,10 @@ hipError_t launch_st_transform(const float *img, int B, int H, int W, int C, con
                                int ow, hipStream_t stream)
 {
     const long long total = (long long)B * oh * ow;
+    if (C == 3) {
+        const hipError_t e = launch_st3<FAM_ST_THETA>(HBM_SLOT_ST, img, B, H, W, StSrc{theta, nullptr, nullptr, tdim}, out, oh, ow, stream);
+        if (e != hipErrorNotSupported) return e;
+    }
     st_transform_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, B, H, W, C, theta, tdim, out, oh, ow);
     return hipGetLastError();
 }
@@ -192,6 +451,10 @@ hipError_t launch_homography_warp(const float *img, int B, int Hi, int Wi, int C
                                   hipStream_t stream)
 {
     const long long total = (long long)B * oh * ow;
+    if (C == 3) {
+        const hipError_t e = launch_st3<FAM_HOMOG>(HBM_SLOT_HOMOG, img, B, Hi, Wi, StSrc{M, nullptr, nullptr, 9}, out, oh, ow, stream);
+        if (e != hipErrorNotSupported) return e;
+    }
     homography_warp_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, B, Hi, Wi, C, M, out, oh, ow);
     return hipGetLastError();
 }

@@ -183,7 +183,7 @@ hipError_t launch_resize_bilinear_slice3(const float *x, int B, int h, int w, in
 hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W,
                             int C, hipStream_t stream);
 // per-launch timing of the HBM-side kernels (flow_ops.hip): slots of vstab_hbm_profile_read
-enum { HBM_SLOT_WARP = 0, HBM_SLOT_GLUE = 1, HBM_SLOT_GLUE_WARP = 2, HBM_SLOT_PF2 = 3, HBM_SLOTS = 4 };
+enum { HBM_SLOT_WARP = 0, HBM_SLOT_GLUE = 1, HBM_SLOT_GLUE_WARP = 2, HBM_SLOT_PF2 = 3, HBM_SLOT_ST = 4, HBM_SLOT_HOMOG = 5, HBM_SLOTS = 6 };
 void hbm_profile_enable(int mode);
 hipError_t hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg_bytes_sum);
 hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *out, int oh, int ow,
@@ -203,7 +203,7 @@ hipError_t launch_get_pixel_value(const float *img, const int32_t *x, const int3
 // Secondary samplers (sampler_ops.hip): spatial_transformer.py / warp.py rows S1-S3.
 // ---------------------------------------------------------------------------------
 hipError_t launch_st_interp(const float *img, int B, int H, int W, int C, const float *x, const float *y,
-                            int npix, float *out, hipStream_t stream);
+                            int oh, int ow, float *out, hipStream_t stream);
 hipError_t launch_st_transform(const float *img, int B, int H, int W, int C, const float *theta, int tdim,
                                float *out, int oh, int ow, hipStream_t stream);
 hipError_t launch_st_meshgrid(float *out, int oh, int ow, hipStream_t stream);

@@ -25,7 +25,7 @@ def trace_ranges(on: bool):
     _lib.check(_lib.lib().vstab_trace_ranges(int(bool(on))))
 
 
-HBM_SLOTS = ("warp_flow", "flow_resize_scale", "flow_glue_warp", "pf2_gather")
+HBM_SLOTS = ("warp_flow", "flow_resize_scale", "flow_glue_warp", "pf2_gather", "st_sampler", "homography_warp")
 
 
 def hbm_profile(mode: int):

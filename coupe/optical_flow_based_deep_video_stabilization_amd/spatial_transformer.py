@@ -39,12 +39,13 @@ def bilinear_interp(im, x, y, out_size):
     B, H, W, Cc = im.shape
     x = _f32_cuda(x.to(torch.float32), "x").reshape(-1)
     y = _f32_cuda(y.to(torch.float32), "y").reshape(-1)
-    npix = int(out_size[0]) * int(out_size[1])
+    oh, ow = int(out_size[0]), int(out_size[1])
+    npix = oh * ow
     if x.numel() != B * npix or y.numel() != B * npix:
         raise ValueError(f"x/y must have B*out_h*out_w = {B * npix} elements")
     out = torch.empty((B * npix, Cc), dtype=torch.float32, device=im.device)
     with torch.cuda.device(im.device):
-        _lib.check(_lib.lib().vstab_st_bilinear_interp(im.data_ptr(), B, H, W, Cc, x.data_ptr(), y.data_ptr(), npix,
+        _lib.check(_lib.lib().vstab_st_bilinear_interp(im.data_ptr(), B, H, W, Cc, x.data_ptr(), y.data_ptr(), oh, ow,
                                                        out.data_ptr(), runtime.stream_ptr()))
     return out
 

@@ -175,9 +175,9 @@ VSTAB_API int vstab_get_pixel_value(const float *img, const int32_t *x, const in
 VSTAB_API int vstab_st_transform(const float *img, int B, int H, int W, int C, const float *theta, int theta_dim,
                                  float *out, int oh, int ow, void *stream);
 /* bilinear_interp(im, x, y, out_size) / _interpolate (spatial_transformer.py:902-964, 787-792): x, y flat
- * [B*npix] normalised to [-1,1]; out [B*npix, C]. */
+ * [B*oh*ow] normalised to [-1,1], out_size = (oh, ow) as the reference passes it; out [B*oh*ow, C]. */
 VSTAB_API int vstab_st_bilinear_interp(const float *img, int B, int H, int W, int C, const float *x, const float *y,
-                                       int npix, float *out, void *stream);
+                                       int oh, int ow, float *out, void *stream);
 /* _meshgrid(out_size) (spatial_transformer.py:755-779): out[3*oh*ow] = x_t row, y_t row, ones. */
 VSTAB_API int vstab_st_meshgrid(float *out, int oh, int ow, void *stream);
 /* warp.transformImage / transformCropImage (warp.py:46-86, 89-129): M [B,9] = refMtrx . pMtrx maps the canonical

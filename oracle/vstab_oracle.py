@@ -380,19 +380,29 @@ def st_bilinear_interp(im, x, y, out_size, dtype=torch.float32):
     return w00 * I00 + w01 * I01 + w10 * I10 + w11 * I11
 
 
-def st_transform(im, theta, out_size, dtype=torch.float32):
+def st_transform(im, theta, out_size, dtype=torch.float32, matmul="blas"):
     """AffineTransformer.transform (ST:400-452) for theta [B,6], ProjectiveTransformer.transform
-    (ST:539-608) for theta [B,8]."""
+    (ST:539-608) for theta [B,8].  The reference's tf.matmul(theta, grid) (ST:447, 593) is a 3-term dot
+    product per coordinate whose rounding sequence TF does not specify (Eigen contraction, fused
+    multiply-add or not by build): matmul="blas" leaves it to torch.matmul, matmul="unfused" evaluates
+    (t0*x + t1*y) + t2*1 with every product and sum rounded to fp32 -- the sequence the HIP kernels use.
+    The two differ by <= 1 ulp of the source coordinate."""
     im = _t(im, dtype)
     B = im.shape[0]
     th = _t(theta, torch.float32).reshape(B, -1)
     grid = torch.from_numpy(st_meshgrid(out_size)).reshape(3, -1)
+
+    def mm(M):                                                              # M [B,r,3] . grid [3,N]
+        if matmul == "blas":
+            return torch.matmul(M, grid.unsqueeze(0).expand(B, 3, -1))
+        return (M[:, :, 0:1] * grid[0] + M[:, :, 1:2] * grid[1]) + M[:, :, 2:3] * grid[2]
+
     if th.shape[1] == 6:
-        T = torch.matmul(th.reshape(B, 2, 3), grid.unsqueeze(0).expand(B, 3, -1))
+        T = mm(th.reshape(B, 2, 3))
         xs, ys = T[:, 0], T[:, 1]
     else:
         th9 = torch.cat([th, torch.ones(B, 1)], 1).reshape(B, 3, 3)
-        T = torch.matmul(th9, grid.unsqueeze(0).expand(B, 3, -1))
+        T = mm(th9)
         z = T[:, 2]
         z = torch.where(z == 0, z + np.float32(1e-8), z)                  # safe_z (:598)
         xs, ys = T[:, 0] / z, T[:, 1] / z
@@ -421,15 +431,18 @@ def warp_vec2mtrx(p, warp_type: str, warp_approx: int):
     return pM
 
 
-def warp_transform_image(image, M, oh: int, ow: int, dtype=torch.float32):
+def warp_transform_image(image, M, oh: int, ow: int, dtype=torch.float32, matmul="blas"):
     """warp.transformImage / transformCropImage (warp.py:46-86, 89-129) given M = refMtrx . pMtrx [B,3,3];
-    image [B,Hi,Wi,C] -> [B,oh,ow,C]."""
+    image [B,Hi,Wi,C] -> [B,oh,ow,C].  `matmul` as in st_transform (warp.py:55, 98 are tf.matmul too)."""
     image = _t(image, dtype)
     B, Hi, Wi, C = image.shape
     M = _t(M, torch.float32).reshape(B, 3, 3)
     X, Y = np.meshgrid(np.linspace(-1, 1, ow), np.linspace(-1, 1, oh))
     XYhom = torch.from_numpy(np.stack([X.flatten(), Y.flatten(), np.ones(oh * ow)], 0).astype(np.float32))
-    W3 = torch.matmul(M, XYhom.unsqueeze(0).expand(B, 3, -1))
+    if matmul == "blas":
+        W3 = torch.matmul(M, XYhom.unsqueeze(0).expand(B, 3, -1))
+    else:
+        W3 = (M[:, :, 0:1] * XYhom[0] + M[:, :, 1:2] * XYhom[1]) + M[:, :, 2:3] * XYhom[2]
     xw = (W3[:, 0] / (W3[:, 2] + np.float32(1e-8))).reshape(B, oh, ow)
     yw = (W3[:, 1] / (W3[:, 2] + np.float32(1e-8))).reshape(B, oh, ow)
     xf, xc, yf, yc = torch.floor(xw), torch.ceil(xw), torch.floor(yw), torch.ceil(yw)
