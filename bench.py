@@ -119,6 +119,12 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph (torch.cuda.CUDAGraph) and replay it; single GPU, no kernel events")
     ap.add_argument("--roctx", action="store_true", help="run every layer inside a named roctx range (rocprofv3 --marker-trace)")
+    ap.add_argument("--alloc-per-step", action="store_true",
+                    help="call stabilise_originalsize (two library calls, seven output allocations per step) instead of the pre-allocated "
+                         "one-call OriginalSizeStabiliser")
+    ap.add_argument("--st-warp", choices=("none", "affine", "projective", "homography"), default="none",
+                    help="BASELINE configs[2]'s spatial_transformer leg: also warp the stabilised frame with AffineTransformer / "
+                         "ProjectiveTransformer (spatial_transformer.py:400-452, 539-608) or warp.transformImage (warp.py:46-86) inside the step")
     ap.add_argument("--vgg16", action="store_true",
                     help="BASELINE config 5: also run the VGG16 trunk (preprocess + 13 conv + 5 pool) on the warped frames")
     args = ap.parse_args()
@@ -129,6 +135,7 @@ def main():
                                                 force=os.environ.get("VSTAB_FORCE_DIST") == "1")
     if rc is not None:
         raise SystemExit(rc)
+    real_stdout = load_launch_module().claim_stdout()      # fd 1 -> stderr from here on: RCCL's banner must not sit beside the JSON line
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -193,13 +200,19 @@ def main():
             gather.submit(buf.cpu() if args.backend == "gloo" else buf)
             group["g"] = 0
 
+    # gatherers for the short groups the warm-up and the timed region end with, allocated HERE: nothing allocates between the
+    # opening barrier and the closing synchronise
+    if gather is not None and quantise is not None:
+        for n_steps in (args.warmup, args.steps):
+            if n_steps % G and n_steps % G not in group["tails"]:
+                group["tails"][n_steps % G] = vdist.FrameGatherer(((n_steps % G) * B, H, W, 3), world, gdev, dtype=gdtype,
+                                                                  schedule=args.gather_schedule)
+
     def flush_and_drain():
         """Gather a group the step count left unfinished (one smaller collective), then wait for everything in flight."""
         g = group["g"]
         if gather is not None and quantise is not None and g > 0:
-            tail = group["tails"].get(g)
-            if tail is None:
-                tail = group["tails"][g] = vdist.FrameGatherer((g * B, H, W, 3), world, gdev, dtype=gdtype, schedule=args.gather_schedule)
+            tail = group["tails"][g]
             buf = u8[group["slot"]][:g].reshape(g * B, H, W, 3)
             tail.submit(buf.cpu() if args.backend == "gloo" else buf)
             tail.drain()
@@ -212,14 +225,38 @@ def main():
         from coupe.optical_flow_based_deep_video_stabilization_amd import vgg16 as vvgg
         vgg = vvgg.Vgg16(seed=7, reuse_outputs=True)
 
+    # the spatial-transformer leg (--st-warp: inside the step; otherwise a few launches after the timed region for roofline_hbm.other_rows)
+    from coupe.optical_flow_based_deep_video_stabilization_amd import spatial_transformer as vst, warp as vwarp
+    import math
+    import types
+    st_rows = []
+    for _ in range(B):            # what a stabiliser applies: +-2 degrees, +-3 % scale, +-3 % shift, per sample
+        r = torch.rand(4, generator=g)
+        a, sc = math.radians(float(r[0]) * 4 - 2), 1 + (float(r[1]) - 0.5) * 0.06
+        st_rows.append([sc * math.cos(a), -sc * math.sin(a), (float(r[2]) - 0.5) * 0.06, sc * math.sin(a), sc * math.cos(a), (float(r[3]) - 0.5) * 0.06])
+    th6 = torch.tensor(st_rows, dtype=torch.float32).cuda()
+    th8 = torch.cat([th6, (torch.rand(B, 2, generator=g).cuda() - 0.5) * 0.02], 1)
+    st_aff, st_proj = vst.AffineTransformer((H, W)), vst.ProjectiveTransformer((H, W))
+    st_cfg = types.SimpleNamespace(warpType="homography", warpApprox=20, batch_size=B, height=H, width=W,
+                                   refMtrx=torch.tensor([[(W - 1) / 2, 0, (W - 1) / 2], [0, (H - 1) / 2, (H - 1) / 2], [0, 0, 1.0]]).cuda())
+    st_M = torch.cat([th8, torch.ones(B, 1, device="cuda")], 1).reshape(B, 3, 3)
+    st_fns = {"affine": lambda im: st_aff.transform(im, th6), "projective": lambda im: st_proj.transform(im, th8),
+              "homography": lambda im: vwarp.transformImage(st_cfg, im, st_M)}
+
     nstep = [0]
 
     dbg = [] if os.environ.get("VSTAB_BENCH_DEBUG") else None
 
+    # one library call per step into buffers allocated once (the fp32-gather path hands `warped` to an asynchronous collective and
+    # therefore needs a fresh tensor per step)
+    stab = None if (args.alloc_per_step or args.gather_fp32) else vs.OriginalSizeStabiliser(B, H, W, Cin, H, W)
+
     def step():
         t0 = time.perf_counter()
-        flows, outflow, warped = vs.stabilise_originalsize(feats, frame)
+        flows, outflow, warped = stab(feats, frame) if stab is not None else vs.stabilise_originalsize(feats, frame)
         t1 = time.perf_counter()
+        if args.st_warp != "none":
+            warped = st_fns[args.st_warp](warped)
         if vgg is not None:
             vgg.build(vvgg.preprocess(warped))
         if gather is not None:
@@ -337,6 +374,7 @@ def main():
         runtime.hbm_profile(0)
         hp = runtime.hbm_profile_read()
         pf2_row = hp.pop("pf2_gather", None)
+        st_in_step = {k: hp.pop(k, None) for k in ("st_sampler", "homography_warp")}
         name = max(hp, key=lambda k: hp[k][0])
         ms_sum, nl, by = hp[name]
         if nl > 0 and ms_sum > 0:
@@ -367,6 +405,38 @@ def main():
                 roofline_hbm["other_rows"] = [{"row": "K9 predict_flow2 gather (pf2_tile_kernel; not HBM-bound: nine LDS taps per pixel)",
                                                "launches": pn, "avg_launch_us": round(pms / pn * 1e3, 2), "alg_bytes_per_launch": pby / pn,
                                                "achieved": round(pg, 1), "unit": "GB/s", "frac": round(pg / HBM_PEAK_GBS, 4)}]
+            # S1-S3: the spatial-transformer / warp.py samplers on this run's frames (24 B per output pixel: 12 gathered + 12 written;
+            # theta is 24-36 B per SAMPLE).  Inside the step with --st-warp; otherwise five launches each AFTER the timed region.
+            st_kernel = {"affine": "st3_tile_kernel<0, %s>", "projective": "st3_tile_kernel<0, %s>", "homography": "st3_tile_kernel<2, %s>"}
+            slot_of = {"affine": "st_sampler", "projective": "st_sampler", "homography": "homography_warp"}
+            for mode in ("affine", "projective", "homography"):
+                if args.st_warp == mode:
+                    sms, sn, sby = st_in_step[slot_of[mode]]
+                    where = "inside the timed steps (--st-warp)"
+                elif args.st_warp == "none":
+                    _, _, wf = out
+                    st_fns[mode](wf)
+                    torch.cuda.synchronize()
+                    runtime.hbm_profile(1)
+                    for _ in range(5):
+                        st_fns[mode](wf)
+                    torch.cuda.synchronize()
+                    runtime.hbm_profile(0)
+                    sms, sn, sby = runtime.hbm_profile_read()[slot_of[mode]]
+                    where = "5 launches on the last step's stabilised frames, after the timed region"
+                else:
+                    continue
+                if sn > 0 and sms > 0:
+                    sg = sby / (sms * 1e-3) / 1e9
+                    roofline_hbm.setdefault("other_rows", []).append(
+                        {"row": {"affine": "S2 AffineTransformer.transform", "projective": "S2 ProjectiveTransformer.transform",
+                                 "homography": "S3 warp.transformImage"}[mode] + f" at {B}x{H}x{W}x3 (" + where + ")",
+                         "kernel": st_kernel[mode] % ("true" if W % 4 == 0 else "false"), "launches": sn,
+                         "avg_launch_us": round(sms / sn * 1e3, 2), "alg_bytes_per_launch": sby / sn,
+                         "alg_bytes_per_output_pixel": round(sby / sn / (B * H * W), 2),
+                         "achieved": round(sg, 1), "unit": "GB/s", "frac": round(sg / HBM_PEAK_GBS, 4)})
+                    if rank == 0:
+                        log(f"{'st ' + mode:<18}{sms / sn:>9.4f} ms  {sby / sn / 1e6:>9.1f} MB  {sg:>8.1f} GB/s  frac {sg / HBM_PEAK_GBS:.3f} of 8 TB/s")
             if rank == 0:
                 log(f"{name:<18}{ms_sum / nl:>9.4f} ms  {by / nl / 1e6:>9.1f} MB  {gbs:>8.1f} GB/s  frac {gbs / HBM_PEAK_GBS:.3f} of 8 TB/s")
 
@@ -389,7 +459,8 @@ def main():
                    "batch_per_gpu": B, "height": H, "width": W, "cin": Cin,
                    "gflop_per_sample": round(netspec.gflop_per_sample(H, W, Cin), 2),
                    "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL, schedule " + args.gather_schedule + f", one collective per {G} step(s)") if gather is not None else False,
-                   "vgg16_trunk": bool(args.vgg16)},
+                   "vgg16_trunk": bool(args.vgg16), "st_warp": args.st_warp,
+                   "host_calls_per_step": "1 (vstab_stabilise_originalsize, outputs pre-allocated)" if stab is not None else "2 + 7 allocations"},
         "roofline": roofline,
         "roofline_hbm": roofline_hbm,
     }
@@ -402,7 +473,7 @@ def main():
                                        "sample": f"failed: {e}"}
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=real_stdout, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

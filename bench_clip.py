@@ -46,6 +46,7 @@ def main():
                                   force=os.environ.get("VSTAB_FORCE_DIST") == "1")     # child job; nothing here touches the GPU
     if rc is not None:
         raise SystemExit(rc)
+    real_stdout = launch.claim_stdout()       # fd 1 -> stderr from here on (RCCL prints its banner to stdout); the JSON line goes to the real one
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -123,7 +124,7 @@ def main():
             "seconds_total": round(elapsed, 4), "seconds_compute_and_overlapped_gather": round(t_compute, 4),
             "seconds_host_issue": round(t_issue, 4),
             "config": {"workload": f"{F_} frames {H}x{W}x{Cin}, micro-batch {MB}, uint8 frames all-gathered per micro-batch, overlapped with compute",
-                       "gathered_bytes": int(F_) * H * W * 3}}), flush=True)
+                       "gathered_bytes": int(F_) * H * W * 3}}), file=real_stdout, flush=True)
     if use_dist:
         dist.destroy_process_group()
 

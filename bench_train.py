@@ -39,6 +39,7 @@ def main():
                                   force=os.environ.get("VSTAB_FORCE_DIST") == "1")     # child job; nothing here touches the GPU
     if rc is not None:
         raise SystemExit(rc)
+    real_stdout = launch.claim_stdout()       # fd 1 -> stderr from here on (RCCL prints its banner to stdout); the JSON line goes to the real one
     if not torch.cuda.is_available():
         raise SystemExit("bench_train.py needs a GPU")
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -99,7 +100,7 @@ def main():
         "data": "synthetic (uniform [0,1) frames, seeded He-normal weights)", "final_loss": float(loss),
         "approx_tflops": round(3.0 * gf * B * world / dt / 1e3, 2), "phases": phases,
         "config": {"workload": f"batch={B} per GPU {H}x{W}x27: train-mode forward + loss_main + backward + Adam (38.7 M parameters)"
-                               + ("; gradients averaged with one RCCL all-reduce of a 155 MB bucket" if use_dist else "")}}), flush=True)
+                               + ("; gradients averaged with one RCCL all-reduce of a 155 MB bucket" if use_dist else "")}}), file=real_stdout, flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -31,12 +31,13 @@ EXPORTS = {
     "vstab_workspace_layout": (C.c_int, [C.c_int] * 4 + [C.POINTER(VstabWsEntry), C.c_int]),
     "vstab_flownets_forward": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 +
                                [C.c_void_p, C.c_size_t, C.c_void_p]),
-    "vstab_flow_resize_scale": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] + [C.c_int] * 2 +
-                                [C.c_float] * 3 + [C.c_void_p]),
+    "vstab_flow_resize_scale": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "vstab_resize_bilinear": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]),
     "vstab_resize_bilinear_slice3": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]),
     "vstab_warp_flow": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
-    "vstab_flow_glue_warp": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float] * 3 + [C.c_void_p]),
+    "vstab_flow_glue_warp": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
+    "vstab_stabilise_originalsize": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p] * 8 +
+                                     [C.c_size_t, C.c_void_p]),
     "vstab_trace_ranges": (C.c_int, [C.c_int]),
     "vstab_hbm_profile_enable": (C.c_int, [C.c_int]),
     "vstab_hbm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),

@@ -928,13 +928,13 @@ extern "C" int vstab_profile_read_direct(vstab_ctx *ctx, double *flops15)
 }
 
 // ------------------------------------------------------------------------- glue + warp
-extern "C" int vstab_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow, float pre,
-                                       float sx, float sy, void *stream)
+extern "C" int vstab_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow, int net_h, int net_w,
+                                       void *stream)
 {
     if (!flow || !out) return fail(nullptr, VSTAB_E_STATE, "flow_resize_scale: NULL buffer");
-    if (B < 1 || h < 1 || w < 1 || oh < 1 || ow < 1) return fail(nullptr, VSTAB_E_SHAPE, "flow_resize_scale: bad shape");
+    if (B < 1 || h < 1 || w < 1 || oh < 1 || ow < 1 || net_h < 1 || net_w < 1) return fail(nullptr, VSTAB_E_SHAPE, "flow_resize_scale: bad shape");
     if (((uintptr_t)flow & 7) || ((uintptr_t)out & 7)) return fail(nullptr, VSTAB_E_ALIGN, "flow_resize_scale: 8-byte alignment");
-    HIP_TRY(nullptr, launch_flow_resize_scale(flow, B, h, w, out, oh, ow, pre, sx, sy, (hipStream_t)stream));
+    HIP_TRY(nullptr, launch_flow_resize_scale(flow, B, h, w, out, oh, ow, net_h, net_w, (hipStream_t)stream));
     return VSTAB_OK;
 }
 
@@ -969,17 +969,31 @@ extern "C" int vstab_warp_flow(const float *img, const float *flow, float *out, 
 }
 
 extern "C" int vstab_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *warped, int oh,
-                                    int ow, int C, float pre, float sx, float sy, void *stream)
+                                    int ow, int C, int net_h, int net_w, void *stream)
 {
     if (!flow || !img || !warped) return fail(nullptr, VSTAB_E_STATE, "flow_glue_warp: NULL buffer");
-    if (B < 1 || h < 1 || w < 1 || oh < 1 || ow < 1) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: bad shape");
+    if (B < 1 || h < 1 || w < 1 || oh < 1 || ow < 1 || net_h < 1 || net_w < 1) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: bad shape");
     if (C != 3 || w < 2) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: C must be 3 and w >= 2 (use flow_resize_scale + warp_flow otherwise)");
     if ((long long)B * oh * ow >= (1ll << 31)) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp: B*oh*ow must be < 2^31");
     if (((uintptr_t)flow & 7) || (((uintptr_t)img | (uintptr_t)outflow | (uintptr_t)warped) & 15))
         return fail(nullptr, VSTAB_E_ALIGN, "flow_glue_warp: flow 8-byte, img/outflow/warped 16-byte alignment");
     TraceRange range("flow_glue+tf_warp");
-    HIP_TRY(nullptr, launch_flow_glue_warp(flow, B, h, w, img, outflow, warped, oh, ow, C, pre, sx, sy, (hipStream_t)stream));
+    HIP_TRY(nullptr, launch_flow_glue_warp(flow, B, h, w, img, outflow, warped, oh, ow, C, net_h, net_w, (hipStream_t)stream));
     return VSTAB_OK;
+}
+
+// evaluate_originalSize's whole graph (main:491-514) behind ONE call: the network, then the flow glue + tf_warp launch.
+extern "C" int vstab_stabilise_originalsize(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, const float *frame, int oh,
+                                            int ow, float *pf6, float *pf5, float *pf4, float *pf3, float *pf2, float *outflow,
+                                            float *warped, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!frame || !warped) return fail(ctx, VSTAB_E_STATE, "stabilise_originalsize: NULL buffer");
+    if (oh < 1 || ow < 1) return fail(ctx, VSTAB_E_SHAPE, "stabilise_originalsize: bad output size");
+    const int rc = vstab_flownets_forward(ctx, feats, B, H, W, Cin, pf6, pf5, pf4, pf3, pf2, workspace, workspace_bytes, stream);
+    if (rc != VSTAB_OK) return rc;
+    const int rc2 = vstab_flow_glue_warp(pf2, B, H - 2, W - 2, frame, outflow, warped, oh, ow, 3, H, W, stream);
+    if (rc2 != VSTAB_OK && ctx) ctx->err = g_last_error;
+    return rc2;
 }
 
 extern "C" int vstab_hbm_profile_enable(int mode)

@@ -373,44 +373,52 @@ hipError_t launch_pf2(const float *T, int B, int h2, int w2, const float *bias2,
 }
 
 // ---------------------------------------------------------------------------------
-// main:497-498: out = resize_images(flow * pre, [oh, ow]); x *= sx; y *= sy.
+// main:497-498: out = resize_images(flow*net_h/h, [oh, ow]); x = x*ow/net_w; y = y*oh/net_h -- every `*` and `/` of the reference's
+// expression is its own TF op, i.e. its own fp32 rounding (a*b/c parses as (a*b)/c), and is evaluated as such here.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void flow_resize_scale_kernel(const float *__restrict__ flow, int B, int h, int w,
-                                                                float *__restrict__ out, int oh, int ow, float pre,
-                                                                float sx, float sy, float ry, float rx)
+// source flow grid + the constants of main:497-498 as the reference's graph applies them, one TF op (one fp32 rounding) each:
+//   predict_flow2*384.0/382   ->  (t * nh) / dh     nh = net_h, dh = the flow's own height
+//   outflow[...,0:1]*out_w/512 -> (v * mx) / dx     mx = out_w, dx = net_w;   y: (v * my) / dy, my = out_h, dy = net_h
+struct GlueParams { int h, w; float nh, dh, mx, dx, my, dy, ry, rx; };
+__device__ __forceinline__ float glue_pre(float t, const GlueParams &G) { return (t * G.nh) / G.dh; }
+__host__ inline GlueParams glue_params(int h, int w, int oh, int ow, int net_h, int net_w)
+{
+    return GlueParams{h, w, (float)net_h, (float)h, (float)ow, (float)net_w, (float)oh, (float)net_h, (float)h / (float)oh, (float)w / (float)ow};
+}
+__global__ __launch_bounds__(256) void flow_resize_scale_kernel(const float *__restrict__ flow, int B, float *__restrict__ out, int oh, int ow,
+                                                                GlueParams G)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)B * oh * ow;
     if (idx >= total) return;
+    const int h = G.h, w = G.w;
     const int n = (int)(idx / (oh * ow));
     const int rem = (int)(idx - (long long)n * oh * ow);
     const int oy = rem / ow, ox = rem - oy * ow;
-    const Lerp Y = legacy_coord(oy, ry, h), X = legacy_coord(ox, rx, w);
+    const Lerp Y = legacy_coord(oy, G.ry, h), X = legacy_coord(ox, G.rx, w);
     const f32x2 *b = reinterpret_cast<const f32x2 *>(flow) + (long long)n * h * w;
     f32x2 tl = b[Y.lo * w + X.lo], tr = b[Y.lo * w + X.hi], bl = b[Y.hi * w + X.lo], br = b[Y.hi * w + X.hi];
     f32x2 o;
-    o.x = lerp2(tl.x * pre, tr.x * pre, bl.x * pre, br.x * pre, X.t, Y.t) * sx;
-    o.y = lerp2(tl.y * pre, tr.y * pre, bl.y * pre, br.y * pre, X.t, Y.t) * sy;
+    o.x = (lerp2(glue_pre(tl.x, G), glue_pre(tr.x, G), glue_pre(bl.x, G), glue_pre(br.x, G), X.t, Y.t) * G.mx) / G.dx;
+    o.y = (lerp2(glue_pre(tl.y, G), glue_pre(tr.y, G), glue_pre(bl.y, G), glue_pre(br.y, G), X.t, Y.t) * G.my) / G.dy;
     reinterpret_cast<f32x2 *>(out)[idx] = o;
 }
 
 // tiled forms (defined next to the warp's tile kernel below); they return hipErrorNotSupported when a shape is not theirs
-static hipError_t launch_glue_tile(const float *flow, int B, int h, int w, float *out, int oh, int ow, float pre, float sx, float sy,
-                                   hipStream_t stream);
+static hipError_t launch_glue_tile(const float *flow, int B, float *out, int oh, int ow, const GlueParams &G, hipStream_t stream);
 static hipError_t launch_resize3_tile(const float *x, int B, int h, int w, int Cs, int c_off, float *out, int oh, int ow, hipStream_t stream);
 
-hipError_t launch_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow, float pre, float sx,
-                                    float sy, hipStream_t stream)
+hipError_t launch_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow, int net_h, int net_w, hipStream_t stream)
 {
     const long long total = (long long)B * oh * ow;
+    const GlueParams G = glue_params(h, w, oh, ow, net_h, net_w);
     {
-        const hipError_t e = launch_glue_tile(flow, B, h, w, out, oh, ow, pre, sx, sy, stream);
+        const hipError_t e = launch_glue_tile(flow, B, out, oh, ow, G, stream);
         if (e != hipErrorNotSupported) return e;
     }
     // same size: TF returns the tensor unchanged; scale 1.0 gives lo = i, t = 0 -> identical values
-    const float ry = (float)h / (float)oh, rx = (float)w / (float)ow;
     return launch_timed(HBM_SLOT_GLUE, 8.0 * B * h * w + 8.0 * total, flow_resize_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
-                        stream, flow, B, h, w, out, oh, ow, pre, sx, sy, ry, rx);
+                        stream, flow, B, out, oh, ow, G);
 }
 
 // generic NHWC legacy-bilinear resize (main:806; one thread per output element)
@@ -505,7 +513,6 @@ __global__ __launch_bounds__(256) void warp_flow_kernel(const float *__restrict_
 // window (bounding box of the tile's corners, coalesced fill, gathers from LDS) and its persistent, flow-prefetching form.
 // ---------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(4))) rgb3 { float r, g, b; };
-struct GlueParams { int h, w; float pre, sx, sy, ry, rx; };      // source flow grid + the constants of main:497-498
 struct __attribute__((packed, aligned(8))) flow2 { f32x2 a, b; };     // two neighbouring flow pixels (8-byte aligned, 16 bytes)
 
 // a workgroup owns a TH x TW tile of ONE sample's output pixels; a wave instruction works on a WH x WW patch (WH * WW = 64)
@@ -554,8 +561,8 @@ __global__ __launch_bounds__(256) void warp3_tile_kernel(const float *__restrict
         }
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            f[j].x = lerp2(tl[j].x * G.pre, tr[j].x * G.pre, bl[j].x * G.pre, br[j].x * G.pre, X[j].t, Y[j].t) * G.sx;
-            f[j].y = lerp2(tl[j].y * G.pre, tr[j].y * G.pre, bl[j].y * G.pre, br[j].y * G.pre, X[j].t, Y[j].t) * G.sy;
+            f[j].x = (lerp2(glue_pre(tl[j].x, G), glue_pre(tr[j].x, G), glue_pre(bl[j].x, G), glue_pre(br[j].x, G), X[j].t, Y[j].t) * G.mx) / G.dx;
+            f[j].y = (lerp2(glue_pre(tl[j].y, G), glue_pre(tr[j].y, G), glue_pre(bl[j].y, G), glue_pre(br[j].y, G), X[j].t, Y[j].t) * G.my) / G.dy;
             if (WRITE_FLOW && ok[j]) reinterpret_cast<f32x2 *>(outflow)[n * HW + (long long)yy[j] * W + xx[j]] = f[j];
         }
     } else {
@@ -646,12 +653,12 @@ hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int
 // main:497-514 as one launch: outflow = glue(flow [B,h,w,2]) at [B,oh,ow,2] (written if `outflow` is given), warped =
 // tf_warp(img [B,oh,ow,3], outflow).  C must be 3 (callers fall back to the two kernels otherwise).
 hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *out, int oh, int ow,
-                                 int C, float pre, float sx, float sy, hipStream_t stream)
+                                 int C, int net_h, int net_w, hipStream_t stream)
 {
     const long long total = (long long)B * oh * ow;
     if (total == 0) return hipSuccess;
     if (!warp3_ok(img, out, outflow, B, oh, ow, C) || w < 2) return hipErrorInvalidValue;
-    const GlueParams G{h, w, pre, sx, sy, (float)h / (float)oh, (float)w / (float)ow};
+    const GlueParams G = glue_params(h, w, oh, ow, net_h, net_w);
     const double src = 8.0 * B * h * w;                       // the source flow is read once from HBM (its 4 taps per pixel hit in cache)
     if (outflow) return launch_warp3<true, true>(HBM_SLOT_GLUE_WARP, src + 32.0 * total, img, flow, out, outflow, B, oh, ow, G, stream);
     return launch_warp3<true, false>(HBM_SLOT_GLUE_WARP, src + 24.0 * total, img, flow, out, nullptr, B, oh, ow, G, stream);
@@ -697,8 +704,8 @@ __global__ __launch_bounds__(256) void glue_tile_kernel(const float *__restrict_
         const bool l1 = X[j].lo != xb[j], h1 = X[j].hi != xb[j];
         const f32x2 tl = l1 ? top[j].b : top[j].a, tr = h1 ? top[j].b : top[j].a, bl = l1 ? bot[j].b : bot[j].a, br = h1 ? bot[j].b : bot[j].a;
         f32x2 o;
-        o.x = lerp2(tl.x * G.pre, tr.x * G.pre, bl.x * G.pre, br.x * G.pre, X[j].t, Y[j].t) * G.sx;
-        o.y = lerp2(tl.y * G.pre, tr.y * G.pre, bl.y * G.pre, br.y * G.pre, X[j].t, Y[j].t) * G.sy;
+        o.x = (lerp2(glue_pre(tl.x, G), glue_pre(tr.x, G), glue_pre(bl.x, G), glue_pre(br.x, G), X[j].t, Y[j].t) * G.mx) / G.dx;
+        o.y = (lerp2(glue_pre(tl.y, G), glue_pre(tr.y, G), glue_pre(bl.y, G), glue_pre(br.y, G), X[j].t, Y[j].t) * G.my) / G.dy;
         if (STAGE) {
             const int q = j * 4 + wave;
             *reinterpret_cast<f32x2 *>(stage + (((q / PPR) * WH + lane / WW) * TW + (q % PPR) * WW + lane % WW) * 2) = o;
@@ -721,12 +728,11 @@ __global__ __launch_bounds__(256) void glue_tile_kernel(const float *__restrict_
     }
 }
 
-static hipError_t launch_glue_tile(const float *flow, int B, int h, int w, float *out, int oh, int ow, float pre, float sx, float sy,
-                                   hipStream_t stream)
+static hipError_t launch_glue_tile(const float *flow, int B, float *out, int oh, int ow, const GlueParams &G, hipStream_t stream)
 {
+    const int h = G.h, w = G.w;
     const long long tiles = (long long)((ow + WT_TW - 1) / WT_TW) * ((oh + WT_TH - 1) / WT_TH) * B;
     if (w < 2 || tiles >= (1ll << 31) || (long long)B * oh * ow >= (1ll << 31) || ((uintptr_t)out & 15)) return hipErrorNotSupported;
-    const GlueParams G{h, w, pre, sx, sy, (float)h / (float)oh, (float)w / (float)ow};
     const int tx = (ow + WT_TW - 1) / WT_TW, ty = (oh + WT_TH - 1) / WT_TH;
     const double bytes = 8.0 * B * h * w + 8.0 * B * oh * ow;
     if ((ow & 1) == 0)

@@ -1,11 +1,10 @@
 // Samplers named by the reference's spatial_transformer.py and warp.py (BASELINE configs[2]'s
 // "spatial_transformer warp").  HBM-bound 4-tap gathers, coordinates generated in-kernel (no grid tensor is materialised).
-// 3-channel frames run on st3_tile_kernel (2-D tiles, source window staged in LDS by aligned 16-byte loads, rows leaving as
-// 16-byte stores); other channel counts on the one-thread-per-pixel kernels.
+// 3-channel frames run on st3_tile_kernel (2-D tiles, 3-dword corner gathers, rows leaving as 16-byte stores); other channel
+// counts on the one-thread-per-pixel kernels.
 // -ffp-contract=off keeps the weight arithmetic the reference's op-by-op fp32 sequence.
 #include "vstab_internal.h"
 #include "hbm_profile.h"
-#include <cstdlib>
 
 namespace vstab {
 
@@ -148,41 +147,23 @@ __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__res
 //   FAM_ST_THETA  Affine/ProjectiveTransformer.transform   (spatial_transformer.py:400-452, 539-608)
 //   FAM_ST_COORDS bilinear_interp with explicit x, y       (spatial_transformer.py:902-964)
 //   FAM_HOMOG     warp.transformImage / transformCropImage (warp.py:46-129)
-// A direct gather of 12-byte pixels is bound by the L1 tag pipe, not by HBM (profiles/README.md, "r02 warp study": a 12-byte
-// pixel per lane is 1.75 64-byte lookups per four lanes and a pixel has four corners).  tf_warp has to live with that -- its
-// sample points come from a flow field, and finding their bounding box costs a dependent memory round trip.  Here the sample
-// points are pure arithmetic on the pixel index (or one coalesced load), so the workgroup
-//   1. computes the four taps of its 16 x 32 output pixels (2 per thread, 4 x 16 wave patches) and reduces their bounding box
-//      (DPP wave reductions, one LDS exchange),
-//   2. copies that window of the source into LDS with ALIGNED 16-byte loads (one lookup per 64 bytes; the window starts at a
-//      column that is a multiple of 4 pixels = 48 bytes, rows are W*12 bytes with W % 4 == 0),
-//   3. takes the four corners of every pixel from LDS (row pitch = 16 mod 32 floats: the two rows a 32-lane group reads fall
-//      on disjoint banks),
-//   4. re-uses the LDS for the finished tile and writes it as 16-byte stores of whole 384-byte rows.
-// A window that does not fit (strong minification, a projective map whose z changes sign inside the tile) falls back to direct
-// 3-dword gathers for that tile (workgroup-uniform); W % 4 != 0 or unaligned bases use the direct form throughout.  The
-// arithmetic is st_sample_pixel's / homography_warp_kernel's statement for statement: bit-identical results.
+// Shaped like tf_warp's tile kernel (flow_ops.hip, warp3_tile_kernel; profiles/README.md "r02 warp study"): a workgroup owns a
+// 16 x 32 tile of ONE sample's output pixels and a wave instruction works on a 4 x 16 patch, so the lines a gather touches are a
+// compact 2-D footprint under any rotation; one 3-dword load per corner; results leave through LDS as 16-byte stores of whole
+// 384-byte tile rows (ow % 4 == 0; 12-byte stores otherwise); XCD-contiguous tile order.
+// Measured and rejected (profiles/README.md "r03 sampler study", the variant is in commit 2076632): staging the tile's source window in LDS
+// (bounding box by DPP reductions, aligned 16-byte fill, corners from LDS) cuts the L1 lookups 3x (0.50 instead of 1.56 per
+// pixel) and is 1.7x SLOWER (0.34-0.39 of 8 TB/s against 0.53-0.64): four barriers and three dependent phases per tile.
+// The arithmetic is st_sample_pixel's / homography_warp_kernel's statement for statement: bit-identical results.
 // ---------------------------------------------------------------------------------
 enum { FAM_ST_THETA = 0, FAM_ST_COORDS = 1, FAM_HOMOG = 2 };
 struct __attribute__((packed, aligned(4))) rgb3 { float r, g, b; };
-struct StSrc { const float *theta; const float *x; const float *y; int tdim; };    // theta [B,tdim] (M [B,9] for FAM_HOMOG) or x, y [B*oh*ow]
+// theta [B,tdim] (M [B,9] for FAM_HOMOG) or x, y [B*oh*ow]; the grid steps 2/(n-1) are divided once on the host (the same IEEE
+// quotient lin11 / homography_warp_kernel compute per pixel): fp32 for tf.linspace, fp64 for np.linspace
+struct StSrc { const float *theta; const float *x; const float *y; int tdim; float sx, sy; double dsx, dsy; };
 
 constexpr int ST_TW = 32, ST_TH = 16, ST_PPT = 2, ST_WW = 16, ST_WH = 4, ST_PPR = ST_TW / ST_WW;
-constexpr int ST_LDS = 6144;            // floats (24 KB): the source window, then the finished tile (16*32*3 = 1536)
-static_assert(ST_WH * (4 * ST_PPT) / ST_PPR == ST_TH && ST_TH * ST_TW * 3 <= ST_LDS, "tile shape");
-
-__device__ __forceinline__ int wave_min_i32(int v)
-{
-    // inclusive DPP scan (row_shr 1,2,4,8; row_bcast 15 into rows 1,3; row_bcast 31 into rows 2,3): lane 63 holds the result
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
-    return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
+static_assert(ST_WH * (4 * ST_PPT) / ST_PPR == ST_TH, "tile shape");
 
 // the four taps of one output pixel: image coordinates clamped into the image (what is addressed), validity per axis (what
 // counts: an invalid tap reads as zero) and the blend weights (ST: w00, w01, w10, w11; homography: xr, yr)
@@ -210,10 +191,10 @@ __device__ __forceinline__ Taps st_taps(float xn, float yn, int H, int W)       
     return t;
 }
 
-__device__ __forceinline__ Taps homog_taps(const float *__restrict__ m, int ox, int oy, int oh, int ow, int Hi, int Wi)   // homography_warp_kernel's
+__device__ __forceinline__ Taps homog_taps(const float *__restrict__ m, int ox, int oy, double dsx, double dsy, int Hi, int Wi)   // homography_warp_kernel's
 {
-    const float X = ow > 1 ? (float)(-1.0 + (double)ox * (2.0 / (double)(ow - 1))) : -1.0f;
-    const float Y = oh > 1 ? (float)(-1.0 + (double)oy * (2.0 / (double)(oh - 1))) : -1.0f;
+    const float X = (float)(-1.0 + (double)ox * dsx);
+    const float Y = (float)(-1.0 + (double)oy * dsy);
     const float xh = (m[0] * X + m[1] * Y) + m[2];
     const float yh = (m[3] * X + m[4] * Y) + m[5];
     const float zh = (m[6] * X + m[7] * Y) + m[8];
@@ -240,13 +221,12 @@ __device__ __forceinline__ float st_blend(const Taps &t, float I00, float I01, f
     return ((t.w0 * I00 + t.w1 * I01) + t.w2 * I10) + t.w3 * I11;      // tf.add_n order
 }
 
-template <int FAM, bool WINDOW, bool STAGE>
+template <int FAM, bool STAGE>
 __global__ __launch_bounds__(256) void st3_tile_kernel(const float *__restrict__ img, int B, int H, int W, StSrc S,
                                                        float *__restrict__ out, int oh, int ow, int tiles_x, int tiles_y)
 {
     constexpr int TW = ST_TW, TH = ST_TH, PPT = ST_PPT, WW = ST_WW, WH = ST_WH, PPR = ST_PPR;
-    __shared__ __attribute__((aligned(16))) float lds[WINDOW ? ST_LDS : (STAGE ? ST_TH * ST_TW * 3 : 4)];
-    __shared__ int red[4][4];
+    __shared__ __attribute__((aligned(16))) float lds[STAGE ? ST_TH * ST_TW * 3 : 4];
     unsigned bx, by, bz;
     xcd_remap_calc(gridDim.x, 1, 1, blockIdx.x, bx, by, bz);
     const int tpi = tiles_x * tiles_y;
@@ -271,7 +251,7 @@ __global__ __launch_bounds__(256) void st3_tile_kernel(const float *__restrict__
         ok[j] = y < oh && x < ow;
         yy[j] = min(y, oh - 1); xx[j] = min(x, ow - 1);          // a pixel beyond the output repeats an edge pixel of this tile (not stored)
         if (FAM == FAM_ST_THETA) {
-            const float xt = lin11(xx[j], ow), yt = lin11(yy[j], oh);
+            const float xt = -1.0f + (float)xx[j] * S.sx, yt = -1.0f + (float)yy[j] * S.sy;
             float xs = (th[0] * xt + th[1] * yt) + th[2];
             float ys = (th[3] * xt + th[4] * yt) + th[5];
             if (S.tdim == 8) {
@@ -285,63 +265,16 @@ __global__ __launch_bounds__(256) void st3_tile_kernel(const float *__restrict__
             const long long i = ((long long)n * oh + yy[j]) * ow + xx[j];
             t[j] = st_taps(S.x[i], S.y[i], H, W);
         } else {
-            t[j] = homog_taps(th, xx[j], yy[j], oh, ow, H, W);
+            t[j] = homog_taps(th, xx[j], yy[j], S.dsx, S.dsy, H, W);
         }
     }
     const rgb3 *b = reinterpret_cast<const rgb3 *>(img) + (long long)n * HW;
     rgb3 I00[PPT], I01[PPT], I10[PPT], I11[PPT];
-    bool windowed = false;
-    if (WINDOW) {
-        int mnx = t[0].xa, mxx = t[0].xb, mny = t[0].ya, mxy = t[0].yb;
 #pragma unroll
-        for (int j = 1; j < PPT; ++j) { mnx = min(mnx, t[j].xa); mxx = max(mxx, t[j].xb); mny = min(mny, t[j].ya); mxy = max(mxy, t[j].yb); }
-        {
-            const int a = wave_min_i32(mnx), c = wave_max_i32(mxx), d = wave_min_i32(mny), e = wave_max_i32(mxy);
-            if (lane == 0) { red[wave][0] = a; red[wave][1] = c; red[wave][2] = d; red[wave][3] = e; }
-        }
-        __syncthreads();
-        const int X0 = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0])) & ~3;     // multiple of 4 pixels = 48 bytes
-        const int X1 = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
-        const int Y0 = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
-        const int Y1 = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
-        const int n4 = ((X1 - X0 + 1) * 3 + 3) >> 2, wh = Y1 - Y0 + 1;                     // float4s per window row, rows
-        const int P = ((n4 * 4 + 15) & ~31) + 16;                                         // row pitch in floats: >= 4 n4, = 16 mod 32
-        windowed = wh * P <= ST_LDS;                                                       // workgroup-uniform
-        if (windowed) {
-            // half a wave per window row (windows are ~28 float4 wide), four rows of loads in flight per thread
-            const long long total = (long long)B * HW * 3;
-            const long long base = ((long long)n * HW + (long long)Y0 * W + X0) * 3;        // multiple of 4 floats
-            const int rsub = wave * 2 + (lane >> 5), l32 = lane & 31;
-            for (int r0 = rsub; r0 < wh; r0 += 32)
-                for (int c4 = l32; c4 < n4; c4 += 32) {
-                    f32x4 v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int r = r0 + 8 * k;
-                        const long long off = base + (long long)r * W * 3 + c4 * 4;
-                        v[k] = (r < wh && off + 4 <= total) ? *reinterpret_cast<const f32x4 *>(img + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (r0 + 8 * k < wh) *reinterpret_cast<f32x4 *>(lds + (r0 + 8 * k) * P + c4 * 4) = v[k];
-                }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const int ra = (t[j].ya - Y0) * P - X0 * 3, rb = (t[j].yb - Y0) * P - X0 * 3;
-                I00[j] = *reinterpret_cast<const rgb3 *>(lds + ra + t[j].xa * 3); I01[j] = *reinterpret_cast<const rgb3 *>(lds + ra + t[j].xb * 3);
-                I10[j] = *reinterpret_cast<const rgb3 *>(lds + rb + t[j].xa * 3); I11[j] = *reinterpret_cast<const rgb3 *>(lds + rb + t[j].xb * 3);
-            }
-        }
+    for (int j = 0; j < PPT; ++j) {
+        I00[j] = b[t[j].ya * W + t[j].xa]; I01[j] = b[t[j].ya * W + t[j].xb];
+        I10[j] = b[t[j].yb * W + t[j].xa]; I11[j] = b[t[j].yb * W + t[j].xb];
     }
-    if (!windowed) {
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            I00[j] = b[t[j].ya * W + t[j].xa]; I01[j] = b[t[j].ya * W + t[j].xb];
-            I10[j] = b[t[j].yb * W + t[j].xa]; I11[j] = b[t[j].yb * W + t[j].xb];
-        }
-    }
-    if (WINDOW && STAGE) __syncthreads();              // every corner has been read: the window becomes the store stage
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const bool v00 = t[j].vxa && t[j].vya, v01 = t[j].vxb && t[j].vya, v10 = t[j].vxa && t[j].vyb, v11 = t[j].vxb && t[j].vyb;
@@ -373,18 +306,17 @@ __global__ __launch_bounds__(256) void st3_tile_kernel(const float *__restrict__
 
 // picks the instantiation for a 3-channel launch; hipErrorNotSupported when the shape is not the tile kernel's
 template <int FAM>
-static hipError_t launch_st3(int slot, const float *img, int B, int H, int W, const StSrc &S, float *out, int oh, int ow, hipStream_t stream)
+static hipError_t launch_st3(int slot, const float *img, int B, int H, int W, StSrc S, float *out, int oh, int ow, hipStream_t stream)
 {
+    S.sx = ow > 1 ? 2.0f / (float)(ow - 1) : 0.0f; S.sy = oh > 1 ? 2.0f / (float)(oh - 1) : 0.0f;
+    S.dsx = ow > 1 ? 2.0 / (double)(ow - 1) : 0.0; S.dsy = oh > 1 ? 2.0 / (double)(oh - 1) : 0.0;
     const long long tx = (ow + ST_TW - 1) / ST_TW, ty = (oh + ST_TH - 1) / ST_TH, tiles = tx * ty * B;
     if (tiles >= (1ll << 31) || (long long)B * H * W * 3 >= (1ll << 31) || (long long)B * oh * ow * 3 >= (1ll << 31)) return hipErrorNotSupported;
-    const bool window = (W & 3) == 0 && ((uintptr_t)img & 15) == 0 && !getenv("VSTAB_ST_NO_WINDOW");
     const bool stage = (ow & 3) == 0 && ((uintptr_t)out & 15) == 0;
     const double bytes = (FAM == FAM_ST_COORDS ? 32.0 : 24.0) * B * oh * ow;       // every output pixel reads ~one source pixel, writes one (+ x, y)
     const dim3 grid((unsigned)tiles), block(256);
-#define ST3_GO(WIN, STG) launch_timed(slot, bytes, st3_tile_kernel<FAM, WIN, STG>, grid, block, stream, img, B, H, W, S, out, oh, ow, (int)tx, (int)ty)
-    if (window) return stage ? ST3_GO(true, true) : ST3_GO(true, false);
-    return stage ? ST3_GO(false, true) : ST3_GO(false, false);
-#undef ST3_GO
+    if (stage) return launch_timed(slot, bytes, st3_tile_kernel<FAM, true>, grid, block, stream, img, B, H, W, S, out, oh, ow, (int)tx, (int)ty);
+    return launch_timed(slot, bytes, st3_tile_kernel<FAM, false>, grid, block, stream, img, B, H, W, S, out, oh, ow, (int)tx, (int)ty);
 }
 
 // warp.vec2mtrx (warp.py:25-43): sl(3) / affine generator -> matrix exponential by Taylor series,
@@ -422,7 +354,7 @@ hipError_t launch_st_interp(const float *img, int B, int H, int W, int C, const 
     const int npix = oh * ow;
     const long long total = (long long)B * npix;
     if (C == 3) {
-        const hipError_t e = launch_st3<FAM_ST_COORDS>(HBM_SLOT_ST, img, B, H, W, StSrc{nullptr, x, y, 0}, out, oh, ow, stream);
+        const hipError_t e = launch_st3<FAM_ST_COORDS>(HBM_SLOT_ST, img, B, H, W, StSrc{nullptr, x, y, 0, 0.f, 0.f, 0., 0.}, out, oh, ow, stream);
         if (e != hipErrorNotSupported) return e;
     }
     st_interp_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, B, H, W, C, x, y, npix, out);
@@ -434,7 +366,7 @@ hipError_t launch_st_transform(const float *img, int B, int H, int W, int C, con
 {
     const long long total = (long long)B * oh * ow;
     if (C == 3) {
-        const hipError_t e = launch_st3<FAM_ST_THETA>(HBM_SLOT_ST, img, B, H, W, StSrc{theta, nullptr, nullptr, tdim}, out, oh, ow, stream);
+        const hipError_t e = launch_st3<FAM_ST_THETA>(HBM_SLOT_ST, img, B, H, W, StSrc{theta, nullptr, nullptr, tdim, 0.f, 0.f, 0., 0.}, out, oh, ow, stream);
         if (e != hipErrorNotSupported) return e;
     }
     st_transform_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, B, H, W, C, theta, tdim, out, oh, ow);
@@ -452,7 +384,7 @@ hipError_t launch_homography_warp(const float *img, int B, int Hi, int Wi, int C
 {
     const long long total = (long long)B * oh * ow;
     if (C == 3) {
-        const hipError_t e = launch_st3<FAM_HOMOG>(HBM_SLOT_HOMOG, img, B, Hi, Wi, StSrc{M, nullptr, nullptr, 9}, out, oh, ow, stream);
+        const hipError_t e = launch_st3<FAM_HOMOG>(HBM_SLOT_HOMOG, img, B, Hi, Wi, StSrc{M, nullptr, nullptr, 9, 0.f, 0.f, 0., 0.}, out, oh, ow, stream);
         if (e != hipErrorNotSupported) return e;
     }
     homography_warp_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, B, Hi, Wi, C, M, out, oh, ow);

@@ -175,7 +175,7 @@ hipError_t launch_pf2(const float *T, int B, int h2, int w2, const float *bias2,
                       int h3, int w3, float *pf2, int H, int W, hipStream_t stream);
 
 hipError_t launch_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh,
-                                    int ow, float pre, float sx, float sy, hipStream_t stream);
+                                    int ow, int net_h, int net_w, hipStream_t stream);
 hipError_t launch_resize_bilinear(const float *x, int B, int h, int w, int C, float *out, int oh,
                                   int ow, hipStream_t stream);
 hipError_t launch_resize_bilinear_slice3(const float *x, int B, int h, int w, int Cs, int c_off, float *out, int oh, int ow,
@@ -187,7 +187,7 @@ enum { HBM_SLOT_WARP = 0, HBM_SLOT_GLUE = 1, HBM_SLOT_GLUE_WARP = 2, HBM_SLOT_PF
 void hbm_profile_enable(int mode);
 hipError_t hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg_bytes_sum);
 hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *out, int oh, int ow,
-                                 int C, float pre, float sx, float sy, hipStream_t stream);
+                                 int C, int net_h, int net_w, hipStream_t stream);
 // 2x2 stride-2 SAME max pool (vgg16.py:51-53), NHWC, C % 4 == 0
 hipError_t launch_maxpool2x2(const float *x, int B, int H, int W, int C, float *out, hipStream_t stream);
 // 3x3 SAME conv on a 3-channel image (VGG16 conv1_1): W HWIO [3][3][3][cout] unpacked, cout % 4 == 0, cout <= 64

@@ -75,18 +75,16 @@ def resize_images_slice3(x, c_off, size):
 
 def flow_to_output_res(predict_flow2, net_h, net_w, out_h, out_w):
     """main:497-498 with 384 -> net_h, 512 -> net_w:
-    resize_images(pf2 * net_h / pf2.shape[1], [out_h, out_w]); x *= out_w/net_w; y *= out_h/net_h."""
+    resize_images(pf2 * net_h / pf2.shape[1], [out_h, out_w]); x = x * out_w / net_w; y = y * out_h / net_h
+    (each `*` and `/` its own fp32 operation, in the reference's order)."""
     f = _f32_cuda(predict_flow2, "predict_flow2")
     B, h, w, two = f.shape
     if two != 2:
         raise ValueError("flow must have 2 channels")
-    pre = float(np.float32(net_h) / np.float32(h))
-    sx = float(np.float32(out_w) / np.float32(net_w))
-    sy = float(np.float32(out_h) / np.float32(net_h))
     out = torch.empty((B, out_h, out_w, 2), dtype=torch.float32, device=f.device)
     with torch.cuda.device(f.device):
         _lib.check(_lib.lib().vstab_flow_resize_scale(f.data_ptr(), B, h, w, out.data_ptr(), out_h, out_w,
-                                                      pre, sx, sy, runtime.stream_ptr()))
+                                                      int(net_h), int(net_w), runtime.stream_ptr()))
     return out
 
 
@@ -100,13 +98,10 @@ def flow_glue_warp(predict_flow2, frame, net_h, net_w, want_outflow=True):
     if two != 2 or img.dim() != 4 or img.shape[0] != B:
         raise ValueError(f"flow_glue_warp: flow {tuple(f.shape)} / frame {tuple(img.shape)} do not match")
     _, oh, ow, Cc = img.shape
-    pre = float(np.float32(net_h) / np.float32(h))
-    sx = float(np.float32(ow) / np.float32(net_w))
-    sy = float(np.float32(oh) / np.float32(net_h))
     outflow = torch.empty((B, oh, ow, 2), dtype=torch.float32, device=f.device) if want_outflow else None
     out = torch.empty_like(img)
     with torch.cuda.device(f.device):
         _lib.check(_lib.lib().vstab_flow_glue_warp(f.data_ptr(), B, h, w, img.data_ptr(),
                                                    outflow.data_ptr() if want_outflow else None, out.data_ptr(), oh, ow, Cc,
-                                                   pre, sx, sy, runtime.stream_ptr()))
+                                                   int(net_h), int(net_w), runtime.stream_ptr()))
     return outflow, out

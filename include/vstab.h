@@ -117,11 +117,12 @@ VSTAB_API int vstab_profile_read_direct(vstab_ctx *ctx, double *flops15);
 /* Name (as rocprofv3 prints it) of the kernel instantiation launch slot `slot` used in the last forward. */
 VSTAB_API int vstab_profile_kernel_name(vstab_ctx *ctx, int slot, char *buf, int cap);
 
-/* ---- glue: main:497-498.  out[B,oh,ow,2] = resize_images(flow * pre, [oh,ow]) with the
- * x channel then multiplied by sx and the y channel by sy (legacy TF bilinear,
- * align_corners=False; identity resample when the size already matches). */
+/* ---- glue: main:497-498 with the literals generalised (384 -> net_h, 512 -> net_w, 382 -> h = the flow's height).
+ * out[B,oh,ow,2] = resize_images(flow*net_h/h, [oh,ow]), then x = x*ow/net_w, y = y*oh/net_h, every `*` and `/`
+ * a separate fp32 operation in the reference's order ((a*b)/c) (legacy TF bilinear, align_corners=False; identity
+ * resample when the size already matches). */
 VSTAB_API int vstab_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow,
-                            float pre, float sx, float sy, void *stream);
+                            int net_h, int net_w, void *stream);
 
 /* ---- glue: main:806 / model.py:857 UpSampling2dLayer defaults.  Legacy TF bilinear
  * resize of an NHWC tensor. */
@@ -145,7 +146,15 @@ VSTAB_API int vstab_warp_flow(const float *img, const float *flow, float *out, i
  * given it is written once and not re-read.  Bit-identical to vstab_flow_resize_scale followed by vstab_warp_flow.
  * C must be 3; img/outflow/warped 16-byte aligned; B*oh*ow < 2^31. */
 VSTAB_API int vstab_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *warped,
-                         int oh, int ow, int C, float pre, float sx, float sy, void *stream);
+                         int oh, int ow, int C, int net_h, int net_w, void *stream);
+
+/* ---- evaluate_originalSize's graph (main:491-514) as ONE call: vstab_flownets_forward, then vstab_flow_glue_warp with the
+ * constants of main:497-498 (net_h = H, net_w = W, the flow's height H-2) on a 3-channel frame [B,oh,ow,3].  Every
+ * output buffer is the caller's (pre-allocated once, re-used every step): a step is one call and no allocation.  `outflow` may
+ * be NULL.  Same results as the two calls. */
+VSTAB_API int vstab_stabilise_originalsize(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, const float *frame,
+                                           int oh, int ow, float *pf6, float *pf5, float *pf4, float *pf3, float *pf2,
+                                           float *outflow, float *warped, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- roctx ranges: with on = 1 every layer of vstab_flownets_forward (conv1 .. conv6_1, predict_flowN+upsample, deconvN,
  * predict_flow2) and the glue/warp launches run inside a named roctx range, so a `rocprofv3 --marker-trace --kernel-trace`

@@ -179,12 +179,14 @@ void vo_flow_to_output_res(const double *pf2, int B, int h, int w, int net_h, in
 {
     size_t n = (size_t)B * h * w * 2;
     double *tmp = (double *)malloc(sizeof(double) * n);
-    double s = (double)((float)net_h / (float)h);
-    for (size_t i = 0; i < n; ++i) tmp[i] = pf2[i] * s;
+    /* the graph's op sequence: (pf2 * net_h) / h, resize, (x * ow) / net_w, (y * oh) / net_h */
+    for (size_t i = 0; i < n; ++i) tmp[i] = (pf2[i] * (double)net_h) / (double)h;
     vo_resize_bilinear(tmp, B, h, w, 2, oh, ow, out);
     free(tmp);
-    double sx = (double)((float)ow / (float)net_w), sy = (double)((float)oh / (float)net_h);
-    for (size_t i = 0; i < (size_t)B * oh * ow; ++i) { out[2 * i] *= sx; out[2 * i + 1] *= sy; }
+    for (size_t i = 0; i < (size_t)B * oh * ow; ++i) {
+        out[2 * i] = (out[2 * i] * (double)ow) / (double)net_w;
+        out[2 * i + 1] = (out[2 * i + 1] * (double)oh) / (double)net_h;
+    }
 }
 
 /* ---- whole network.  wts: 88 pointers in this order:

@@ -228,15 +228,15 @@ def flownetS_pyramid(feats, weights: Dict[str, np.ndarray], dtype=torch.float64,
 
 # --------------------------------------------------------------------------- glue
 def flow_to_output_res(pf2, net_h: int, net_w: int, out_h: int, out_w: int):
-    """main:497-498 with the literals generalised (384 -> net_h, 512 -> net_w):
-    outflow = resize_images(pf2 * net_h / pf2.shape[1], [out_h, out_w]);
-    x *= out_w / net_w; y *= out_h / net_h."""
+    """main:497-498 with the literals generalised (384 -> net_h, 512 -> net_w), as the graph's op sequence:
+        outflow = resize_images(predict_flow2*384.0/predict_flow2.shape[1], [out_h, out_w])     # (pf2 * 384.0) / 382
+        outflow = concat([outflow[...,0:1]*out_w/512, outflow[...,1:2]*out_h/384], 3)           # (f * out_w) / 512, (f * out_h) / 384
+    Python parses a*b/c as (a*b)/c and TF builds one op per operator: a multiply by the numerator, then a divide by the
+    denominator, each rounded to the tensor's dtype -- NOT one multiply by the quotient (which differs by <= 1 ulp)."""
     dt = pf2.dtype
-    s = torch.tensor(np.float32(net_h) / np.float32(pf2.shape[1]), dtype=dt)
-    f = resize_bilinear_legacy(pf2 * s, out_h, out_w)
-    sx = torch.tensor(np.float32(out_w) / np.float32(net_w), dtype=dt)
-    sy = torch.tensor(np.float32(out_h) / np.float32(net_h), dtype=dt)
-    return torch.stack([f[..., 0] * sx, f[..., 1] * sy], dim=3)
+    c = lambda v: torch.tensor(float(v), dtype=dt)
+    f = resize_bilinear_legacy((pf2 * c(net_h)) / c(pf2.shape[1]), out_h, out_w)
+    return torch.stack([(f[..., 0] * c(out_w)) / c(net_w), (f[..., 1] * c(out_h)) / c(net_h)], dim=3)
 
 
 # --------------------------------------------------------------------------- warp

@@ -85,9 +85,57 @@ def test_fused_glue_warp_bit_identical(B, hn, wn, oh, ow):
     assert torch.equal(of, of_ref) and torch.equal(wp, wp_ref)
     none, wp2 = vs.flow_glue_warp(pf2, frame, hn, wn, want_outflow=False)
     assert none is None and torch.equal(wp2, wp_ref)
-    cpu_of = vo.flow_to_output_res(pf2.cpu(), hn, wn, oh, ow).float()
-    assert maxabs(of, cpu_of) <= 2e-5
+    # the glue is the graph's op sequence -- (pf2*net_h)/h, legacy bilinear, (x*ow)/net_w, (y*oh)/net_h, one fp32 rounding per
+    # TF op (main:497-498) -- in the kernels as in the fp32 oracle: identical bits
+    cpu_of = vo.flow_to_output_res(pf2.cpu(), hn, wn, oh, ow)
+    assert cpu_of.dtype == torch.float32 and torch.equal(of.cpu(), cpu_of)
     assert torch.equal(wp.cpu(), vo.tf_warp(frame.cpu(), of.cpu(), oh, ow, torch.float32))
+
+
+def test_one_call_stabiliser_bit_identical_and_reuses_its_buffers():
+    # vstab_stabilise_originalsize (one library call, outputs allocated once) against the two-call path
+    w = wts.synthetic_weights(seed=3, cin=27, random_bn=True, flow_gain=2.0)
+    runtime.reset()
+    vs.assign_weights(w)
+    g = torch.Generator().manual_seed(5)
+    for (B, H, W, oh, ow) in ((2, 64, 96, 64, 96), (1, 70, 90, 96, 120)):
+        feats = torch.rand(B, H, W, 27, generator=g).cuda()
+        frame = torch.rand(B, oh, ow, 3, generator=g).cuda()
+        flows, outflow, warped = vs.stabilise_originalsize(feats, frame)
+        stab = vs.OriginalSizeStabiliser(B, H, W, 27, oh, ow)
+        f2, o2, w2 = stab(feats, frame)
+        for k in vo.FLOW_KEYS:
+            assert torch.equal(f2[k], flows[k]), k
+        assert torch.equal(o2, outflow) and torch.equal(w2, warped)
+        ptrs = (w2.data_ptr(), o2.data_ptr(), f2["predict_flow2"].data_ptr())
+        feats2 = torch.rand(B, H, W, 27, generator=g).cuda()
+        f3, o3, w3 = stab(feats2, frame)
+        assert (w3.data_ptr(), o3.data_ptr(), f3["predict_flow2"].data_ptr()) == ptrs          # same buffers, new contents
+        assert torch.equal(w3, vs.stabilise_originalsize(feats2, frame)[2])
+        nof = vs.OriginalSizeStabiliser(B, H, W, 27, oh, ow, want_outflow=False)
+        assert nof(feats2, frame)[1] is None and torch.equal(nof(feats2, frame)[2], w3)
+        with pytest.raises(ValueError):
+            stab(feats[:, :-2], frame)
+        with pytest.raises(ValueError):
+            stab(feats, frame.double())
+    with pytest.raises(ValueError):
+        vs.OriginalSizeStabiliser(1, 64, 64, 6, 64, 64)          # weights are for 27 channels
+
+
+def test_batch_sliced_odd_frame_takes_the_two_launch_path():
+    # a view like frame[1:] of an odd-sized frame starts at an address that is not 16-byte aligned: the fused launch cannot
+    # take it (its contract), the evaluator must still work -- through vstab_flow_resize_scale + vstab_warp_flow
+    w = wts.synthetic_weights(seed=3, cin=27, random_bn=True, flow_gain=2.0)
+    runtime.reset()
+    vs.assign_weights(w)
+    g = torch.Generator().manual_seed(9)
+    feats = torch.rand(2, 64, 64, 27, generator=g).cuda()
+    big = torch.rand(3, 37, 53, 3, generator=g).cuda()
+    frame = big[1:]
+    assert frame.data_ptr() % 16 != 0 and frame.is_contiguous()
+    flows, outflow, warped = vs.stabilise_originalsize(feats, frame)
+    _, outflow_c, warped_c = vs.stabilise_originalsize(feats, frame.clone())
+    assert torch.equal(outflow, outflow_c) and torch.equal(warped, warped_c)
 
 
 def test_get_pixel_value():
@@ -246,13 +294,13 @@ def test_new_entry_points_reject_bad_arguments():
     flow = torch.zeros(1, 8, 8, 2, device="cuda")
     img3, img4 = torch.zeros(1, 8, 8, 3, device="cuda"), torch.zeros(1, 8, 8, 4, device="cuda")
     of, out = torch.zeros(1, 8, 8, 2, device="cuda"), torch.zeros(1, 8, 8, 3, device="cuda")
-    ok = L.vstab_flow_glue_warp(flow.data_ptr(), 1, 8, 8, img3.data_ptr(), of.data_ptr(), out.data_ptr(), 8, 8, 3, 1.0, 1.0, 1.0, st)
+    ok = L.vstab_flow_glue_warp(flow.data_ptr(), 1, 8, 8, img3.data_ptr(), of.data_ptr(), out.data_ptr(), 8, 8, 3, 10, 10, st)
     assert ok == 0
-    assert L.vstab_flow_glue_warp(None, 1, 8, 8, img3.data_ptr(), of.data_ptr(), out.data_ptr(), 8, 8, 3, 1.0, 1.0, 1.0, st) == -6      # NULL
-    assert L.vstab_flow_glue_warp(flow.data_ptr(), 1, 8, 8, img4.data_ptr(), of.data_ptr(), out.data_ptr(), 8, 8, 4, 1.0, 1.0, 1.0, st) == -1   # C != 3
-    assert L.vstab_flow_glue_warp(flow.data_ptr(), 1, 8, 1, img3.data_ptr(), of.data_ptr(), out.data_ptr(), 8, 8, 3, 1.0, 1.0, 1.0, st) == -1   # one-column flow
-    assert L.vstab_flow_glue_warp(flow.data_ptr(), 0, 8, 8, img3.data_ptr(), of.data_ptr(), out.data_ptr(), 8, 8, 3, 1.0, 1.0, 1.0, st) == -1   # empty batch
-    assert L.vstab_flow_glue_warp(flow.data_ptr(), 1, 8, 8, img3.data_ptr(), of.data_ptr(), out.data_ptr() + 4, 8, 8, 3, 1.0, 1.0, 1.0, st) == -2   # alignment
+    assert L.vstab_flow_glue_warp(None, 1, 8, 8, img3.data_ptr(), of.data_ptr(), out.data_ptr(), 8, 8, 3, 10, 10, st) == -6      # NULL
+    assert L.vstab_flow_glue_warp(flow.data_ptr(), 1, 8, 8, img4.data_ptr(), of.data_ptr(), out.data_ptr(), 8, 8, 4, 10, 10, st) == -1   # C != 3
+    assert L.vstab_flow_glue_warp(flow.data_ptr(), 1, 8, 1, img3.data_ptr(), of.data_ptr(), out.data_ptr(), 8, 8, 3, 10, 10, st) == -1   # one-column flow
+    assert L.vstab_flow_glue_warp(flow.data_ptr(), 0, 8, 8, img3.data_ptr(), of.data_ptr(), out.data_ptr(), 8, 8, 3, 10, 10, st) == -1   # empty batch
+    assert L.vstab_flow_glue_warp(flow.data_ptr(), 1, 8, 8, img3.data_ptr(), of.data_ptr(), out.data_ptr() + 4, 8, 8, 3, 10, 10, st) == -2   # alignment
     assert b"flow_glue_warp" in L.vstab_last_error(None)
     x = torch.zeros(1, 8, 8, 27, device="cuda")
     assert L.vstab_resize_bilinear_slice3(x.data_ptr(), 1, 8, 8, 27, 24, out.data_ptr(), 8, 8, st) == 0

@@ -102,7 +102,7 @@ def test_sampler_errors():
 
 
 # ---------------------------------------------------------------------------------------------------
-# 3-channel frames run on the tiled kernel (st3_tile_kernel: LDS-staged source window, 16-byte row stores).
+# 3-channel frames run on the tiled kernel (st3_tile_kernel: 2-D tiles, 3-dword corner gathers, 16-byte row stores).
 # The oracle evaluates theta . grid as the kernel does (matmul="unfused": every product and sum rounded to
 # fp32), so the comparison is bit for bit; against torch.matmul's rounding sequence the source coordinate
 # may differ by one ulp, which a noise image turns into <= ulp(W) * 1 of output error.
@@ -115,12 +115,12 @@ def _thetas(B, g, amp=0.15):
 
 
 @pytest.mark.parametrize("B,H,W,oh,ow", [
-    (2, 64, 96, 64, 96),        # window + staged stores
-    (2, 50, 70, 50, 70),        # W % 4 != 0: direct gathers, 12-byte stores
-    (1, 48, 64, 37, 53),        # window, ragged output (ow % 4 != 0)
-    (2, 45, 66, 40, 64),        # no window, staged stores
-    (1, 240, 320, 32, 32),      # 7.5x minification: the window does not fit, per-tile fallback to direct gathers
-    (3, 16, 16, 80, 120),       # magnification: tiny windows
+    (2, 64, 96, 64, 96),        # whole tiles, staged 16-byte stores
+    (2, 50, 70, 50, 70),        # ow % 4 != 0: 12-byte stores, ragged tiles
+    (1, 48, 64, 37, 53),        # ragged output of an aligned source
+    (2, 45, 66, 40, 64),        # odd source, staged stores
+    (1, 240, 320, 32, 32),      # 7.5x minification
+    (3, 16, 16, 80, 120),       # magnification
 ])
 def test_tiled_sampler_three_channels_bit_exact(B, H, W, oh, ow):
     g = torch.Generator().manual_seed(H * W + oh)
@@ -152,7 +152,7 @@ def test_tiled_sampler_edges_and_wild_maps():
     out = st.AffineTransformer((H, W)).transform(im.cuda(), th6.cuda())
     assert torch.equal(out.cpu(), vo.st_transform(im, th6, (H, W), matmul="unfused"))
     assert maxabs(out[0], im[0]) <= 1e-5
-    # projective maps whose z changes sign inside the frame (samples scatter over the whole source: window fallback), z == 0 rows
+    # projective maps whose z changes sign inside the frame (samples scatter over the whole source), z == 0 rows
     th8 = torch.tensor([[1., 0, 0, 0, 1, 0, 2.0, 0.0], [1., 0, 0, 0, 1, 0, 0.0, -1.0], [0.5, 0.2, 0, -0.2, 0.5, 0, 1.0, 1.0],
                         [1., 0, 0, 0, 1, 0, 0.5, 0.5]])
     outp = st.ProjectiveTransformer((H, W)).transform(im.cuda(), th8.cuda())

@@ -117,9 +117,24 @@ def test_flow_glue_constants():
     pf2 = torch.ones(1, 382, 510, 2, dtype=F64)
     f = vo.flow_to_output_res(pf2, 384, 512, 384, 512)
     assert f.shape == (1, 384, 512, 2)
-    assert torch.allclose(f, torch.full_like(f, float(np.float32(384.0) / np.float32(382.0))), atol=1e-12)
+    assert torch.allclose(f, torch.full_like(f, 384.0 / 382.0), atol=1e-15)
     f2 = vo.flow_to_output_res(pf2, 384, 512, 768, 1024)
     assert torch.allclose(f2[..., 0] / f[0, 0, 0, 0], torch.full((1, 768, 1024), 2.0, dtype=F64))
+
+
+def test_flow_glue_is_the_graphs_op_sequence_not_one_multiply():
+    # main:497-498: `pf2*384.0/382` is (pf2 * 384.0) / 382 -- two TF ops, two fp32 roundings -- and `f*out_h/384` likewise.
+    # One multiply by the fp32 quotient (what rounds 1-2 restated) differs in the last bit for about a third of all inputs;
+    # these known answers tell the two forms apart.
+    pf2 = torch.linspace(-40.0, 40.0, 382 * 4, dtype=torch.float32).view(1, 382, 4, 1).repeat(1, 1, 1, 2).contiguous()
+    lit = vo.flow_to_output_res(pf2, 384, 512, 382, 4)   # same size: resize_images returns its input, only the arithmetic acts
+    nh, dh = np.float32(384), np.float32(382)
+    want_x = ((pf2[..., 0].numpy() * nh) / dh * np.float32(4)) / np.float32(512)
+    want_y = ((pf2[..., 1].numpy() * nh) / dh * np.float32(382)) / np.float32(384)
+    assert np.array_equal(lit[..., 0].numpy(), want_x) and np.array_equal(lit[..., 1].numpy(), want_y)
+    one_mul = pf2[..., 1].numpy() * (nh / dh) * (np.float32(382) / np.float32(384))
+    assert (one_mul != want_y).mean() > 0.2              # the single-multiply form is a different function
+    assert np.abs(one_mul - want_y).max() <= 2 * np.spacing(np.float32(40.0))
 
 
 # --------------------------------------------------------------------------- secondary samplers
