@@ -42,9 +42,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define VSTAB_ABL 0        // tuning-harness ablations (tools/conv_bench): 1 no operand fetch, 2 no LDS stores, 4 no barrier;
 #endif                     // never defined in the product build
 
+#if defined(VSTAB_HARNESS) && defined(VSTAB_STAMP)
+// diagnostic build of tools/conv_bench only: s_memtime / s_memrealtime of wave 0 of every workgroup at four points (entry, loop
+// start, loop end, exit) go to a buffer nothing else reads (MI355X_MICROARCH.md, DVFS item 6; cdna_hip_programming.md, In-kernel stamps)
+__device__ unsigned long long g_conv_stamps[8 * 8192];
+#define STAMP(i) do { if (threadIdx.x == 0 && sid < 8192) { g_conv_stamps[sid * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+                                                          if ((i) == 0 || (i) == 3) g_conv_stamps[sid * 8 + 4 + (i) / 3] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+hipError_t conv_read_stamps(unsigned long long *host, size_t n) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), n * sizeof(unsigned long long)); }
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 template <int BM, int BN, int WM, int WN, bool VEC, bool DMA = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
 {
+#if defined(VSTAB_HARNESS) && defined(VSTAB_STAMP)
+    const unsigned sid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#endif
+    STAMP(0);
     static_assert(WM * WN == 4, "four waves per workgroup");
     static_assert(!DMA || VEC, "LDS-DMA staging needs the 16-byte operand path");
     constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
@@ -307,6 +322,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
             __syncthreads();                       // waits vmcnt(0) for the DMA, then the barrier
             int buf = 0;
             rd(0, 0, fa0, fb0);
+            STAMP(1);
             for (int kt = kt0; kt + 1 < kt1; ++kt) {
                 if (!(VSTAB_ABL & 1)) dma_tile(kt + 1, buf ^ 1);         // lands in the idle buffer while this tile computes
                 rd(buf, 1, fa1, fb1);
@@ -327,6 +343,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
             rd(buf, 3, fa1, fb1);
             mm(fa0, fb0);
             mm(fa1, fb1);
+            STAMP(2);
         }
     } else if (kt0 < kt1) {
         load_tile(kt0);
@@ -381,8 +398,63 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
         mm(fa1, fb1);
     }
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (p.ksplit == 1) {
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane's 16 registers are 16
+    // ROWS of one column.  Stored as they stand that is 64 four-byte store instructions per wave and tile, and the tile's end is
+    // store-ISSUE bound: in-kernel stamps (tools/conv_bench -DVSTAB_STAMP, profiles/README.md "r03 stamps") put it at 23.5 k
+    // cycles for a 128x128 tile -- 5-6 % of a layer at one workgroup per CU, with the matrix pipe idle.  So the tile is
+    // transposed through LDS (the operand buffers are free by now and exactly as large as the tile) and leaves as 16-byte
+    // stores of whole rows.  Same values: bias is added on the way in, the activation applied on the way out.
+    const bool to_slab = p.ksplit > 1;
+    if (to_slab || p.out_vec4) {
+        static_assert(BM * BN <= 2 * (BM + BN) * 32, "the output tile fits the operand buffers");
+        __syncthreads();                              // every wave has read its last fragments
+        float *sC = sA;                               // [BM][BN]
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int cl = (wn * NB + nb) * 32 + li;
+            const float bv = (!to_slab && n0 + cl < p.N) ? p.bias[n0 + cl] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    sC[row * BN + cl] = to_slab ? acc[mb][nb][r] : acc[mb][nb][r] + bv;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int C4 = BN / 4;
+        float *pz = p.partial + ((long long)z * p.Mmax + m0) * p.Npad;
+        const float slope = p.act == 1 ? 0.1f : 0.0f;
+#pragma unroll 4
+        for (int e = tid; e < BM * C4; e += 256) {
+            const int row = e / C4, c4 = e - row * C4;
+            const int col = n0 + c4 * 4;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(sC + row * BN + c4 * 4);
+            if (to_slab) {
+                if (m0 + row < ph.M) *reinterpret_cast<f32x4 *>(pz + (long long)row * p.Npad + col) = v;
+                continue;
+            }
+            const int oo = ooff[row];
+            if (oo < 0 || col >= p.N) continue;
+            float *o = p.out + (long long)oo + col;
+            if (col + 4 <= p.N) {
+                if (p.act == 3) v += *reinterpret_cast<const f32x4 *>(o);                 // accumulate (gradient sums)
+                else if (p.act) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], slope * v[i]);
+                }
+                *reinterpret_cast<f32x4 *>(o) = v;
+            } else {
+                for (int i = 0; col + i < p.N; ++i) {
+                    float x = v[i];
+                    if (p.act == 3) x += o[i];
+                    else if (p.act) x = fmaxf(x, slope * x);
+                    o[i] = x;
+                }
+            }
+        }
+    } else {                                          // an output that is not 16-byte friendly (arbitrary caller tensors): 4-byte stores
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int col = n0 + (wn * NB + nb) * 32 + li;
@@ -403,21 +475,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
                 }
             }
         }
-    } else {
-        float *pz = p.partial + ((long long)z * p.Mmax + m0) * p.Npad;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int col = n0 + (wn * NB + nb) * 32 + li;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (wm * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m0 + row < ph.M) pz[(long long)row * p.Npad + col] = acc[mb][nb][r];
-                }
-            }
-        }
     }
+    STAMP(3);
 }
 
 // Sum the split-K slabs, add bias, activate, scatter to the output tensor.
@@ -534,13 +593,17 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
 #else
     p.no_remap = 0;
 #endif
+    p.out_vec4 = (((uintptr_t)p.out & 15) == 0 && (p.Cs_out & 3) == 0 && (p.c_off & 3) == 0) ? 1 : 0;
+#ifdef VSTAB_HARNESS
+    if (getenv("VSTAB_NO_VEC_EPILOGUE")) p.out_vec4 = 0;                                 // A/B switch of tools/conv_bench
+#endif
     const int BM = (tile == TILE_64x128 || tile == TILE_64x64) ? 64 : (tile == TILE_256x32 ? 256 : 128);
     const int BN = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : ((tile == TILE_128x64 || tile == TILE_64x64) ? 64 : 32);
     if (p.in_bytes >= 0x80000000u || p.w_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.Npad % BN != 0 || p.SEGP % 32 != 0 || p.SEGP < p.SEG || p.NSEG < 1 || p.ksplit < 1 || p.nphase < 1 || p.nphase > 16)
         return hipErrorInvalidValue;
     if (vec4 && ((p.Cs_in & 3) || (p.SEG & 3) || (p.SEG_STRIDE & 3))) return hipErrorInvalidValue;
-    if (p.ksplit > 1 && ((p.N & 3) || (p.Cs_out & 3) || (p.c_off & 3) || p.partial == nullptr))
+    if (p.ksplit > 1 && ((p.N & 3) || (p.Cs_out & 3) || (p.c_off & 3) || p.partial == nullptr || ((uintptr_t)p.partial & 15)))
         return hipErrorInvalidValue;
     dim3 grid((p.Mmax + BM - 1) / BM, p.Npad / BN, p.nphase * p.ksplit), block(256);
     // With events the kernel is dispatched through hipExtLaunchKernelGGL, which timestamps the kernel's own

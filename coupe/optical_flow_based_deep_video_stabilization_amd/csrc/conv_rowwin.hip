@@ -158,9 +158,35 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
         }
     }
 
-    // epilogue: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  As in conv_mfma.hip the tile leaves through LDS (the window
+    // buffers are free now) as 16-byte stores of whole 256-byte pixel rows instead of 32 four-byte store instructions per wave.
     const int col = wn * 32 + li;
-    if (col < p.N) {
+    if (p.out_vec4) {
+        constexpr int TP = 64 * MB;                   // pixels of the tile; sC [TP][64]
+        __syncthreads();                              // every wave has read its last operands out of the window
+        float *sC = win;
+        const float bv = col < p.N ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sC[(wm * 32 * MB + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + col] = acc[mb][r] + bv;
+        __syncthreads();
+        const float slope = p.act == 1 ? 0.1f : 0.0f;
+        float *orow = p.out + ((long long)(n * p.Ho + oy) * p.Wo + ox0) * p.Cs_out + p.c_off;
+#pragma unroll 4
+        for (int e = tid; e < TP * 16; e += 256) {
+            const int px = e >> 4, c4 = (e & 15) * 4;
+            if (ox0 + px >= p.Wo || c4 >= p.N) continue;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(sC + px * 64 + c4);
+            if (p.act) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], slope * v[i]);
+            }
+            float *o = orow + (long long)px * p.Cs_out + c4;
+            if (c4 + 4 <= p.N) *reinterpret_cast<f32x4 *>(o) = v;
+            else for (int i = 0; c4 + i < p.N; ++i) o[i] = v[i];
+        }
+    } else if (col < p.N) {
         const float bv = p.bias[col];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
@@ -200,14 +226,17 @@ hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEven
     if (p.ox_base < 0 || p.ox_base >= p.Wo || (p.ox_base & 1) || p.ntile_x < 0) return hipErrorInvalidValue;
     const int ntx = p.ntile_x > 0 ? p.ntile_x : (p.Wo - p.ox_base + tile - 1) / tile;       // x tiles of THIS launch
     dim3 grid(p.Ho, ntx, p.B), block(256);       // (row, x tile, sample): see the XCD remap in the kernel
+    RowWinParams q = p;
+    // the staged epilogue needs 16-byte friendly output rows and the [tile][64] staging area inside the two window buffers
+    q.out_vec4 = (((uintptr_t)p.out & 15) == 0 && (p.Cs_out & 3) == 0 && (p.c_off & 3) == 0 && 2 * p.WLEN >= tile * 64) ? 1 : 0;
     const bool timed = ev_start || ev_stop;      // timestamps of the kernel's own dispatch packet, no marker packets (see conv_mfma.hip); a
                                                  // launch that is one half of a pair carries only the start or only the stop event
     if (p.MB == 2) {
-        if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<7, 2>), grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, p);
-        else conv_rowwin_kernel<7, 2><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(p);
+        if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<7, 2>), grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, q);
+        else conv_rowwin_kernel<7, 2><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(q);
     } else {
-        if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<4, 1>), grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, p);
-        else conv_rowwin_kernel<4, 1><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(p);
+        if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<4, 1>), grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, q);
+        else conv_rowwin_kernel<4, 1><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(q);
     }
     return hipGetLastError();
 }

@@ -91,6 +91,7 @@ struct ConvParams {
     int act;                // 0 = none, 1 = leaky relu 0.1 (max(v, 0.1 v)), 2 = relu, 3 = none, ADD to what is in out
     int nphase, ksplit, Mmax;
     int no_remap;           // tuning switch: keep the dispatch order (VSTAB_NO_XCD_REMAP)
+    int out_vec4;           // set by launch_conv: out, Cs_out and c_off are 16-byte friendly -> the tile leaves through LDS as 16-byte stores
     ConvPhase ph[16];       // 4 transposed-conv phases, or the 16 positions of a Winograd-domain GEMM
 };
 
@@ -123,6 +124,7 @@ struct RowWinParams {
     int Ho, Wo, Cs_out, c_off;
     int N, Npad, act;
     int MB;                 // 2: 128-pixel tiles; 1: 64-pixel tiles (small launches)
+    int out_vec4;           // set by launch_conv_rowwin: the tile leaves through LDS as 16-byte stores
     int ox_base, ntile_x;   // first output column and number of x tiles of this launch (0 tiles = up to the row end): a row whose length
                             // is 128 k + (1..64) runs as k 128-pixel tiles plus ONE 64-pixel tile in a second launch instead of a
                             // half-empty 128-pixel one (Wo = 960 at 1080p: 6 % of the first layer's MFMA work)

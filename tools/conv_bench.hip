@@ -4,10 +4,14 @@
 // Build: scripts/build_tools.sh ; run on the GPU box.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 #include "../include/vstab.h"
 #include "../coupe/optical_flow_based_deep_video_stabilization_amd/csrc/vstab_internal.h"
 using namespace vstab;
+#ifdef VSTAB_STAMP
+namespace vstab { hipError_t conv_read_stamps(unsigned long long *host, size_t n); }
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 
 int main(int argc, char **argv)
@@ -58,6 +62,29 @@ int main(int argc, char **argv)
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     const int BN = (tile == 0 || tile == 3) ? 128 : ((tile == 1 || tile == 4) ? 64 : 32), BM = (tile == 3 || tile == 4) ? 64 : 128;
     const long long blocks = (long long)((p.Mmax + BM - 1) / BM) * (p.Npad / BN) * p.nphase * p.ksplit;
+#ifdef VSTAB_STAMP
+    {   // per-workgroup phases of the LAST launch, in shader cycles (s_memtime), and the clock the kernel ran at
+        const size_t nb = (size_t)std::min<long long>(blocks, 8192);
+        std::vector<unsigned long long> st(nb * 8);
+        CK(vstab::conv_read_stamps(st.data(), st.size()));
+        std::vector<double> pro, loop, epi, tot, clk;
+        unsigned long long t_first = ~0ull, t_last = 0;
+        for (size_t b = 0; b < nb; ++b) {
+            const unsigned long long *s = &st[b * 8];
+            if (!s[3] || s[3] < s[0]) continue;
+            pro.push_back((double)(s[1] - s[0])); loop.push_back((double)(s[2] - s[1])); epi.push_back((double)(s[3] - s[2])); tot.push_back((double)(s[3] - s[0]));
+            if (s[5] > s[4]) clk.push_back((double)(s[3] - s[0]) / (double)(s[5] - s[4]) * 100.0);      // MHz: s_memrealtime ticks at 100 MHz
+            t_first = std::min(t_first, s[4]); t_last = std::max(t_last, s[5]);
+        }
+        auto med = [](std::vector<double> &v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        const int ktiles = (KT + p.ksplit - 1) / p.ksplit;
+        const double mfma_per_tile = 4.0 * (BM / 64) * (BN / 64) * 4 * 64;        // cycles of matrix-pipe time per K-tile per wave (64 per v_mfma_f32_32x32x2)
+        const double l = med(loop);
+        printf("stamps (%zu workgroups, medians, shader cycles): prologue %.0f  loop %.0f = %.1f per K-tile (matrix pipe %.0f -> %.3f)  epilogue %.0f  total %.0f;"
+               " clock %.0f MHz; kernel span %.1f us\n", pro.size(), med(pro), l, l / ktiles, mfma_per_tile, mfma_per_tile * ktiles / l, med(epi), med(tot), med(clk),
+               (double)(t_last - t_first) / 100.0);
+    }
+#endif
     printf("layer %2d tile %d ksplit %2d blocks %6lld KT %4d  %8.2f us  %7.1f TF(issued)  frac %.3f\n", layer, tile, p.ksplit, blocks, KT,
            ms * 1e3, 2 * macs / (ms * 1e-3) / 1e12, 2 * macs / (ms * 1e-3) / 1e12 / 157.3);
     return 0;
