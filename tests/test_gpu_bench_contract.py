@@ -31,6 +31,25 @@ def test_bench_prints_one_contract_line():
     assert rh["bound"] == "hbm" and rh["unit"] == "GB/s" and rh["peak"] == 8000.0 and abs(rh["frac"] - rh["achieved"] / rh["peak"]) < 1e-3
     assert 0.1 < rh["frac"] < 1.0 and rh["entry_point"] == "vstab_flow_glue_warp" and rh["launches"] >= 1
     assert abs(rh["alg_bytes_per_output_pixel"] - 40.0) < 0.2
+    # the spatial-transformer / warp.py samplers ride along as rows of the same block (24 algorithmic bytes per output pixel)
+    st_rows = [r_ for r_ in rh["other_rows"] if r_["row"].startswith(("S2 ", "S3 "))]
+    assert len(st_rows) == 3 and all(abs(r_["alg_bytes_per_output_pixel"] - 24.0) < 1e-6 and 0.05 < r_["frac"] < 1.0 for r_ in st_rows)
+    assert d["config"]["host_calls_per_step"].startswith("1 ")
+
+
+def test_bench_self_launched_rccl_rank_prints_exactly_one_line():
+    """The N > 1 path with one rank: the parent starts a torch.distributed.run child (no port picked ahead of time), the rank
+    initialises RCCL -- which prints its version banner to file descriptor 1 on these boxes -- and all-gathers its uint8 frames;
+    stdout must still be exactly the one JSON line."""
+    env = dict(os.environ, VSTAB_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "self-launch:" in r.stderr and "--rdzv-endpoint=127.0.0.1:0" in r.stderr and "--master-port" not in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "uint8 warped frames" in d["config"]["all_gather"]
 
 
 def test_bench_self_launches_two_ranks_rehearsal():
