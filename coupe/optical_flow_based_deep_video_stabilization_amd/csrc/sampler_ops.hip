@@ -151,9 +151,10 @@ __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__res
 // 16 x 32 tile of ONE sample's output pixels and a wave instruction works on a 4 x 16 patch, so the lines a gather touches are a
 // compact 2-D footprint under any rotation; one 3-dword load per corner; results leave through LDS as 16-byte stores of whole
 // 384-byte tile rows (ow % 4 == 0; 12-byte stores otherwise); XCD-contiguous tile order.
-// Measured and rejected (profiles/README.md "r03 sampler study", the variant is in commit 2076632): staging the tile's source window in LDS
-// (bounding box by DPP reductions, aligned 16-byte fill, corners from LDS) cuts the L1 lookups 3x (0.50 instead of 1.56 per
-// pixel) and is 1.7x SLOWER (0.34-0.39 of 8 TB/s against 0.53-0.64): four barriers and three dependent phases per tile.
+// Measured and rejected twice (profiles/README.md "r03 sampler study"): staging the source window in LDS -- bounding box of the taps
+// by DPP reductions, aligned 16-byte fill, corners from LDS -- cuts the L1 lookups 3x (0.50 instead of 1.56 per pixel) and is
+// SLOWER both per workgroup tile (commit 2076632: four barriers, three dependent phases; 0.34-0.39 of 8 TB/s against 0.53-0.65)
+// and per wave patch with no barrier at all (0.41-0.49): what bounds these kernels is requests in flight, not tag lookups.
 // The arithmetic is st_sample_pixel's / homography_warp_kernel's statement for statement: bit-identical results.
 // ---------------------------------------------------------------------------------
 enum { FAM_ST_THETA = 0, FAM_ST_COORDS = 1, FAM_HOMOG = 2 };
