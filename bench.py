@@ -92,6 +92,60 @@ def cpu_baseline(batch, H, W, Cin, weights, seconds_budget=20.0):
                       f"(network + flow glue + warp), torch-CPU fp32 restatement of the TF graph"}
 
 
+def secondary_rows(vs, runtime, log):
+    """Short forms of bench_clip.py and bench_train.py on this GPU; every row is best-effort (a failure is reported, not raised)."""
+    rows = {}
+    try:        # configs[3]'s per-GPU work: a 1080p clip shard in micro-batches of 8, frames quantised to uint8 as the writer does
+        from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
+        F_, MB, H, W = 24, 8, 1080, 1920
+        g = torch.Generator().manual_seed(5)
+        feats = torch.rand(MB, H, W, 27, generator=g).cuda()
+        frame = torch.rand(MB, H, W, 3, generator=g).cuda()
+        shard = torch.empty((F_, H, W, 3), dtype=torch.uint8, device="cuda")
+        stab = vs.OriginalSizeStabiliser(MB, H, W, 27, H, W, want_outflow=False)
+
+        def run():
+            for b0 in range(0, F_, MB):
+                _, _, warped = stab(feats, frame)
+                _lib.check(_lib.lib().vstab_quantise_output(warped.data_ptr(), MB * H * W, shard[b0:b0 + MB].data_ptr(), runtime.stream_ptr()))
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rows["clip_shard_1080p"] = {"frames_per_s": round(F_ / dt, 1), "frames": F_, "micro_batch": MB, "ms_per_micro_batch": round(dt / (F_ // MB) * 1e3, 2),
+                                    "what": "BASELINE configs[3] per-GPU work (bench_clip.py without the all-gather): network + glue + warp + uint8 quantise at 1080x1920"}
+        del stab, feats, frame, shard
+        log(f"secondary: 1080p clip shard {F_ / dt:.1f} frames/s")
+    except Exception as e:      # noqa: BLE001
+        rows["clip_shard_1080p"] = {"error": repr(e)[:200]}
+    try:        # one optimiser step of the reference's training graph (main:176-335), what bench_train.py times
+        from coupe.optical_flow_based_deep_video_stabilization_amd import train_step, weights as wts
+        torch.cuda.empty_cache()
+        B, H, W = 8, 512, 512
+        tr = train_step.Trainer(wts.synthetic_weights(seed=1, cin=27, random_bn=False, flow_gain=0.2), B, H, W)
+        g = torch.Generator().manual_seed(0)
+        feats = torch.rand(B, H, W, 27, generator=g).cuda()
+        gt, un = torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda()
+        for _ in range(2):
+            tr.step(feats, gt, un, lr=1e-4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            loss = tr.step(feats, gt, un, lr=1e-4)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        rows["train_step_512"] = {"ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 1), "batch": B, "final_loss": float(loss),
+                                  "what": "train-mode forward + loss_main + backward + Adam at 8 x 512x512x27 (bench_train.py)"}
+        log(f"secondary: training step {dt * 1e3:.2f} ms")
+        del tr
+    except Exception as e:      # noqa: BLE001
+        rows["train_step_512"] = {"error": repr(e)[:200]}
+    torch.cuda.empty_cache()
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +173,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph (torch.cuda.CUDAGraph) and replay it; single GPU, no kernel events")
     ap.add_argument("--roctx", action="store_true", help="run every layer inside a named roctx range (rocprofv3 --marker-trace)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short secondary measurements after the timed region (BASELINE configs[3]-shaped sharded clip, one "
+                         "training step; single GPU only)")
     ap.add_argument("--alloc-per-step", action="store_true",
                     help="call stabilise_originalsize (two library calls, seven output allocations per step) instead of the pre-allocated "
                          "one-call OriginalSizeStabiliser")
@@ -464,6 +521,10 @@ def main():
         "roofline": roofline,
         "roofline_hbm": roofline_hbm,
     }
+    # ---- secondary rows, AFTER the timed region and never part of `value`: what bench_clip.py (BASELINE configs[3]) and
+    # bench_train.py measure at length, in short form, so that a driver that only runs bench.py sees them
+    if rank == 0 and world == 1 and dist is None and not args.no_secondary and graph is None:
+        res["secondary"] = secondary_rows(vs, runtime, log)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:
