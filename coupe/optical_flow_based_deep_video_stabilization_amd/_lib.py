@@ -35,6 +35,7 @@ EXPORTS = {
     "vstab_resize_bilinear": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]),
     "vstab_resize_bilinear_slice3": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p]),
     "vstab_warp_flow": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "vstab_selftest_div_const": (C.c_int, [C.c_float, C.c_uint, C.c_ulonglong, C.c_void_p, C.c_void_p]),
     "vstab_flow_glue_warp": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
     "vstab_stabilise_originalsize": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 2 + [C.c_void_p] * 8 +
                                      [C.c_size_t, C.c_void_p]),

@@ -938,6 +938,16 @@ extern "C" int vstab_flow_resize_scale(const float *flow, int B, int h, int w, f
     return VSTAB_OK;
 }
 
+extern "C" int vstab_selftest_div_const(float d, unsigned first_bits, unsigned long long count, unsigned long long *bad_count_dev, void *stream)
+{
+    if (!bad_count_dev) return fail(nullptr, VSTAB_E_STATE, "selftest_div_const: NULL counter");
+    if (count < 1 || count > (1ull << 32)) return fail(nullptr, VSTAB_E_SHAPE, "selftest_div_const: 1 <= count <= 2^32");
+    const hipError_t e = launch_div_const_selftest(d, first_bits, count, bad_count_dev, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(nullptr, VSTAB_E_SHAPE, "selftest_div_const: the glue takes the plain division for this divisor");
+    HIP_TRY(nullptr, e);
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_resize_bilinear(const float *x, int B, int h, int w, int C, float *out, int oh, int ow, void *stream)
 {
     if (!x || !out) return fail(nullptr, VSTAB_E_STATE, "resize_bilinear: NULL buffer");

@@ -6,6 +6,7 @@
 #include "hbm_profile.h"
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -379,11 +380,58 @@ hipError_t launch_pf2(const float *T, int B, int h2, int w2, const float *bias2,
 // source flow grid + the constants of main:497-498 as the reference's graph applies them, one TF op (one fp32 rounding) each:
 //   predict_flow2*384.0/382   ->  (t * nh) / dh     nh = net_h, dh = the flow's own height
 //   outflow[...,0:1]*out_w/512 -> (v * mx) / dx     mx = out_w, dx = net_w;   y: (v * my) / dy, my = out_h, dy = net_h
-struct GlueParams { int h, w; float nh, dh, mx, dx, my, dy, ry, rx; };
-__device__ __forceinline__ float glue_pre(float t, const GlueParams &G) { return (t * G.nh) / G.dh; }
+// The three divisors are constants of the launch, and an IEEE fp32 division by a run-time value costs ~11 instructions (scale,
+// quarter-rate reciprocal, refinement, fix-up) ten times per pixel -- it made the stand-alone glue ALU-bound (0.67 -> 0.40 of
+// 8 TB/s at 1080p).  With r = RN(1/d) from the host the same correctly rounded quotient takes five: q = x*r, then two
+// residual corrections q += (x - d*q)*r with fused multiply-adds -- the tail of the hardware's own sequence (Markstein: the last
+// correction of a quotient already within one ulp rounds correctly unless d's significand is all ones).  Checked against `/`
+// on the device for EVERY fp32 x whose quotient is a normal number (vstab_selftest_div_const, tests/test_gpu_parity.py);
+// divisors outside 1 <= d <= 2^24 or with an all-ones significand take the plain division; x = +-inf is passed through.
+struct GlueParams { int h, w; float nh, dh, mx, dx, my, dy, ry, rx; float rdh, rdx, rdy; int fast; };
+__device__ __forceinline__ float div_const(float x, float d, float r, bool fast)
+{
+    if (!fast) return x / d;
+    float q = x * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, x), r, q);
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, x), r, q);
+    return __builtin_isinf(x) ? x : q;                  // +-inf / d (d > 0) = +-inf; the corrections would turn it into NaN
+}
+__device__ __forceinline__ float glue_pre(float t, const GlueParams &G) { return div_const(t * G.nh, G.dh, G.rdh, G.fast); }
+__device__ __forceinline__ float glue_post_x(float v, const GlueParams &G) { return div_const(v * G.mx, G.dx, G.rdx, G.fast); }
+__device__ __forceinline__ float glue_post_y(float v, const GlueParams &G) { return div_const(v * G.my, G.dy, G.rdy, G.fast); }
+__host__ inline bool div_const_ok(float d)
+{
+    uint32_t u;
+    memcpy(&u, &d, 4);
+    return d >= 1.0f && d <= 16777216.0f && (u & 0x7fffffu) != 0x7fffffu;
+}
 __host__ inline GlueParams glue_params(int h, int w, int oh, int ow, int net_h, int net_w)
 {
-    return GlueParams{h, w, (float)net_h, (float)h, (float)ow, (float)net_w, (float)oh, (float)net_h, (float)h / (float)oh, (float)w / (float)ow};
+    GlueParams G{h, w, (float)net_h, (float)h, (float)ow, (float)net_w, (float)oh, (float)net_h, (float)h / (float)oh, (float)w / (float)ow, 0.f, 0.f, 0.f, 0};
+    G.rdh = (float)(1.0 / (double)G.dh); G.rdx = (float)(1.0 / (double)G.dx); G.rdy = (float)(1.0 / (double)G.dy);
+    G.fast = div_const_ok(G.dh) && div_const_ok(G.dx) && div_const_ok(G.dy);
+    return G;
+}
+
+// device self-test of div_const against the IEEE division: every fp32 bit pattern x in [first, first + count) whose quotient is
+// finite and normal; counts the mismatches
+__global__ __launch_bounds__(256) void div_const_selftest_kernel(float d, float r, unsigned first, unsigned long long count, unsigned long long *bad)
+{
+    unsigned long long n = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256) {
+        const float x = __builtin_bit_cast(float, (unsigned)(first + i));
+        const float want = x / d;
+        if (x != x || !(fabsf(want) >= 1.17549435e-38f)) continue;              // NaN numerators and denormal / zero quotients are not compared
+        const float got = div_const(x, d, r, true);
+        if (__builtin_bit_cast(unsigned, got) != __builtin_bit_cast(unsigned, want)) ++n;
+    }
+    if (n) atomicAdd(bad, n);
+}
+hipError_t launch_div_const_selftest(float d, unsigned first, unsigned long long count, unsigned long long *bad, hipStream_t stream)
+{
+    if (!div_const_ok(d)) return hipErrorInvalidValue;
+    div_const_selftest_kernel<<<dim3(4096), dim3(256), 0, stream>>>(d, (float)(1.0 / (double)d), first, count, bad);
+    return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void flow_resize_scale_kernel(const float *__restrict__ flow, int B, float *__restrict__ out, int oh, int ow,
                                                                 GlueParams G)
@@ -399,8 +447,8 @@ __global__ __launch_bounds__(256) void flow_resize_scale_kernel(const float *__r
     const f32x2 *b = reinterpret_cast<const f32x2 *>(flow) + (long long)n * h * w;
     f32x2 tl = b[Y.lo * w + X.lo], tr = b[Y.lo * w + X.hi], bl = b[Y.hi * w + X.lo], br = b[Y.hi * w + X.hi];
     f32x2 o;
-    o.x = (lerp2(glue_pre(tl.x, G), glue_pre(tr.x, G), glue_pre(bl.x, G), glue_pre(br.x, G), X.t, Y.t) * G.mx) / G.dx;
-    o.y = (lerp2(glue_pre(tl.y, G), glue_pre(tr.y, G), glue_pre(bl.y, G), glue_pre(br.y, G), X.t, Y.t) * G.my) / G.dy;
+    o.x = glue_post_x(lerp2(glue_pre(tl.x, G), glue_pre(tr.x, G), glue_pre(bl.x, G), glue_pre(br.x, G), X.t, Y.t), G);
+    o.y = glue_post_y(lerp2(glue_pre(tl.y, G), glue_pre(tr.y, G), glue_pre(bl.y, G), glue_pre(br.y, G), X.t, Y.t), G);
     reinterpret_cast<f32x2 *>(out)[idx] = o;
 }
 
@@ -561,8 +609,8 @@ __global__ __launch_bounds__(256) void warp3_tile_kernel(const float *__restrict
         }
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            f[j].x = (lerp2(glue_pre(tl[j].x, G), glue_pre(tr[j].x, G), glue_pre(bl[j].x, G), glue_pre(br[j].x, G), X[j].t, Y[j].t) * G.mx) / G.dx;
-            f[j].y = (lerp2(glue_pre(tl[j].y, G), glue_pre(tr[j].y, G), glue_pre(bl[j].y, G), glue_pre(br[j].y, G), X[j].t, Y[j].t) * G.my) / G.dy;
+            f[j].x = glue_post_x(lerp2(glue_pre(tl[j].x, G), glue_pre(tr[j].x, G), glue_pre(bl[j].x, G), glue_pre(br[j].x, G), X[j].t, Y[j].t), G);
+            f[j].y = glue_post_y(lerp2(glue_pre(tl[j].y, G), glue_pre(tr[j].y, G), glue_pre(bl[j].y, G), glue_pre(br[j].y, G), X[j].t, Y[j].t), G);
             if (WRITE_FLOW && ok[j]) reinterpret_cast<f32x2 *>(outflow)[n * HW + (long long)yy[j] * W + xx[j]] = f[j];
         }
     } else {
@@ -704,8 +752,8 @@ __global__ __launch_bounds__(256) void glue_tile_kernel(const float *__restrict_
         const bool l1 = X[j].lo != xb[j], h1 = X[j].hi != xb[j];
         const f32x2 tl = l1 ? top[j].b : top[j].a, tr = h1 ? top[j].b : top[j].a, bl = l1 ? bot[j].b : bot[j].a, br = h1 ? bot[j].b : bot[j].a;
         f32x2 o;
-        o.x = (lerp2(glue_pre(tl.x, G), glue_pre(tr.x, G), glue_pre(bl.x, G), glue_pre(br.x, G), X[j].t, Y[j].t) * G.mx) / G.dx;
-        o.y = (lerp2(glue_pre(tl.y, G), glue_pre(tr.y, G), glue_pre(bl.y, G), glue_pre(br.y, G), X[j].t, Y[j].t) * G.my) / G.dy;
+        o.x = glue_post_x(lerp2(glue_pre(tl.x, G), glue_pre(tr.x, G), glue_pre(bl.x, G), glue_pre(br.x, G), X[j].t, Y[j].t), G);
+        o.y = glue_post_y(lerp2(glue_pre(tl.y, G), glue_pre(tr.y, G), glue_pre(bl.y, G), glue_pre(br.y, G), X[j].t, Y[j].t), G);
         if (STAGE) {
             const int q = j * 4 + wave;
             *reinterpret_cast<f32x2 *>(stage + (((q / PPR) * WH + lane / WW) * TW + (q % PPR) * WW + lane % WW) * 2) = o;

@@ -188,6 +188,7 @@ hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int
 enum { HBM_SLOT_WARP = 0, HBM_SLOT_GLUE = 1, HBM_SLOT_GLUE_WARP = 2, HBM_SLOT_PF2 = 3, HBM_SLOT_ST = 4, HBM_SLOT_HOMOG = 5, HBM_SLOTS = 6 };
 void hbm_profile_enable(int mode);
 hipError_t hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg_bytes_sum);
+hipError_t launch_div_const_selftest(float d, unsigned first, unsigned long long count, unsigned long long *bad, hipStream_t stream);
 hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *out, int oh, int ow,
                                  int C, int net_h, int net_w, hipStream_t stream);
 // 2x2 stride-2 SAME max pool (vgg16.py:51-53), NHWC, C % 4 == 0

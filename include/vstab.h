@@ -124,6 +124,13 @@ VSTAB_API int vstab_profile_kernel_name(vstab_ctx *ctx, int slot, char *buf, int
 VSTAB_API int vstab_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow,
                             int net_h, int net_w, void *stream);
 
+/* ---- device self-test of the glue's division by a launch constant (five fused operations on a host-side reciprocal instead
+ * of a run-time IEEE division): compares it with `x / d` for the `count` fp32 bit patterns x starting at `first_bits` whose
+ * quotient is finite and normal, and ADDS the number of mismatches to *bad_count_dev (device memory, 8-byte aligned).
+ * VSTAB_E_SHAPE for a divisor the glue would divide plainly (outside [1, 2^24], or an all-ones significand). */
+VSTAB_API int vstab_selftest_div_const(float d, unsigned first_bits, unsigned long long count, unsigned long long *bad_count_dev,
+                                       void *stream);
+
 /* ---- glue: main:806 / model.py:857 UpSampling2dLayer defaults.  Legacy TF bilinear
  * resize of an NHWC tensor. */
 VSTAB_API int vstab_resize_bilinear(const float *x, int B, int h, int w, int C, float *out, int oh, int ow,

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import coupe.optical_flow_based_deep_video_stabilization_amd as vs
-from coupe.optical_flow_based_deep_video_stabilization_amd import netspec, runtime, weights as wts
+from coupe.optical_flow_based_deep_video_stabilization_amd import _lib, netspec, runtime, weights as wts
 from oracle import vstab_oracle as vo
 
 pytestmark = pytest.mark.gpu
@@ -90,6 +90,30 @@ def test_fused_glue_warp_bit_identical(B, hn, wn, oh, ow):
     cpu_of = vo.flow_to_output_res(pf2.cpu(), hn, wn, oh, ow)
     assert cpu_of.dtype == torch.float32 and torch.equal(of.cpu(), cpu_of)
     assert torch.equal(wp.cpu(), vo.tf_warp(frame.cpu(), of.cpu(), oh, ow, torch.float32))
+
+
+def test_glue_division_by_launch_constants_is_the_ieee_quotient():
+    # The glue divides by three constants of the launch (main:497-498: /382, /512, /384).  The kernels do it with five fused
+    # operations on a host-side reciprocal instead of the ~11-instruction run-time division; this compares the two ON THE DEVICE:
+    # for the divisors of the reference's and BASELINE's sizes over EVERY fp32 bit pattern (2^32 numerators each), for every
+    # integer divisor up to 4096 over a stride through the patterns, and checks which divisors take the plain division.
+    import ctypes as C
+    L = _lib.lib()
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    st = runtime.stream_ptr()
+    for d in (382.0, 510.0, 384.0, 512.0, 718.0, 1278.0, 720.0, 1280.0, 1078.0, 1918.0, 1080.0, 1920.0, 254.0, 3.0, 7.0, 1023.0, 16777213.0):
+        _lib.check(L.vstab_selftest_div_const(C.c_float(d), 0, 1 << 32, bad.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
+    for d in range(1, 4097):
+        _lib.check(L.vstab_selftest_div_const(C.c_float(float(d)), (d * 2654435761) & 0xFFFFFFFF, 1 << 21, bad.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
+    for d in (0.5, 16777215.0, float(1 << 25), float("nan")):          # < 1, all-ones significand, > 2^24: plain division there
+        assert L.vstab_selftest_div_const(C.c_float(d), 0, 16, bad.data_ptr(), st) == -1
+    # and through the glue itself on values that once told the single-multiply form apart (tests/test_oracle_kat.py)
+    pf2 = torch.linspace(-40.0, 40.0, 382 * 4).view(1, 382, 4, 1).repeat(1, 1, 1, 2).contiguous()
+    assert torch.equal(vs.flow_to_output_res(pf2.cuda(), 384, 512, 382, 4).cpu(), vo.flow_to_output_res(pf2, 384, 512, 382, 4))
 
 
 def test_one_call_stabiliser_bit_identical_and_reuses_its_buffers():
