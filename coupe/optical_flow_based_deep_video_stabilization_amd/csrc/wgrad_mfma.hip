@@ -158,10 +158,39 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
         }
     }
 
-    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  As in conv_mfma.hip the tile leaves through
+    // LDS (the operand ring is free now and as large as the tile) as 16-byte stores of whole rows when the destination allows it,
+    // instead of 64 four-byte store instructions per wave.
     const bool slab = p.ksplit > 1;
     const int ld = slab ? p.Cout : (p.ldw ? p.ldw : p.Cout);
     float *dst = slab ? p.partial + (size_t)(batch * p.ksplit + split) * p.M * p.Cout : p.dW + (size_t)batch * p.M * p.Cout + p.col0;
+    const bool vec = ((ld & 3) == 0) && ((p.Cout & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    if (vec) {
+        static_assert(BM * BN <= 2 * KT * (BM + BN), "the output tile fits the operand ring");
+        float *sC = sA;                                   // [BM][BN]; the loop's last barrier has every wave past its last read
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int cl = wn * (BN / 2) + nb * 32 + li;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sC[(wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + cl] = acc[mb][nb][r];
+        }
+        __syncthreads();
+        constexpr int C4 = BN / 4;
+        const bool rmw = p.ksplit == 1 && p.accumulate;
+#pragma unroll 4
+        for (int e = tid; e < BM * C4; e += 256) {
+            const int rl = e / C4, c4 = e - rl * C4;
+            const int row = m0 + rl, col = n0 + c4 * 4;
+            if (row >= p.M || col >= p.Cout) continue;    // Cout % 4 == 0: a float4 is inside or outside as a whole
+            f32x4 v = *reinterpret_cast<const f32x4 *>(sC + rl * BN + c4 * 4);
+            float *o = dst + (size_t)row * ld + col;
+            if (rmw) v += *reinterpret_cast<const f32x4 *>(o);
+            *reinterpret_cast<f32x4 *>(o) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int col = n0 + wn * (BN / 2) + nb * 32 + li;
