@@ -69,7 +69,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < iters; ++i) CK(launch_conv(p, (ConvTile)tile, vec4, 0));
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
-    const int BN = (tile == 0 || tile == 3) ? 128 : ((tile == 1 || tile == 4) ? 64 : 32), BM = (tile == 3 || tile == 4) ? 64 : 128;
+    const int BN = (tile == 0 || tile == 3) ? 128 : ((tile == 1 || tile == 4) ? 64 : 32), BM = (tile == 3 || tile == 4) ? 64 : (tile == 5 ? 256 : 128);
     const long long blocks = (long long)((p.Mmax + BM - 1) / BM) * (p.Npad / BN) * p.nphase * p.ksplit;
 #ifdef VSTAB_STAMP
     {   // per-workgroup phases of the LAST launch, in shader cycles (s_memtime), and the clock the kernel ran at
