@@ -341,6 +341,45 @@ def test_new_entry_points_reject_bad_arguments():
     torch.cuda.synchronize()
 
 
+def test_round3_entry_points_reject_bad_arguments():
+    """vstab_stabilise_originalsize, the glue's new (net_h, net_w) arguments, vstab_st_bilinear_interp(oh, ow) and the division
+    self-test: VSTAB_E_* for arguments outside their contract, through the ABI."""
+    import ctypes as C
+    L = _lib.lib()
+    st = runtime.stream_ptr()
+    w = wts.synthetic_weights(seed=3, cin=27, random_bn=False)
+    runtime.reset()
+    vs.assign_weights(w)
+    ctx = runtime.get_context()
+    B, H, W = 1, 64, 64
+    feats, frame = torch.rand(B, H, W, 27, device="cuda"), torch.rand(B, H, W, 3, device="cuda")
+    stab = vs.OriginalSizeStabiliser(B, H, W, 27, H, W)
+    pf = [f.data_ptr() for f in stab.flows]
+    ws = stab.ws
+    args = lambda fe=feats.data_ptr(), fr=frame.data_ptr(), wp=stab.warped.data_ptr(), oh=H, ow=W, wsb=ws.numel(): (
+        ctx._h, fe, B, H, W, 27, fr, oh, ow, *pf, stab.outflow.data_ptr(), wp, ws.data_ptr(), wsb, st)
+    assert L.vstab_stabilise_originalsize(*args()) == 0
+    assert L.vstab_stabilise_originalsize(*args(fr=None)) == -6                     # NULL frame
+    assert L.vstab_stabilise_originalsize(*args(wp=None)) == -6                     # NULL output
+    assert L.vstab_stabilise_originalsize(*args(fe=None)) == -6                     # NULL feats (caught by the forward)
+    assert L.vstab_stabilise_originalsize(*args(oh=0)) == -1                        # empty output
+    assert L.vstab_stabilise_originalsize(*args(wsb=1024)) < 0                      # workspace too small
+    assert L.vstab_stabilise_originalsize(None, *args()[1:]) == -6                  # no context
+    flow = torch.zeros(1, 8, 8, 2, device="cuda")
+    out = torch.zeros(1, 8, 8, 2, device="cuda")
+    assert L.vstab_flow_resize_scale(flow.data_ptr(), 1, 8, 8, out.data_ptr(), 8, 8, 10, 10, st) == 0
+    assert L.vstab_flow_resize_scale(flow.data_ptr(), 1, 8, 8, out.data_ptr(), 8, 8, 0, 10, st) == -1      # net_h < 1
+    img = torch.zeros(1, 8, 8, 3, device="cuda")
+    xy = torch.zeros(16, device="cuda")
+    o = torch.zeros(16, 3, device="cuda")
+    assert L.vstab_st_bilinear_interp(img.data_ptr(), 1, 8, 8, 3, xy.data_ptr(), xy.data_ptr(), 4, 4, o.data_ptr(), st) == 0
+    assert L.vstab_st_bilinear_interp(img.data_ptr(), 1, 8, 8, 3, xy.data_ptr(), xy.data_ptr(), 0, 4, o.data_ptr(), st) == -1
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    assert L.vstab_selftest_div_const(C.c_float(382.0), 0, 0, bad.data_ptr(), st) == -1                  # empty range
+    assert L.vstab_selftest_div_const(C.c_float(382.0), 0, 16, None, st) == -6
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------- predict_flow2 gather (K9 / F8) on its own
 def _pf2_reference(T, bias2, pf3, H, W):
     """pf2[y,x,o] = b[o] + sum_{dy,dx} T[ny(y+dy)-1, nx(x+dx)-1][3dy+dx][o] over the in-image taps, then eight sequential adds of
