@@ -416,8 +416,8 @@ def main():
                     # Winograd F(2x2,3x3) form (4/9 of the direct convolution's multiply-adds); *_direct count those layers as the
                     # direct convolutions SURVEY.md 8d prices -- a work rate, which may exceed what the matrix pipe itself does
                     "flops_counted": "issued by the MFMA kernel; *_direct = same layers as direct convolutions (Winograd stages x9/4)",
-                    "note": "peak = 157.3 TFLOP/s at the nominal 2.4 GHz; in-kernel stamps (profiles/README.md, r03 stamps) show the chip holding "
-                            "2.03-2.17 GHz in these launches and answering every saved matrix-pipe cycle with a lower clock (power-limited, not schedule-limited)",
+                    "note": "peak = 157.3 TFLOP/s at the nominal 2.4 GHz; in situ the chip holds 2.32-2.35 GHz in these launches (PMC on long dispatches, "
+                            "profiles/power_clock_r03_insitu.txt) with the matrix pipe 0.83-0.86 busy: the gap is prologue + epilogue that all workgroups of a launch run in lockstep",
                     "achieved_direct": round(d_dfl / (d_ms * 1e-3) / 1e12, 2),
                     "frac_direct": round(d_dfl / (d_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                     "all_mfma_launches": {"launches_per_step": 15, "ms_per_step": round(tot_ms, 4),
