@@ -1006,6 +1006,16 @@ extern "C" int vstab_stabilise_originalsize(vstab_ctx *ctx, const float *feats, 
     return rc2;
 }
 
+#if defined(VSTAB_HARNESS) && defined(VSTAB_STAMP)
+// diagnostic build only (scripts/insitu_stamps.py): per-workgroup s_memtime stamps of the conv launches of a forward
+namespace vstab { void conv_stamp_reset(); hipError_t conv_read_stamps_slot(int slot, unsigned long long *host, size_t n); }
+extern "C" __attribute__((visibility("default"))) int vstab_debug_stamp_reset(void) { vstab::conv_stamp_reset(); return 0; }
+extern "C" __attribute__((visibility("default"))) int vstab_debug_stamp_read(int slot, unsigned long long *host, size_t n)
+{
+    return vstab::conv_read_stamps_slot(slot, host, n) == hipSuccess ? 0 : -3;
+}
+#endif
+
 extern "C" int vstab_hbm_profile_enable(int mode)
 {
     if (mode < 0 || mode > 2) return fail(nullptr, VSTAB_E_SHAPE, "hbm_profile_enable: mode must be 0, 1 or 2");

@@ -45,10 +45,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #if defined(VSTAB_HARNESS) && defined(VSTAB_STAMP)
 // diagnostic build of tools/conv_bench only: s_memtime / s_memrealtime of wave 0 of every workgroup at four points (entry, loop
 // start, loop end, exit) go to a buffer nothing else reads (MI355X_MICROARCH.md, DVFS item 6; cdna_hip_programming.md, In-kernel stamps)
-__device__ unsigned long long g_conv_stamps[8 * 8192];
-#define STAMP(i) do { if (threadIdx.x == 0 && sid < 8192) { g_conv_stamps[sid * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-                                                          if ((i) == 0 || (i) == 3) g_conv_stamps[sid * 8 + 4 + (i) / 3] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-hipError_t conv_read_stamps(unsigned long long *host, size_t n) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), n * sizeof(unsigned long long)); }
+// 32 launch slots (launch_conv numbers its launches; conv_stamp_reset() restarts the count) so that a whole forward can be read back
+__device__ unsigned long long g_conv_stamps[32][8 * 8192];
+#define STAMP(i) do { if (threadIdx.x == 0 && sid < 8192) { g_conv_stamps[p.stamp_slot & 31][sid * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+                                                          if ((i) == 0 || (i) == 3) g_conv_stamps[p.stamp_slot & 31][sid * 8 + 4 + (i) / 3] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+static int g_stamp_next = 0;
+void conv_stamp_reset()
+{
+    g_stamp_next = 0;
+    void *d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_conv_stamps)) == hipSuccess) (void)hipMemset(d, 0, sizeof(unsigned long long) * 32 * 8 * 8192);
+}
+hipError_t conv_read_stamps_slot(int slot, unsigned long long *host, size_t n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), n * sizeof(unsigned long long), (size_t)(slot & 31) * 8 * 8192 * sizeof(unsigned long long));
+}
+hipError_t conv_read_stamps(unsigned long long *host, size_t n) { return conv_read_stamps_slot((g_stamp_next - 1) & 31, host, n); }
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -592,6 +604,9 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
     p.no_remap = no_remap;
 #else
     p.no_remap = 0;
+#endif
+#if defined(VSTAB_HARNESS) && defined(VSTAB_STAMP)
+    p.stamp_slot = g_stamp_next++;
 #endif
     p.out_vec4 = (((uintptr_t)p.out & 15) == 0 && (p.Cs_out & 3) == 0 && (p.c_off & 3) == 0) ? 1 : 0;
 #ifdef VSTAB_HARNESS

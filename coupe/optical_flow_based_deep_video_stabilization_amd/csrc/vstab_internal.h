@@ -91,6 +91,7 @@ struct ConvParams {
     int act;                // 0 = none, 1 = leaky relu 0.1 (max(v, 0.1 v)), 2 = relu, 3 = none, ADD to what is in out
     int nphase, ksplit, Mmax;
     int no_remap;           // tuning switch: keep the dispatch order (VSTAB_NO_XCD_REMAP)
+    int stamp_slot;         // -DVSTAB_STAMP diagnostic builds: which stamp buffer this launch writes (launch_conv counts)
     int out_vec4;           // set by launch_conv: out, Cs_out and c_off are 16-byte friendly -> the tile leaves through LDS as 16-byte stores
     ConvPhase ph[16];       // 4 transposed-conv phases, or the 16 positions of a Winograd-domain GEMM
 };
