@@ -48,7 +48,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // 32 launch slots (launch_conv numbers its launches; conv_stamp_reset() restarts the count) so that a whole forward can be read back
 __device__ unsigned long long g_conv_stamps[32][8 * 8192];
 #define STAMP(i) do { if (threadIdx.x == 0 && sid < 8192) { g_conv_stamps[p.stamp_slot & 31][sid * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-                                                          if ((i) == 0 || (i) == 3) g_conv_stamps[p.stamp_slot & 31][sid * 8 + 4 + (i) / 3] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+                                                          if ((i) == 0 || (i) == 3) g_conv_stamps[p.stamp_slot & 31][sid * 8 + 4 + (i) / 3] = __builtin_amdgcn_s_memrealtime(); \
+                                                          if ((i) == 0) { g_conv_stamps[p.stamp_slot & 31][sid * 8 + 6] = __builtin_amdgcn_s_getreg(63492);      /* HW_ID */ \
+                                                                          g_conv_stamps[p.stamp_slot & 31][sid * 8 + 7] = __builtin_amdgcn_s_getreg(63508); } } } while (0)   /* XCC_ID */
 static int g_stamp_next = 0;
 void conv_stamp_reset()
 {

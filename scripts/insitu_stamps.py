@@ -53,6 +53,17 @@ for slot, name in enumerate(names):
         print(f"      started within 1 us: {int((st < 1).sum())}; sorted start times at ranks 255/256/383/384/511/512/640/768/896: " +
               " ".join(f"{srt[min(k, len(srt) - 1)]:.1f}" for k in (255, 256, 383, 384, 511, 512, 640, 768, 896)))
         late = st > np.percentile(st, 50) + 1
+        # which workgroups share a CU?  HW_ID: cu_id bits 11:8, sh_id 12, se_id 15:13; XCC_ID low bits
+        hw, xcc = s[:, 6], s[:, 7] & 0xf
+        cu = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)
+        ids = np.nonzero(ok)[0]
+        first = st < 1
+        by_cu = {}
+        for wid, c in zip(ids[first], cu[first]):
+            by_cu.setdefault(int(c), []).append(int(wid))
+        pairs = [v for v in by_cu.values() if len(v) >= 2]
+        diffs = sorted({abs(v[1] - v[0]) for v in pairs})
+        print(f"      first-round workgroups on {len(by_cu)} distinct CUs; id differences of co-resident ones: {diffs[:12]}; xcc of id 0..15: {[int(x) for x in xcc[np.argsort(ids)][:16]]}")
         if late.any():
             for nm, m in (("first round", ~late), ("later", late)):
                 print(f"      {nm:<12} prologue {np.median(pro[m]):8.0f}  loop {np.median(loop[m]):8.0f}  epilogue {np.median(epi[m]):8.0f}  (cycles, medians; loop p90 {np.percentile(loop[m], 90):.0f})")
