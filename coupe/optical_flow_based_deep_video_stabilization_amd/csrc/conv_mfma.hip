@@ -37,6 +37,9 @@ namespace vstab {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define VSTAB_COMMA ,
+#include "conv_kloop_gfx950.inc"
 
 #ifndef VSTAB_ABL
 #define VSTAB_ABL 0        // tuning-harness ablations (tools/conv_bench): 1 no operand fetch, 2 no LDS stores, 4 no barrier;
@@ -329,8 +332,74 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     constexpr int NLD = (VEC ? A_ROWS_V : A_ELEMS_S) + B_PASS;        // global loads per tile
     constexpr int NST = NLD;                                          // LDS writes per tile
     constexpr bool PIN = (NLD <= G) && (NST <= G);
+#ifdef VSTAB_NO_ASM_KLOOP
+    constexpr bool ASM_KLOOP = false;                                 // A/B builds only (scripts/build_variant_lib.sh)
+#else
+    constexpr bool ASM_KLOOP = DMA && VEC && BM == 128 && WM == 2 && WN == 2 && (BN == 128 || BN == 64) && VSTAB_ABL == 0;
+#endif
 
-    if constexpr (DMA) {
+    if constexpr (ASM_KLOOP) {
+        // The whole K loop as one assembly block (conv_kloop_gfx950.inc, written by tools/gen_conv_kloop.py, which documents the
+        // schedule): same tiles, same buffers, same MFMA order per accumulator as the C++ loop below -- bit-identical results --
+        // with every fragment read issued a full k-group ahead of its use, the fetch of tile t+1 (validity test per gathered row
+        // by EXEC narrowing, `buffer_load_dwordx4 ... lds`) between the MFMAs of k-group 0, one barrier per tile inside k-group 3.
+        if (kt0 < kt1) {
+            dma_tile(kt0, 0);                      // leaves the cursor on tile kt0 + 1
+            __syncthreads();
+            STAMP(1);
+            const unsigned ldsA = (unsigned)(size_t)(__attribute__((address_space(3))) void *)sA;
+            unsigned la[4], lb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int chunk = ((2 * q + lh) ^ sw) * 4;
+                la[q] = ldsA + (unsigned)(a_row0 + chunk) * 4u;
+                lb[q] = ldsA + (unsigned)(2 * BM * 32 + b_row0 + chunk) * 4u;
+            }
+            int span[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) span[j] = max(RA[j].z - RA[j].y, 0);
+            const unsigned long long ain = (unsigned long long)(size_t)(p.in - bias_el);
+            const unsigned long long awt = (unsigned long long)(size_t)(p.wpk + ph.w_off);
+            i32x4 din, dwt;                        // the two buffer descriptors (stride 0, raw, the ranges of rin_b / rwt)
+            din.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ain);
+            din.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ain >> 32) & 0xffffu));
+            din.z = __builtin_amdgcn_readfirstlane((int)(p.in_bytes + 4u * (unsigned)bias_el));
+            din.w = 0x00020000;
+            dwt.x = __builtin_amdgcn_readfirstlane((int)(unsigned)awt);
+            dwt.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(awt >> 32) & 0xffffu));
+            dwt.z = __builtin_amdgcn_readfirstlane((int)p.w_bytes);
+            dwt.w = 0x00020000;
+            const int m_a = __builtin_amdgcn_readfirstlane((int)ldsA + wave_u * 1024);
+            const int m_b = __builtin_amdgcn_readfirstlane((int)ldsA + 2 * BM * 128 + wave_u * 1024);
+            const int wstep = p.Npad * 128;
+            int s_ky = c_ky, s_sg = c_sg, s_kc = c_kc, s_soffw = (kt0 + 1) * wstep, s_n = kt1 - kt0 - 1;
+            int t_qseg, t_qabs, t_soff, t_t, t_kyc;
+            unsigned v_t, v_o0, v_o1;
+#define VSTAB_KLOOP_IO(ACCS)                                                                                                                \
+            : ACCS, [ky] "+s"(s_ky), [sg] "+s"(s_sg), [kc] "+s"(s_kc), [soffw] "+s"(s_soffw), [n] "+s"(s_n),                              \
+              [qseg] "=&s"(t_qseg), [qabs] "=&s"(t_qabs), [soff] "=&s"(t_soff), [t] "=&s"(t_t), [kyc] "=&s"(t_kyc),                        \
+              [vt] "=&v"(v_t), [vo0] "=&v"(v_o0), [vo1] "=&v"(v_o1)                                                                        \
+            : [la0] "v"(la[0]), [la1] "v"(la[1]), [la2] "v"(la[2]), [la3] "v"(la[3]),                                                     \
+              [lb0] "v"(lb[0]), [lb1] "v"(lb[1]), [lb2] "v"(lb[2]), [lb3] "v"(lb[3]),                                                     \
+              [x0] "v"(RA[0].x), [x1] "v"(RA[1].x), [x2] "v"(RA[2].x), [x3] "v"(RA[3].x),                                                 \
+              [lo0] "v"(RA[0].y), [lo1] "v"(RA[1].y), [lo2] "v"(RA[2].y), [lo3] "v"(RA[3].y),                                             \
+              [span0] "v"(span[0]), [span1] "v"(span[1]), [span2] "v"(span[2]), [span3] "v"(span[3]),                                     \
+              [w0] "v"(RA[0].w), [w1] "v"(RA[1].w), [w2] "v"(RA[2].w), [w3] "v"(RA[3].w),                                                 \
+              [y0] "v"(R[0].y), [y1] "v"(R[1].y), [y2] "v"(R[2].y), [y3] "v"(R[3].y),                                                     \
+              [wv] "v"(wvoff0), [rin] "s"(din), [rwt] "s"(dwt), [ma] "s"(m_a), [mb] "s"(m_b),                                            \
+              [kps] "s"(kps), [nseg] "s"(L_NSEG), [lstride] "s"(L_STRIDE), [pitch] "s"(row_pitch), [hi] "s"(p.Hi), [wstep] "s"(wstep)     \
+            : "memory", "vcc", "scc", VSTAB_KLOOP_CLOBBERS
+            if constexpr (BN == 128) {
+                asm volatile(VSTAB_KLOOP_ASM_128x128
+                             VSTAB_KLOOP_IO([c00] "+a"(acc[0][0]) VSTAB_COMMA [c01] "+a"(acc[0][1]) VSTAB_COMMA [c10] "+a"(acc[1][0]) VSTAB_COMMA [c11] "+a"(acc[1][1])));
+            } else {
+                asm volatile(VSTAB_KLOOP_ASM_128x64
+                             VSTAB_KLOOP_IO([c00] "+a"(acc[0][0]) VSTAB_COMMA [c10] "+a"(acc[1][0])));
+            }
+#undef VSTAB_KLOOP_IO
+            STAMP(2);
+        }
+    } else if constexpr (DMA) {
         if (kt0 < kt1) {
             dma_tile(kt0, 0);
             __syncthreads();                       // waits vmcnt(0) for the DMA, then the barrier
@@ -547,6 +616,9 @@ __global__ __launch_bounds__(256) void splitk_combine_kernel(const ConvParams p)
     *reinterpret_cast<f32x4 *>(p.out + oo + c4 * 4) = s;
 }
 
+constexpr int CONV_CUS = 256;                           // MI355X: 8 XCDs x 32 CUs
+constexpr size_t CONV_LDS_TWO_PER_CU = 56 * 1024;       // an LDS request of which only two fit a CU's 160 KB
+
 template <int BM, int BN>
 static size_t conv_lds_bytes()
 {
@@ -572,6 +644,9 @@ hipError_t conv_set_attributes()
     VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, false>), 128, 64)
     VSTAB_SET((conv_mfma_kernel<128, 128, 2, 2, true, true>), 128, 128)
     VSTAB_SET((conv_mfma_kernel<128, 64, 2, 2, true, true>), 128, 64)
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<128, 64, 2, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)CONV_LDS_TWO_PER_CU);
+    if (e != hipSuccess) return e;
     VSTAB_SET((conv_mfma_kernel<128, 32, 4, 1, true, true>), 128, 32)
     VSTAB_SET((conv_mfma_kernel<64, 128, 1, 4, true, true>), 64, 128)
     VSTAB_SET((conv_mfma_kernel<256, 32, 4, 1, true, true>), 256, 32)
@@ -635,9 +710,20 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
     const bool use_dma = lds_dma_enabled();
     if (tile == TILE_128x128 && vec4 && use_dma)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 128, 2, 2, true, true>), (conv_lds_bytes<128, 128>()));
-    else if (tile == TILE_128x64 && vec4 && use_dma)
-        VSTAB_LAUNCH((conv_mfma_kernel<128, 64, 2, 2, true, true>), (conv_lds_bytes<128, 64>()));
-    else if (tile == TILE_128x32 && vec4 && use_dma)
+    else if (tile == TILE_128x64 && vec4 && use_dma) {
+        // Three of these workgroups fit a CU (48 KB of LDS each).  A launch of 513 ... 1024 of them that is a whole number of
+        // two-per-CU rounds but not of three-per-CU rounds runs its last quarter one workgroup per CU -- or, as the dispatcher
+        // hands the stragglers to whichever CU frees a slot first, two on some CUs and none on others (in-situ stamps of
+        // deconv2 at B=8 512x512: 1024 workgroups, the last 256 take 63 us alone and 105 us where two share a CU, 238 us in
+        // all).  Asking for 56 KB makes it two even rounds: 202 us.  Longer launches (the Winograd-domain GEMMs, 2048 / 4096
+        // workgroups) measure the same or slower that way and keep three.
+        size_t lds = conv_lds_bytes<128, 64>();
+        {
+            const long long wgs = (long long)grid.x * grid.y * grid.z;
+            if (wgs > 2 * CONV_CUS && wgs <= 4 * CONV_CUS && wgs % (2 * CONV_CUS) == 0) lds = CONV_LDS_TWO_PER_CU;
+        }
+        VSTAB_LAUNCH((conv_mfma_kernel<128, 64, 2, 2, true, true>), lds);
+    } else if (tile == TILE_128x32 && vec4 && use_dma)
         VSTAB_LAUNCH((conv_mfma_kernel<128, 32, 4, 1, true, true>), (conv_lds_bytes<128, 32>()));
     else if (tile == TILE_64x128 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<64, 128, 1, 4, true, true>), (conv_lds_bytes<64, 128>()));

@@ -49,6 +49,10 @@ for slot, name in enumerate(names):
         q = lambda v: " ".join(f"{np.percentile(v, k):7.1f}" for k in (0, 10, 25, 50, 75, 90, 100))
         print(f"      start us  (min p10 p25 p50 p75 p90 max): {q(st)}")
         print(f"      life  us  (min p10 p25 p50 p75 p90 max): {q(life)}")
+        end = st + life
+        print(f"      end   us  (min p10 p25 p50 p75 p90 max): {q(end)}")
+        lastk = np.argsort(end)[-6:]
+        print("      last to end (dispatch id, start us, life us, loop cycles): " + "  ".join(f"({int(np.nonzero(ok)[0][k])}, {st[k]:.1f}, {life[k]:.1f}, {int(loop[k])})" for k in lastk))
         srt = np.sort(st)
         print(f"      started within 1 us: {int((st < 1).sum())}; sorted start times at ranks 255/256/383/384/511/512/640/768/896: " +
               " ".join(f"{srt[min(k, len(srt) - 1)]:.1f}" for k in (255, 256, 383, 384, 511, 512, 640, 768, 896)))

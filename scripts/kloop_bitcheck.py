@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""sha256 of every output of one forward (B=8 512x512x27, seeded) -- run once per library build (VSTAB_LIB) and compare the lines:
+the assembly K loop keeps the C++ loop's MFMA order per accumulator, so the two builds must print the same digests."""
+import hashlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import coupe.optical_flow_based_deep_video_stabilization_amd as vs   # noqa: E402
+
+B, H, W = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (8, 512, 512)))
+vs.initialize_global_variables(seed=1, cin=27)
+g = torch.Generator().manual_seed(1000)
+feats = torch.rand(B, H, W, 27, generator=g).cuda()
+outs = vs.flownetS_pyramid(feats, B)
+torch.cuda.synchronize()
+for i, o in enumerate(outs if isinstance(outs, (tuple, list)) else [outs]):
+    print(i, tuple(o.shape), hashlib.sha256(o.detach().cpu().numpy().tobytes()).hexdigest()[:24])

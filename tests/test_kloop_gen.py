@@ -1,0 +1,72 @@
+"""The assembly K loop (csrc/conv_kloop_gfx950.inc) is generated: the committed file must be what tools/gen_conv_kloop.py prints, and the
+schedule it encodes must keep the properties the kernel relies on (no GPU needed: text checks)."""
+import importlib.util
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "coupe", "optical_flow_based_deep_video_stabilization_amd", "csrc", "conv_kloop_gfx950.inc")
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("gen_conv_kloop", os.path.join(ROOT, "tools", "gen_conv_kloop.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_committed_include_is_the_generators_output():
+    assert open(INC).read() == _gen().render()
+
+
+def _blocks():
+    g = _gen()
+    return {bn: g.Gen(bn).generate() for bn in (128, 64)}
+
+
+def test_every_tile_body_has_the_full_mfma_count_and_one_barrier():
+    for bn, lines in _blocks().items():
+        per_tile = 4 * 4 * 2 * (bn // 64)                                   # 4 k-groups x 4 j x MB x NB
+        text = "\n".join(lines)
+        bodies = re.split(r"\.Lvk\d+_(?:body0|body1|tail0|tail1|end)_%=:", text)[1:5]
+        assert len(bodies) == 4
+        for i, b in enumerate(bodies):
+            assert b.count("v_mfma_f32_32x32x2_f32") == per_tile
+            assert b.count("s_barrier") == (1 if i < 2 else 0)                  # steady-state bodies only; the last tile fetches nothing
+            assert b.count("buffer_load_dwordx4") == ((4 + bn // 32) if i < 2 else 0)
+
+
+def test_exec_is_whole_again_before_every_lds_dma_load_and_no_mfma_runs_under_a_narrowed_exec():
+    for lines in _blocks().values():
+        narrowed = False
+        for l in lines:
+            if l.startswith("v_cmpx"):
+                narrowed = True
+            elif l.startswith("s_mov_b64 exec, -1"):
+                narrowed = False
+            elif l.startswith(("buffer_load", "v_mfma", "ds_read", "s_barrier", "s_cbranch", "s_branch")):
+                assert not narrowed, l
+
+
+def test_m0_is_written_at_least_one_instruction_before_the_load_that_uses_it():
+    for lines in _blocks().values():
+        for i, l in enumerate(lines):
+            if l.startswith("buffer_load"):
+                assert not lines[i - 1].startswith("s_add_i32 m0"), (lines[i - 1], l)          # 1 wait state: SALU M0 write -> LDS-DMA
+                assert any(x.startswith("s_add_i32 m0") for x in lines[max(0, i - 10):i])
+
+
+def test_accumulator_chain_order_is_k_group_then_j():
+    """per accumulator the A/B fragment registers come in the order the C++ loop multiplies them (bit-identical results)"""
+    g = _gen()
+    for bn in (128, 64):
+        gen = g.Gen(bn)
+        for s in (0, 1):
+            seq = {}
+            for l in gen.mfmas(s):
+                m = re.match(r"v_mfma_f32_32x32x2_f32 %\[(c\d\d)\], v(\d+), v(\d+),", l)
+                seq.setdefault(m.group(1), []).append((int(m.group(2)), int(m.group(3))))
+            for acc, ops in seq.items():
+                mb, nb = int(acc[1]), int(acc[2])
+                a0, b0 = g.frag(s, f"A{mb}", 0), g.frag(s, f"B{nb}", 0)
+                assert ops == [(a0 + j, b0 + j) for j in range(4)]

@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Writes csrc/conv_kloop_gfx950.inc: the steady-state K loop of conv_mfma_kernel<128, BN, 2, 2, true, true> (BN = 128, 64) as one
+gfx950 assembly block per tile shape -- explicit issue order, s_waitcnt placement and barrier position.
+
+    python tools/gen_conv_kloop.py            # rewrites the .inc (tests/test_kloop_gen.py checks the committed file is what this prints)
+
+What one K-tile (32 floats of K, tile t in LDS buffer b, tile t+1 fetched into buffer b^1) looks like for a wave
+(MB x NB blocks of 32x32, G = 4*MB*NB MFMAs per 8-k group, four groups per tile):
+
+    group 0   wait for fragment set 0 | ds_read set 1 <- (b, k-group 1) | G MFMAs on set 0, between them: the cursor arithmetic
+              (SALU), per gathered row the validity test + `buffer_load_dwordx4 ... lds` of tile t+1, then the weight rows
+    group 1   wait set 1 | ds_read set 0 <- (b, k-group 2) | G MFMAs on set 1
+    group 2   wait set 0 | ds_read set 1 <- (b, k-group 3) | G MFMAs on set 0
+    group 3   wait set 1 (= every read of buffer b has returned) | G/4 MFMAs | s_waitcnt vmcnt(0) + s_barrier (tile t+1 has
+              landed for everyone, buffer b is free) | ds_read set 0 <- (b^1, k-group 0) | the other 3G/4 MFMAs on set 1
+
+Every fragment read is issued a whole group (G x 64 cycles) before its first use, so its s_waitcnt never stalls; hipcc's own
+schedule of the same loop issues the reads behind the group's MFMAs, two MFMAs before their use (profiles/README.md r03).
+The MFMA order per accumulator is the C++ loop's (k-group, then j = 0..3), so the results are bit-identical to it.
+
+Registers: fragments live in v[FR .. FR+31] (named in the clobber list: inline-asm operands cannot address the single
+registers of a 128-bit tuple, which the MFMA operands are); everything else is an operand.
+"""
+import os
+import sys
+
+FR = 96                       # first fragment register: 8 tuples of 4
+
+
+def frag(s, name, nb_count):
+    """register tuple base of fragment `name` (A0, A1, B0, B1) of set s"""
+    idx = {"A0": 0, "A1": 4, "B0": 8, "B1": 12}[name]
+    return FR + 16 * s + idx
+
+
+def tup(r):
+    return f"v[{r}:{r + 3}]"
+
+
+class Gen:
+    def __init__(self, BN):
+        self.BM, self.BN = 128, BN
+        self.MB, self.NB = 2, BN // 64
+        self.G = 4 * self.MB * self.NB
+        self.A_ROWS = 4
+        self.B_PASS = BN // 32
+        self.A_BUF = self.BM * 128           # bytes per A buffer
+        self.B_BUF = self.BN * 128
+        self.out = []
+
+    def e(self, s):
+        self.out.append(s)
+
+    # -- pieces
+    def reads(self, buf, q, s):
+        a, b = buf * self.A_BUF, buf * self.B_BUF
+        r = [f"ds_read_b128 {tup(frag(s, 'A0', 0))}, %[la{q}] offset:{a}",
+             f"ds_read_b128 {tup(frag(s, 'B0', 0))}, %[lb{q}] offset:{b}",
+             f"ds_read_b128 {tup(frag(s, 'A1', 0))}, %[la{q}] offset:{a + 4096}"]
+        if self.NB == 2:
+            r.append(f"ds_read_b128 {tup(frag(s, 'B1', 0))}, %[lb{q}] offset:{b + 4096}")
+        return r
+
+    def mfmas(self, s):
+        m = []
+        for jj in range(4):
+            for mb in range(self.MB):
+                for nb in range(self.NB):
+                    a = frag(s, f"A{mb}", 0) + jj
+                    b = frag(s, f"B{nb}", 0) + jj
+                    m.append(f"v_mfma_f32_32x32x2_f32 %[c{mb}{nb}], v{a}, v{b}, %[c{mb}{nb}]")
+        return m
+
+    def cursor_chunks(self):
+        c1 = ["s_lshl_b32 %[qseg], %[kc], 5",
+              "s_mul_i32 %[t], %[sg], %[lstride]",
+              "s_add_i32 %[qabs], %[t], %[qseg]",
+              "s_mul_i32 %[t], %[ky], %[pitch]",
+              "s_add_i32 %[t], %[t], %[qabs]",
+              "s_lshl_b32 %[soff], %[t], 2",
+              "s_mov_b32 %[kyc], %[ky]"]
+        c2 = ["s_add_i32 %[kc], %[kc], 1",
+              "s_cmp_eq_u32 %[kc], %[kps]",
+              "s_cselect_b32 %[kc], 0, %[kc]",
+              "s_addc_u32 %[sg], %[sg], 0",
+              "s_cmp_eq_u32 %[sg], %[nseg]",
+              "s_cselect_b32 %[sg], 0, %[sg]",
+              "s_addc_u32 %[ky], %[ky], 0"]
+        return [c1, c2]
+
+    def row_chunk(self, j, nxt):
+        vo = f"%[vo{j & 1}]"
+        return [f"s_add_i32 m0, %[ma], {nxt * self.A_BUF + j * 4096}",
+                f"v_mov_b32 {vo}, 0xc0000000",
+                f"v_sub_u32 %[vt], %[qabs], %[lo{j}]",
+                f"v_cmpx_gt_u32 vcc, %[span{j}], %[vt]",
+                f"v_add_u32 %[vt], %[kyc], %[y{j}]",
+                f"v_cmpx_gt_u32 vcc, %[hi], %[vt]",
+                f"v_cmpx_lt_i32 vcc, %[qseg], %[w{j}]",
+                f"v_mov_b32 {vo}, %[x{j}]",
+                "s_mov_b64 exec, -1",
+                f"buffer_load_dwordx4 {vo}, %[rin], %[soff] offen lds"]
+
+    def b_chunk(self, jb, nxt):
+        c = [f"s_add_i32 m0, %[mb], {nxt * self.B_BUF + jb * 4096}",
+             f"s_add_i32 %[t], %[soffw], {jb * 4096}",
+             f"buffer_load_dwordx4 %[wv], %[rwt], %[t] offen lds"]
+        if jb == self.B_PASS - 1:
+            c.append("s_add_i32 %[soffw], %[soffw], %[wstep]")
+        return c
+
+    def group(self, pre, mf, chunks_at, post=()):
+        """pre: lines before the first MFMA; mf: MFMA lines; chunks_at: {slot: [lines]} issued after MFMA `slot`"""
+        for l in pre:
+            self.e(l)
+        for i, m in enumerate(mf):
+            self.e(m)
+            for l in chunks_at.get(i, ()):
+                self.e(l)
+        for l in post:
+            self.e(l)
+
+    def body(self, b, exit_label, next_label):
+        nxt = b ^ 1
+        G = self.G
+        chunks = self.cursor_chunks() + [self.row_chunk(j, nxt) for j in range(self.A_ROWS)] + [self.b_chunk(jb, nxt) for jb in range(self.B_PASS)]
+        stride = 1 if len(chunks) >= G else max(1, (G - 1) // len(chunks))
+        at = {}
+        for i, c in enumerate(chunks):
+            at.setdefault(min(i * stride, G - 2), []).extend(c)
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 1, 1), self.mfmas(0), at)
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 2, 0), self.mfmas(1), {})
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 3, 1), self.mfmas(0), {})
+        k = G // 4
+        at3 = {k - 1: ["s_waitcnt vmcnt(0)", "s_barrier"] + self.reads(nxt, 0, 0),
+               k: ["s_sub_u32 %[n], %[n], 1"]}
+        post = ["s_cmp_eq_u32 %[n], 0", f"s_cbranch_scc1 {exit_label}"]
+        if next_label:
+            post.append(f"s_branch {next_label}")
+        self.group(["s_waitcnt lgkmcnt(0)"], self.mfmas(1), at3, post)
+
+    def tail(self, b, end_label):
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 1, 1), self.mfmas(0), {})
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 2, 0), self.mfmas(1), {})
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 3, 1), self.mfmas(0), {})
+        self.group(["s_waitcnt lgkmcnt(0)"], self.mfmas(1), {}, [f"s_branch {end_label}"] if end_label else [])
+
+    def generate(self):
+        L = lambda n: f".Lvk{self.BN}_{n}_%="
+        self.e("s_nop 4")
+        for l in self.reads(0, 0, 0):
+            self.e(l)
+        self.e("s_cmp_eq_u32 %[n], 0")
+        self.e(f"s_cbranch_scc1 {L('tail0')}")
+        self.e(L("body0") + ":")
+        self.body(0, L("tail1"), None)
+        self.e(L("body1") + ":")
+        self.body(1, L("tail0"), L("body0"))
+        self.e(L("tail0") + ":")
+        self.tail(0, L("end"))
+        self.e(L("tail1") + ":")
+        self.tail(1, None)
+        self.e(L("end") + ":")
+        self.e("s_nop 15")          # the last MFMAs' results are read by the epilogue's v_accvgpr_read: 18 wait states (16-pass XDL write -> VALU read)
+        self.e("s_nop 7")
+        return self.out
+
+    def clobbers(self):
+        return [f"v{FR + i}" for i in range(32)]     # the B1 tuples of the 64-column shape stay unused: one list for both shapes
+
+
+def render():
+    o = ["// GENERATED by tools/gen_conv_kloop.py -- do not edit; see that file for the schedule this encodes.",
+         "// clang-format off"]
+    for BN in (128, 64):
+        g = Gen(BN)
+        lines = g.generate()
+        o.append(f"#define VSTAB_KLOOP_ASM_128x{BN} \\")
+        for l in lines:
+            o.append(f'    "{l}\\n" \\')
+        o.append("    \"\"")
+        if BN == 128:
+            o.append("#define VSTAB_KLOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in g.clobbers()))
+    o.append("// clang-format on")
+    return "\n".join(o) + "\n"
+
+
+if __name__ == "__main__":
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "coupe", "optical_flow_based_deep_video_stabilization_amd", "csrc",
+                        "conv_kloop_gfx950.inc")
+    text = render()
+    if len(sys.argv) > 1 and sys.argv[1] == "--print":
+        sys.stdout.write(text)
+    else:
+        with open(path, "w") as f:
+            f.write(text)
+        print("wrote", os.path.normpath(path), len(text.splitlines()), "lines")
