@@ -32,6 +32,8 @@ namespace vstab {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#include "conv_kloop_gfx950.inc"
 
 // MB = 32-pixel blocks per wave: 2 -> 128 output pixels per workgroup (wave tile 64 x 32); 1 -> 64 pixels (wave tile 32 x 32) for
 // launches that would otherwise put fewer than two workgroups on a CU (one sample at 384x512: 384 workgroups on 256 CUs run as
@@ -71,8 +73,11 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
             wv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
         }
     };
+    // byte stride of the two window buffers: the assembly loop fetches windows by LDS-DMA, whole 4 KB wave chunks (lanes past the
+    // window's end land zeros), so its buffers are a whole number of chunks apart
+    const int wstride = (MB == 2 && p.asm_loop) ? VSTAB_ROWWIN_BUF_BYTES / 4 : p.WLEN;
     auto store_window = [&](int buf) {
-        float *d = win + buf * p.WLEN;
+        float *d = win + buf * wstride;
 #pragma unroll
         for (int j = 0; j < NWIN4; ++j) {
             const int c4 = tid + 256 * j;
@@ -122,6 +127,51 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
 
     load_window(0);
     store_window(0);
+    if (MB == 2 && p.asm_loop) {
+        // The K loop as one assembly block (conv_kloop_gfx950.inc; tools/gen_conv_kloop.py documents the schedule): same MFMA order per
+        // accumulator as the C++ loop below, so the same bits; fragments of K-tile t+1 are requested under the MFMAs of tile t,
+        // the next filter row's window arrives by LDS-DMA, one barrier per filter row.
+        if constexpr (MB == 2) {
+            __syncthreads();
+            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)win;
+            unsigned a0c = lds0 + (unsigned)a_off0 * 4u, a1c = lds0 + (unsigned)a_off1 * 4u;
+            unsigned a0n = a0c + VSTAB_ROWWIN_BUF_BYTES, a1n = a1c + VSTAB_ROWWIN_BUF_BYTES;
+            const unsigned vb = (unsigned)((wn * 32 + li) * 32 + lh * 4) * 4u;
+            unsigned w[7];                            // per-lane byte offset of its 16 bytes of every window chunk inside the input row, or out of range
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int c4 = tid + 256 * j;
+                const int g = g0 + 4 * c4;
+                w[j] = (g >= 0 && g < row_floats && 4 * c4 < p.WLEN) ? (unsigned)g * 4u : OOB;
+            }
+            const unsigned long long ain = (unsigned long long)(size_t)p.in, awt = (unsigned long long)(size_t)p.wpk;
+            i32x4 din, dwt;
+            din.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ain);
+            din.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ain >> 32) & 0xffffu));
+            din.z = __builtin_amdgcn_readfirstlane((int)p.in_bytes);
+            din.w = 0x00020000;
+            dwt.x = __builtin_amdgcn_readfirstlane((int)(unsigned)awt);
+            dwt.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(awt >> 32) & 0xffffu));
+            dwt.z = __builtin_amdgcn_readfirstlane(KT * ktile_stride * 4);
+            dwt.w = 0x00020000;
+            const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
+            const int m_cur = __builtin_amdgcn_readfirstlane((int)lds0 + wave_u * 1024);
+            int m_n = m_cur + VSTAB_ROWWIN_BUF_BYTES;                     // the first fetch goes to buffer 1
+            const int m_x = m_cur ^ m_n;
+            int s_iy = oy * p.s_in + p.off_y + 1;                         // the next filter row to fetch
+            int s_soff = ((n * p.Hi + s_iy) * p.Wi) * p.Cs_in * 4;
+            int s_koff = 0, s_nrows = p.KH - 1;
+            unsigned v_t0, v_t1;
+            long long s_mask;
+            asm volatile(VSTAB_ROWWIN_ASM_KPR6
+                         : [c0] "+a"(acc[0]), [c1] "+a"(acc[MB - 1]), [a0c] "+v"(a0c), [a1c] "+v"(a1c), [a0n] "+v"(a0n), [a1n] "+v"(a1n),
+                           [mn] "+s"(m_n), [iy] "+s"(s_iy), [soff] "+s"(s_soff), [koff] "+s"(s_koff), [nrows] "+s"(s_nrows),
+                           [vt0] "=&v"(v_t0), [vt1] "=&v"(v_t1), [mask] "=&s"(s_mask)
+                         : [vb] "v"(vb), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]),
+                           [din] "s"(din), [dwt] "s"(dwt), [mx] "s"(m_x), [hi] "s"(p.Hi), [rowbytes] "s"(row_floats * 4), [kstride] "s"(ktile_stride * 4)
+                         : "memory", "scc", VSTAB_ROWWIN_CLOBBERS);
+        }
+    } else {
     load_b(b0, 0);
     __syncthreads();
     int buf = 0, kt = 0;
@@ -156,6 +206,7 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
             __syncthreads();
             buf ^= 1;
         }
+    }
     }
 
     // epilogue: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  As in conv_mfma.hip the tile leaves through LDS (the window
@@ -229,11 +280,16 @@ hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEven
     RowWinParams q = p;
     // the staged epilogue needs 16-byte friendly output rows and the [tile][64] staging area inside the two window buffers
     q.out_vec4 = (((uintptr_t)p.out & 15) == 0 && (p.Cs_out & 3) == 0 && (p.c_off & 3) == 0 && 2 * p.WLEN >= tile * 64) ? 1 : 0;
+    q.asm_loop = (p.MB == 2 && (p.SEGP >> 5) == 6 && p.KH >= 1 && 4 * p.WLEN <= VSTAB_ROWWIN_BUF_BYTES) ? 1 : 0;
+#ifdef VSTAB_NO_ASM_KLOOP
+    q.asm_loop = 0;                              // A/B builds only (scripts/build_variant_lib.sh)
+#endif
+    const size_t lds2 = q.asm_loop ? (size_t)2 * VSTAB_ROWWIN_BUF_BYTES : (size_t)2 * p.WLEN * 4;
     const bool timed = ev_start || ev_stop;      // timestamps of the kernel's own dispatch packet, no marker packets (see conv_mfma.hip); a
                                                  // launch that is one half of a pair carries only the start or only the stop event
     if (p.MB == 2) {
-        if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<7, 2>), grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, q);
-        else conv_rowwin_kernel<7, 2><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(q);
+        if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<7, 2>), grid, block, lds2, stream, ev_start, ev_stop, 0, q);
+        else conv_rowwin_kernel<7, 2><<<grid, block, lds2, stream>>>(q);
     } else {
         if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<4, 1>), grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, q);
         else conv_rowwin_kernel<4, 1><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(q);

@@ -169,6 +169,110 @@ class Gen:
         return [f"v{FR + i}" for i in range(32)]     # the B1 tuples of the 64-column shape stay unused: one list for both shapes
 
 
+class RowWinGen:
+    """conv_rowwin_kernel<7, 2> (the network's first layer): KH filter rows x KPR K-tiles, wave tile 64 pixels x 32 channels.
+
+    One K-tile = 32 MFMAs (16 k-steps x 2 pixel blocks) fed by 8 ds_read2_b64 (A, straight out of the input-row window in LDS)
+    and 4 buffer_load_dwordx4 (B, the packed weights, global -> registers).  Two register sets each; tile t multiplies set t&1
+    while the loads of tile t+1 fill the other one: B first (longest latency), then one A read per MFMA.  The window of filter
+    row ky+1 is fetched by LDS-DMA during tile 0 of row ky (no staging registers, no ds_write); the row's only barrier sits
+    four MFMAs into its last tile: by then every wave has all its reads of this row's window behind it and its share of the
+    next window landed, and the A reads of the next row's first tile follow under the remaining 28 MFMAs."""
+    A = (64, 96)          # A fragment sets: 16 registers per pixel block, two blocks
+    B = (128, 144)        # B fragment sets
+    BUF = 7 * 4096        # byte stride of the two window buffers
+
+    def __init__(self, kpr=6):
+        self.kpr = kpr
+        assert kpr % 2 == 0
+        self.out = []
+
+    def e(self, s):
+        self.out.append(s)
+
+    def mfmas(self, P):
+        m = []
+        for s in range(16):
+            for mb in range(2):
+                m.append(f"v_mfma_f32_32x32x2_f32 %[c{mb}], v{self.A[P] + 16 * mb + s}, v{self.B[P] + s}, %[c{mb}]")
+        return m
+
+    def b_loads(self, Q):
+        r = [f"buffer_load_dwordx4 v[{self.B[Q] + 4 * q}:{self.B[Q] + 4 * q + 3}], %[vb], %[dwt], %[koff] offen offset:{32 * q}" for q in range(4)]
+        r[-1] = [r[-1], "s_add_i32 %[koff], %[koff], %[kstride]"]
+        return [x if isinstance(x, list) else [x] for x in r]
+
+    def a_reads(self, Q, kc, nxt):
+        r = []
+        for i in range(4):
+            for mb in range(2):
+                base = self.A[Q] + 16 * mb + 4 * i
+                addr = f"%[a{mb}{'n' if nxt else 'c'}]"
+                r.append([f"ds_read2_b64 v[{base}:{base + 3}], {addr} offset0:{16 * kc + 4 * i} offset1:{16 * kc + 4 * i + 2}"])
+        return r
+
+    def dma(self):
+        c = [["s_cmp_lt_u32 %[iy], %[hi]", "s_cselect_b64 %[mask], -1, 0"]]
+        for j in range(7):
+            vt = f"%[vt{j & 1}]"
+            c.append([f"s_add_i32 m0, %[mn], {j * 4096}",
+                      f"v_cndmask_b32_e64 {vt}, -2.0, %[w{j}], %[mask]",
+                      f"buffer_load_dwordx4 {vt}, %[din], %[soff] offen lds"])
+        c.append(["s_add_i32 %[iy], %[iy], 1", "s_add_i32 %[soff], %[soff], %[rowbytes]"])
+        return c
+
+    def tile(self, P, wait_vm, chunks, barrier_after=None):
+        self.e(f"s_waitcnt vmcnt({wait_vm}) lgkmcnt(0)")
+        first = 0 if barrier_after is None else barrier_after + 1
+        for i, m in enumerate(self.mfmas(P)):
+            self.e(m)
+            if barrier_after is not None and i == barrier_after:
+                self.e("s_barrier")
+            k = i - first
+            if 0 <= k < len(chunks):
+                for l in chunks[k]:
+                    self.e(l)
+        assert len(chunks) <= 32 - first
+
+    def row(self, more):
+        n = self.kpr
+        for t in range(n):
+            P, Q = t & 1, (t & 1) ^ 1
+            last = t == n - 1
+            if last and not more:
+                self.tile(P, 0, [])
+                continue
+            chunks = self.b_loads(Q) + self.a_reads(Q, 0 if last else t + 1, last)
+            if t == 0 and more:
+                chunks += self.dma()
+            self.tile(P, 7 if (t == 1 and more) else 0, chunks, barrier_after=3 if last else None)
+
+    def generate(self):
+        L = lambda n: f".Lvrw_{n}_%="
+        self.e("s_nop 4")
+        for c in self.b_loads(0) + self.a_reads(0, 0, False):
+            for l in c:
+                self.e(l)
+        self.e("s_cmp_eq_u32 %[nrows], 0")
+        self.e(f"s_cbranch_scc1 {L('last')}")
+        self.e(L("more") + ":")
+        self.row(True)
+        self.e("v_swap_b32 %[a0c], %[a0n]")
+        self.e("v_swap_b32 %[a1c], %[a1n]")
+        self.e("s_xor_b32 %[mn], %[mn], %[mx]")          # mx = m_cur ^ m_nxt: toggles between the two buffers' DMA bases
+        self.e("s_sub_u32 %[nrows], %[nrows], 1")
+        self.e("s_cmp_lg_u32 %[nrows], 0")
+        self.e(f"s_cbranch_scc1 {L('more')}")
+        self.e(L("last") + ":")
+        self.row(False)
+        self.e("s_nop 15")
+        self.e("s_nop 7")
+        return self.out
+
+    def clobbers(self):
+        return [f"v{i}" for i in range(self.A[0], self.B[1] + 16)]
+
+
 def render():
     o = ["// GENERATED by tools/gen_conv_kloop.py -- do not edit; see that file for the schedule this encodes.",
          "// clang-format off"]
@@ -181,6 +285,13 @@ def render():
         o.append("    \"\"")
         if BN == 128:
             o.append("#define VSTAB_KLOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in g.clobbers()))
+    r = RowWinGen(6)
+    o.append("#define VSTAB_ROWWIN_ASM_KPR6 \\")
+    for l in r.generate():
+        o.append(f'    "{l}\\n" \\')
+    o.append("    \"\"")
+    o.append("#define VSTAB_ROWWIN_CLOBBERS " + ", ".join(f'"{c}"' for c in r.clobbers()))
+    o.append("#define VSTAB_ROWWIN_BUF_BYTES " + str(RowWinGen.BUF))
     o.append("// clang-format on")
     return "\n".join(o) + "\n"
 
