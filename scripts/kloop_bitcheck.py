@@ -16,5 +16,15 @@ g = torch.Generator().manual_seed(1000)
 feats = torch.rand(B, H, W, 27, generator=g).cuda()
 outs = vs.flownetS_pyramid(feats, B)
 torch.cuda.synchronize()
-for i, o in enumerate(outs if isinstance(outs, (tuple, list)) else [outs]):
-    print(i, tuple(o.shape), hashlib.sha256(o.detach().cpu().numpy().tobytes()).hexdigest()[:24])
+def walk(name, o):
+    if isinstance(o, dict):
+        for k in sorted(o):
+            walk(f"{name}.{k}", o[k])
+    elif isinstance(o, (tuple, list)):
+        for i, v in enumerate(o):
+            walk(f"{name}[{i}]", v)
+    elif torch.is_tensor(o):
+        print(name, tuple(o.shape), hashlib.sha256(o.detach().cpu().numpy().tobytes()).hexdigest()[:24])
+
+
+walk("out", outs)
