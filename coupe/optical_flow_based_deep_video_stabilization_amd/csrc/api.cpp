@@ -138,7 +138,8 @@ static double split_cost_us(long long tiles, int KT, int ks, double slab_bytes, 
     // 64-row tiles cost half a 128-row tile per K-tile when few workgroups run (measured), a little more than half
     // on a full chip (1.5x the LDS fragment reads per MFMA), so large layers keep the 128-row tile
     const double TAU2 = 4.2 * (BN >= 128 ? 1.0 : (BN == 64 ? 0.58 : 0.36)) * (BM == 64 ? 0.55 : 1.0);
-    const double TAU1 = 0.525 * TAU2, T0 = 5.0;     // in-situ: 2.10 vs 4.00 us per K-tile (conv4_1), 2.20 vs 4.19 (conv4)
+    const double TAU1 = 0.525 * TAU2, T0 = 5.0;     // in-situ: 2.10 vs 4.00 us per K-tile (conv4_1), 2.20 vs 4.19 (conv4); with the assembly K loop
+                                                    // 1.87 vs 3.52: same ratio, and 3.55 / 0.53 / T0 3..11 pick the same splits at B=8 512x512 (r03k sweep)
     const double BW = 1.2e7;                                        // bytes per us for the slab traffic (L2 / MALL resident)
     const int kts = (KT + ks - 1) / ks, ks_eff = (KT + kts - 1) / kts;
     const long long blocks = tiles * ks_eff, full = blocks / 512, rem = blocks % 512;
@@ -325,10 +326,14 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         if (ENC_IO[i].cs_in != cin_i || !wino_applies(B, pl.eh[i], pl.ew[i], cin_i, e.cout)) continue;      // plain input buffer
         const int TH = (pl.eh[i] + 1) / 2, TW = (pl.ew[i] + 1) / 2;
         fill_wino_gemm(pl.wcp[i], B, pl.eh[i], pl.ew[i], cin_i, e.cout);
-        // 128x64 tiles: the reduction is short (K = C_in: 8..32 K-tiles), so prologue and epilogue weigh in and THREE co-resident
-        // workgroups per CU (48 KB of LDS each) overlap them better than two 128x128 ones (measured: 181 -> 176, 154 -> 149,
-        // 50 -> 45.5 us; a 128x256 tile with one workgroup per CU: 227 / 177 / 88 us)
-        pl.wtile[i] = TILE_128x64;
+        // The reduction is short (K = C_in: 8..32 K-tiles), so a workgroup's prologue and epilogue weigh in.  Stages with at least
+        // two full rounds of 128x128 tiles (2 per CU) take those: twice the MFMA work per prologue + epilogue (in situ with the
+        // assembly K loop, B=8 512x512: conv3_1 163.5 -> 152 us, conv4_1 138 -> 135.5); smaller stages keep 128x64 tiles, three
+        // co-resident workgroups per CU (conv5_1 40 vs 41.3 us, conv6_1 44.5 vs 68.5)
+        {
+            const long long t128 = 16LL * ((pl.wcp[i].Mmax + 127) / 128) * (e.cout / 128);
+            pl.wtile[i] = t128 >= 1024 ? TILE_128x128 : TILE_128x64;
+        }
         wino_v = std::max(wino_v, (size_t)B * 16 * TH * TW * cin_i);
         wino_m = std::max(wino_m, (size_t)B * 16 * TH * TW * e.cout);
         pl.wino[i] = true;
