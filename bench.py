@@ -416,8 +416,10 @@ def main():
                     # Winograd F(2x2,3x3) form (4/9 of the direct convolution's multiply-adds); *_direct count those layers as the
                     # direct convolutions SURVEY.md 8d prices -- a work rate, which may exceed what the matrix pipe itself does
                     "flops_counted": "issued by the MFMA kernel; *_direct = same layers as direct convolutions (Winograd stages x9/4)",
-                    "note": "peak = 157.3 TFLOP/s at the nominal 2.4 GHz; in situ the chip holds 2.32-2.35 GHz in these launches (PMC on long dispatches, "
-                            "profiles/power_clock_r03_insitu.txt) with the matrix pipe 0.83-0.86 busy: the gap is prologue + epilogue that all workgroups of a launch run in lockstep",
+                    "note": "peak = 157.3 TFLOP/s at the nominal 2.4 GHz; in situ the chip holds 2.34-2.39 GHz in these launches (in-kernel stamps, "
+                            "profiles/insitu_stamps_r03k_asm.txt); the K loops are assembly blocks (0.98 of the pipe with two workgroups per CU, 0.94 with one), "
+                            "what is left is prologue + epilogue that the workgroups of a launch run in lockstep; the dominant kernel's average includes the "
+                            "short-reduction Winograd-domain GEMMs of conv3_1 / conv4_1 (0.71 / 0.81; conv2 / conv3 0.89 / 0.91)",
                     "achieved_direct": round(d_dfl / (d_ms * 1e-3) / 1e12, 2),
                     "frac_direct": round(d_dfl / (d_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                     "all_mfma_launches": {"launches_per_step": 15, "ms_per_step": round(tot_ms, 4),
