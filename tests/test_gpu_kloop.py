@@ -1,0 +1,52 @@
+"""The assembly K loops (csrc/conv_kloop_gfx950.inc) through the C ABI's generic convolution: reductions of one, two, three ... K-tiles
+take the loop's tail-only / body0 / body1 exits for both tile shapes it serves (128x128: cout >= 128, 128x64: cout = 64), rows past
+the end of the GEMM, padded segment tails and out-of-image taps ride on the EXEC-narrowed validity test.  Reference: torch conv2d in
+fp64 on the CPU.  (The first layer's row-window loop is reached through the network only: tests/test_gpu_parity.py, test_gpu_network_property.py.)"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_forward(x, W, b, k, s, p, act=0):
+    B, Hi, Wi, cin = x.shape
+    cout = W.shape[3]
+    Ho, Wo = (Hi + 2 * p - k) // s + 1, (Wi + 2 * p - k) // s + 1
+    y = torch.empty(B, Ho, Wo, cout, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    n = L.vstab_conv_forward_workspace_bytes(B, Hi, Wi, cin, cin, k, s, p, cout, cout, 0, act, Ho, Wo)
+    assert n > 0
+    ws = torch.empty(int(n) + 256, dtype=torch.uint8, device=x.device)
+    _lib.check(L.vstab_conv_forward(x.data_ptr(), B, Hi, Wi, cin, 0, cin, W.data_ptr(), b.data_ptr(), k, s, p, y.data_ptr(), Ho, Wo, cout, 0, cout, act,
+                                    ws.data_ptr(), ws.numel(), None))
+    torch.cuda.synchronize()
+    return y
+
+
+def _ref(x, W, b, k, s, p):
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), W.double().permute(3, 2, 0, 1), b.double(), stride=s, padding=p)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("cout", [64, 128, 256])
+@pytest.mark.parametrize("B,H,W,cin,k,s,p", [
+    (2, 16, 16, 32, 1, 1, 0),      # one K-tile: the loop is its tail only
+    (2, 16, 16, 64, 1, 1, 0),      # two: body 0, tail 1
+    (1, 20, 24, 96, 1, 1, 0),      # three: body 0, body 1, tail 0
+    (3, 9, 11, 128, 1, 1, 0),      # four, rows past the end of the GEMM (297 = 2 x 128 + 41)
+    (2, 13, 17, 36, 3, 1, 1),      # 3x3, padded segment tail (108 of 128 floats), out-of-image taps, odd sizes
+    (1, 23, 29, 64, 5, 2, 2),      # 5x5 stride 2 (conv2 / conv3's form)
+    (2, 12, 12, 260, 3, 2, 1),     # segment of 780 floats: 25 K-tiles per filter row, the last one 12 floats
+])
+def test_generic_conv_through_the_assembly_k_loop(B, H, W, cin, k, s, p, cout):
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout + k)
+    x = torch.randn(B, H, W, cin, generator=g)
+    Wt = torch.randn(k, k, cin, cout, generator=g) / (k * k * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    y = _conv_forward(x.cuda(), Wt.cuda(), b.cuda(), k, s, p)
+    ref = _ref(x, Wt, b, k, s, p)
+    assert y.shape == ref.shape
+    assert float((y.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
