@@ -83,6 +83,7 @@ EXPORTS = {
     "vstab_column_sum": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vstab_pf2_from_taps": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vstab_pf2_taps_backward": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_predict2_tap_table": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vstab_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_float] * 4 + [C.c_void_p]),
     "vstab_bn_scratch_bytes": (C.c_size_t, [C.c_longlong, C.c_int]),
     "vstab_bn_lrelu_train_forward": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

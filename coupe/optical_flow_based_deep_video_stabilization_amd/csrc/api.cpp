@@ -383,11 +383,8 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         p.Ho = p.Hi; p.Wo = p.Wi; p.Cs_out = 32; p.c_off = 0;
         p.N = 32; p.Npad = 32; p.act = 0; p.nphase = 1; p.ksplit = 1;
         p.ph[0].Hg = p.Hi; p.ph[0].Wg = p.Wi; p.ph[0].M = B * p.Hi * p.Wi; p.Mmax = p.ph[0].M;
-        // 256-row tiles while they still fill the chip once (B=8 512^2: 512 workgroups, two per CU: 42 -> 36 us); more rows per
-        // workgroup amortise the 7-K-tile loop's prologue.  Larger launches keep 128 rows (four workgroups per CU: B=16 1080p
-        // 516 vs 542 us), smaller ones would leave CUs idle
-        const long long t256 = ((long long)B * pl.eh[1] * pl.ew[1] + 255) / 256;
-        pl.tile[14] = (t256 >= 256 && t256 <= 640) ? TILE_256x32 : TILE_128x32; pl.vec4[14] = true;
+        // (launched as tap_panel_kernel, tap_panel.hip: the parameters here only feed the flop / byte accounting of the reports)
+        pl.tile[14] = TILE_128x32; pl.vec4[14] = true;
         set_ranges(p);
     }
     // ---- predict6..3 tap tables: 1x1 conv of the level's (concat) tensor -> 18 (pad 32) columns
@@ -453,6 +450,7 @@ extern "C" int vstab_create(vstab_ctx **out, int device)
     HIP_TRY(nullptr, hipSetDevice(device));
     HIP_TRY(nullptr, conv_set_attributes());
     HIP_TRY(nullptr, rowwin_set_attributes());
+    HIP_TRY(nullptr, tap_panel_set_attributes());
     vstab_ctx *c = new (std::nothrow) vstab_ctx();
     if (!c) return fail(nullptr, VSTAB_E_NOMEM, "vstab_create: out of host memory");
     c->device = device;
@@ -658,10 +656,9 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
     {
         NEED(W, "predict2/W_conv2d", 3, 3, 194, 2)
         NEED(b, "predict2/b_conv2d", 2)
-        const KLayout L = klayout_run(1, 1, 196);
-        ctx->tab_w = reserve((size_t)L.ktiles() * 32 * 32);
-        pack_predict2_table(W->data, 194, 196, 32, host.data() + ctx->tab_w);
         ctx->tab_b = reserve(32);
+        ctx->tab_wp = reserve((size_t)200 * 32);
+        pack_predict2_panel(W->data, 194, 200, host.data() + ctx->tab_wp);
         ctx->zero_b = reserve(1024);             // zero bias for the Winograd-domain GEMMs (bias is added by the inverse transform)
         ctx->pred2_b = reserve(4);
         host[ctx->pred2_b] = b->data[0]; host[ctx->pred2_b + 1] = b->data[1];
@@ -869,9 +866,10 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         TraceRange layer_range("predict_flow2");
         ConvParams p = pl.cp[14];
         p.in = buf(B_CONCAT2); p.out = buf(B_T);
-        p.wpk = dw + ctx->tab_w; p.bias = dw + ctx->tab_b; p.partial = nullptr;
-        HIP_TRY(ctx, launch_conv(p, pl.tile[14], true, stream, EV_A(14), EV_B(14)));
-        ctx->prof_kernel[14] = conv_kernel_name(pl.tile[14], true);
+        const long long M2 = (long long)B * pl.eh[1] * pl.ew[1];
+        if (!tap_panel_applicable(M2, p.Cs_in, p.in, p.out)) return fail(ctx, VSTAB_E_SHAPE, "predict_flow2 tap table: unsupported geometry");
+        HIP_TRY(ctx, launch_tap_panel(p.in, M2, dw + ctx->tab_wp, p.out, stream, EV_A(14), EV_B(14)));
+        ctx->prof_kernel[14] = "tap_panel_kernel";
         HIP_TRY(ctx, launch_pf2(buf(B_T), B, pl.eh[1], pl.ew[1], dw + ctx->pred2_b, pf3, pl.eh[3], pl.ew[3], pf2, H, W, stream));
     }
 #undef EV_A

@@ -163,6 +163,15 @@ void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wp
                  [&](int, int, int ci, int n) { return W[((size_t)(n >> 1) * cin + ci) * 2 + (n & 1)]; }, wpk);
 }
 
+// the same table for tap_panel_kernel (tap_panel.hip): plain [kpad][32] rows, row c = input channel, column n = 2 * tap + component;
+// rows >= cin (concat2's padding channels, the tail of the last 8-float chunk) and columns >= 18 are zero
+void pack_predict2_panel(const float *W, int cin, int kpad, float *wp)
+{
+    std::memset(wp, 0, sizeof(float) * (size_t)kpad * 32);
+    for (int c = 0; c < cin; ++c)
+        for (int n = 0; n < 18; ++n) wp[(size_t)c * 32 + n] = W[((size_t)(n >> 1) * cin + c) * 2 + (n & 1)];
+}
+
 // ---------------------------------------------------------------------------------
 // Index tables for DEVICE-side packing (training: the weights change every step, so the gather is replayed on the GPU
 // by pack_apply_kernel): tbl[i] = 1 + index into the raw weight tensor of packed element i, 0 = structural zero.

@@ -563,6 +563,17 @@ extern "C" int vstab_pf2_from_taps(const float *T, int B, int h2, int w2, const 
     return VSTAB_OK;
 }
 
+extern "C" int vstab_predict2_tap_table(const float *concat2, long long M, const float *table, float *T, void *stream)
+{
+    if (!concat2 || !table || !T) return fail(nullptr, VSTAB_E_STATE, "predict2_tap_table: NULL buffer");
+    if (M < 1 || M * 784 >= 0x80000000LL) return fail(nullptr, VSTAB_E_SHAPE, "predict2_tap_table: 1 <= M, M * 784 < 2^31");
+    if (((uintptr_t)concat2 | (uintptr_t)T | (uintptr_t)table) & 15) return fail(nullptr, VSTAB_E_ALIGN, "predict2_tap_table: buffers must be 16-byte aligned");
+    static const hipError_t attr = tap_panel_set_attributes();
+    HIP_TRY(nullptr, attr);
+    HIP_TRY(nullptr, launch_tap_panel(concat2, M, table, T, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_pf2_taps_backward(const float *g, int cs_g, int B, int H, int W, float *dT, int h2, int w2, void *stream)
 {
     if (!g || !dT) return fail(nullptr, VSTAB_E_STATE, "pf2_taps_backward: NULL buffer");

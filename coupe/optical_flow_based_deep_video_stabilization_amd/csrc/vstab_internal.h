@@ -175,6 +175,11 @@ hipError_t launch_predict_up(const float *src, int ks, long long slab_stride, in
 
 // predict_flow2 (model.py:882-887) from the per-source-pixel tap table T[B,h2,w2,32]
 // (T[.., tap*2 + o] = sum_c concat2[.., c] * W[tap][c][o]) and pf3.
+// predict_flow2's tap table as one burst-loaded panel per 64 pixel rows (tap_panel.hip): x [M][196], wp [200][32], T [M][32]
+bool tap_panel_applicable(long long M, int cs_in, const void *x, const void *T);
+hipError_t launch_tap_panel(const float *x, long long M, const float *wp, float *T, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                            hipEvent_t ev_stop = nullptr);
+hipError_t tap_panel_set_attributes();
 hipError_t launch_pf2(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3,
                       int h3, int w3, float *pf2, int H, int W, hipStream_t stream);
 
@@ -337,6 +342,7 @@ void pack_winograd(const float *W, const double *scale, int cin, int cout, int n
 // predict head W[3][3][Cin][2] -> tap-table weights: 1x1 conv (run mode over cs_in) with 18 (pad npad)
 // output columns, col = tap*2 + o
 void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wpk);
+void pack_predict2_panel(const float *W, int cin, int kpad, float *wp);        // [kpad][32] for tap_panel_kernel
 
 // BatchNormLayer(lrelu 0.1, no gamma) in training mode, in place on an NHWC channel slice, and its backward (train_ops.hip).
 // scratch: 2 * bn_chunks(rows, C) * C floats.

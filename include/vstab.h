@@ -347,6 +347,11 @@ VSTAB_API int vstab_pad_nearest_upsample_backward(const float *dout, int B, int 
 VSTAB_API int vstab_pf2_from_taps(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2,
                                   int H, int W, void *stream);
 VSTAB_API int vstab_pf2_taps_backward(const float *g, int cs_g, int B, int H, int W, float *dT, int h2, int w2, void *stream);
+/* The tap table itself as vstab_flownets_forward computes it (csrc/tap_panel.hip; model.py:882-885's 3x3 head applied per SOURCE pixel):
+ * T [M,32] = concat2 [M,196] x table, M = B*h2*w2 pixel rows of 196 floats (194 channels + 2 of padding), table [200][32] on the device with
+ * table[c][tap*2+o] = W[tap][c][o] for c < 194, zero elsewhere (rows 194..199 and columns 18..31).  concat2 and T 16-byte aligned,
+ * M*784 < 2^31. */
+VSTAB_API int vstab_predict2_tap_table(const float *concat2, long long M, const float *table, float *T, void *stream);
 /* out[c] (+)= sum over the rows of g[row*cs + c_off + c] (bias gradients), deterministic two-stage reduction. */
 VSTAB_API size_t vstab_column_sum_scratch_bytes(long long rows, int C);
 VSTAB_API int vstab_column_sum(const float *g, long long rows, int cs, int c_off, int C, float *out, int accumulate, void *scratch,

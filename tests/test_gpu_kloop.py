@@ -50,3 +50,56 @@ def test_generic_conv_through_the_assembly_k_loop(B, H, W, cin, k, s, p, cout):
     ref = _ref(x, Wt, b, k, s, p)
     assert y.shape == ref.shape
     assert float((y.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+
+
+# ----------------------------------------------------------------------------- predict_flow2's tap table (csrc/tap_panel.hip)
+def _tap_table(W):
+    """[200][32] device table of vstab_predict2_tap_table from the head's filter W [3,3,194,2]"""
+    t = torch.zeros(200, 32, dtype=torch.float32)
+    t[:194, :18] = W.reshape(9, 194, 2).permute(1, 0, 2).reshape(194, 18)
+    return t
+
+
+@pytest.mark.parametrize("M", [32, 33, 1000, 8 * 128 * 128])
+def test_predict2_tap_table_vs_fp64_matmul(M):
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, 196, generator=g)
+    W = torch.randn(3, 3, 194, 2, generator=g) / 194 ** 0.5
+    tab = _tap_table(W)
+    xd, td = x.cuda(), tab.cuda()
+    T = torch.full((M, 32), 7.0, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().vstab_predict2_tap_table(xd.data_ptr(), M, td.data_ptr(), T.data_ptr(), None))
+    torch.cuda.synchronize()
+    ref = x.double() @ tab.double()[:196]                             # rows 196..199 of the table pair with the NEXT pixel's floats: zero
+    assert float((T.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float(T[:, 18:].abs().max()) == 0.0                       # the padding columns of the table rows are written as zeros
+
+
+def test_predict2_tap_table_keeps_pixels_apart():
+    """a workgroup multiplies straight out of the contiguous pixel rows; the last 8-float chunk of a row reaches into the NEXT pixel's
+    first four floats, which must not leak into this pixel's sums -- not even as NaN * 0; nor may concat2's two padding channels"""
+    g = torch.Generator().manual_seed(5)
+    M = 96
+    x = torch.randn(M, 196, generator=g)
+    W = torch.randn(3, 3, 194, 2, generator=g) / 194 ** 0.5
+    tab = _tap_table(W).cuda()
+    T0 = torch.empty(M, 32, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().vstab_predict2_tap_table(x.cuda().data_ptr(), M, tab.data_ptr(), T0.data_ptr(), None))
+    x2 = x.clone()
+    x2[40, 0:4] = float("nan")                                       # pixel 40's first floats: only row 40 of T may change
+    xd = x2.cuda()
+    T1 = torch.empty(M, 32, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().vstab_predict2_tap_table(xd.data_ptr(), M, tab.data_ptr(), T1.data_ptr(), None))
+    torch.cuda.synchronize()
+    keep = torch.ones(M, dtype=torch.bool); keep[40] = False
+    assert torch.equal(T0.cpu()[keep], T1.cpu()[keep])
+    assert bool(torch.isnan(T1[40, :18]).all())
+
+
+def test_predict2_tap_table_rejects_bad_arguments():
+    L = _lib.lib()
+    x = torch.zeros(64, 196, device="cuda"); tab = torch.zeros(200, 32, device="cuda"); T = torch.zeros(64, 32, device="cuda")
+    assert L.vstab_predict2_tap_table(None, 64, tab.data_ptr(), T.data_ptr(), None) != 0
+    assert L.vstab_predict2_tap_table(x.data_ptr(), 0, tab.data_ptr(), T.data_ptr(), None) != 0
+    assert L.vstab_predict2_tap_table(x.data_ptr(), 3_000_000, tab.data_ptr(), T.data_ptr(), None) != 0       # 2.35e9 bytes of rows
+    assert L.vstab_predict2_tap_table(x.data_ptr() + 4, 32, tab.data_ptr(), T.data_ptr(), None) != 0
