@@ -369,6 +369,7 @@ def main():
     # launch is bracketed by HIP events on its own stream inside the C library; launches are grouped
     # by kernel instantiation (as rocprofv3 names them) and the one with the most time is reported.
     roofline = None
+    tap_launch_ms = None
     if use_events:
         ms, flops, _nrec = ctx.profile_read()      # sums over every recorded pass of the timed region
         dflops = ctx.profile_read_direct()         # the same layers counted as direct convolutions
@@ -383,6 +384,9 @@ def main():
             g_[0] += m / nf; g_[1] += f; g_[2] += 1; g_[3] += df
         dom = max(groups, key=lambda k: groups[k][0])
         tot_ms, tot_fl = sum(ms) / nf, sum(flops)
+        if "predict2_taps" in ctx.LAUNCH_SLOTS:        # the one HBM-bound launch among them: priced by bytes in roofline_hbm.other_rows
+            i14 = list(ctx.LAUNCH_SLOTS).index("predict2_taps")
+            tap_launch_ms = (ms[i14] / nf, inst[i14])
         if rank == 0:
             log(f"{'launch':<14}{'ms':>9}{'GFLOP':>10}{'TFLOP/s':>10}{'frac':>8}  kernel")
             for name, m, f, k in zip(ctx.LAUNCH_SLOTS, ms, flops, inst):
@@ -466,6 +470,15 @@ def main():
                 roofline_hbm["other_rows"] = [{"row": "K9 predict_flow2 gather (pf2_tile_kernel; not HBM-bound: nine LDS taps per pixel)",
                                                "launches": pn, "avg_launch_us": round(pms / pn * 1e3, 2), "alg_bytes_per_launch": pby / pn,
                                                "achieved": round(pg, 1), "unit": "GB/s", "frac": round(pg / HBM_PEAK_GBS, 4)}]
+            if tap_launch_ms and tap_launch_ms[0] > 0:               # K9's table: 784 B read + 128 B written per quarter-resolution pixel
+                h1, w1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+                h2, w2 = (h1 + 4 - 5) // 2 + 1, (w1 + 4 - 5) // 2 + 1
+                tby = float(B * h2 * w2 * (784 + 128))
+                tg = tby / (tap_launch_ms[0] * 1e-3) / 1e9
+                roofline_hbm.setdefault("other_rows", []).append(
+                    {"row": "K9 predict_flow2 tap table (" + tap_launch_ms[1] + "; HBM-bound, 7.8 FLOP/B)", "launches": 1,
+                     "avg_launch_us": round(tap_launch_ms[0] * 1e3, 2), "alg_bytes_per_launch": tby, "achieved": round(tg, 1), "unit": "GB/s",
+                     "frac": round(tg / HBM_PEAK_GBS, 4)})
             # S1-S3: the spatial-transformer / warp.py samplers on this run's frames (24 B per output pixel: 12 gathered + 12 written;
             # theta is 24-36 B per SAMPLE).  Inside the step with --st-warp; otherwise five launches each AFTER the timed region.
             st_kernel = {"affine": "st3_tile_kernel<0, %s>", "projective": "st3_tile_kernel<0, %s>", "homography": "st3_tile_kernel<2, %s>"}
