@@ -28,6 +28,9 @@ namespace vstab {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define VSTAB_COMMA ,
+#include "conv_kloop_gfx950.inc"
 
 // ptab[k] = {x element offset of (n, s*oy - p, s*ox - p, 0), s*oy - p, s*ox - p, 0}
 __global__ __launch_bounds__(256) void wgrad_pixel_table_kernel(int B, int Hi, int Wi, int Cs, int Ho, int Wo, int s, int p,
@@ -126,7 +129,57 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p)
     const int li = lane & 31, lh = lane >> 5;
     const int a_col = wm * 64 + li, b_col = wn * (BN / 2) + li;
 
-    if (kt0 < kt1) {
+#ifdef VSTAB_NO_ASM_KLOOP
+    constexpr bool ASM_KLOOP = false;               // A/B builds only (scripts/build_variant_lib.sh)
+#else
+    constexpr bool ASM_KLOOP = true;
+#endif
+    if (ASM_KLOOP && kt0 < kt1) {
+        // The K loop as one assembly block (conv_kloop_gfx950.inc; tools/gen_conv_kloop.py documents the schedule): same tiles, same
+        // MFMA order per accumulator as the C++ loop below (bit-identical), fragment reads a group of four k-steps ahead of their use.
+        load_pt(kt0);
+        dma_tile(kt0, 0);
+        load_pt(kt0 + 1);
+        __syncthreads();
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)sA;
+        const unsigned ra0 = lds0 + (unsigned)(lh * BM + a_col) * 4u, ra1 = ra0 + 128u;
+        const unsigned rb0 = lds0 + (unsigned)(2 * KT * BM + lh * BN + b_col) * 4u, rb1 = rb0 + 128u;
+        const unsigned long long ax = (unsigned long long)(size_t)(p.x + (long long)batch * p.x_bstride);
+        const unsigned long long ag = (unsigned long long)(size_t)(p.g + (long long)batch * p.g_bstride);
+        i32x4 dx, dg;
+        dx.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ax);
+        dx.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ax >> 32) & 0xffffu));
+        dx.z = __builtin_amdgcn_readfirstlane((int)p.x_bytes);
+        dx.w = 0x00020000;
+        dg.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ag);
+        dg.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ag >> 32) & 0xffffu));
+        dg.z = __builtin_amdgcn_readfirstlane((int)p.g_bytes);
+        dg.w = 0x00020000;
+        const int m_a = __builtin_amdgcn_readfirstlane((int)lds0 + wave_u * 1024);
+        const int m_b = m_a + 2 * KT * BM * 4;
+        const unsigned long long mok = __builtin_amdgcn_ballot_w64(m_ok), nok = __builtin_amdgcn_ballot_w64(n_ok);
+        int v_k = (kt0 + 1) * KT + (tid >> 5), v_kb = (kt0 + 1) * KT + tid / BL;
+        int v_bo = (v_kb * p.Cs_g + b_delta) * 4;
+        int s_n = kt1 - kt0 - 1, s_t;
+        unsigned v_t, v_o0, v_o1;
+#define VSTAB_WG_IO(ACCS)                                                                                                                    \
+        : ACCS, [vk] "+v"(v_k), [vkb] "+v"(v_kb), [vbo] "+v"(v_bo), [n] "+s"(s_n), [t] "=&s"(s_t), [vt] "=&v"(v_t), [vo0] "=&v"(v_o0),       \
+          [vo1] "=&v"(v_o1)                                                                                                                 \
+        : [ra0] "v"(ra0), [ra1] "v"(ra1), [rb0] "v"(rb0), [rb1] "v"(rb1), [vky] "v"(ky), [vkx] "v"(kx), [vad] "v"(a_delta),                \
+          [px0] "v"(pt[0].x), [py0] "v"(pt[0].y), [pz0] "v"(pt[0].z), [px1] "v"(pt[1].x), [py1] "v"(pt[1].y), [pz1] "v"(pt[1].z),          \
+          [px2] "v"(pt[2].x), [py2] "v"(pt[2].y), [pz2] "v"(pt[2].z), [px3] "v"(pt[3].x), [py3] "v"(pt[3].y), [pz3] "v"(pt[3].z),          \
+          [rx] "s"(dx), [rg] "s"(dg), [ptab] "s"(p.ptab), [ma] "s"(m_a), [mb] "s"(m_b), [mok] "s"(mok), [nok] "s"(nok),                    \
+          [kk] "s"(p.K), [km1] "s"(p.K - 1), [hi] "s"(p.Hi), [wi] "s"(p.Wi), [brow] "s"(BR * p.Cs_g * 4), [btile] "s"(KT * p.Cs_g * 4)    \
+        : "memory", "vcc", "scc", VSTAB_WGRAD_CLOBBERS
+        if constexpr (BN == 128) {
+            asm volatile(VSTAB_WGRAD_ASM_128 VSTAB_WG_IO([c00] "+a"(acc[0][0]) VSTAB_COMMA [c01] "+a"(acc[0][NBW - 1]) VSTAB_COMMA [c10] "+a"(acc[1][0])
+                                                        VSTAB_COMMA [c11] "+a"(acc[1][NBW - 1])));
+        } else {
+            asm volatile(VSTAB_WGRAD_ASM_64 VSTAB_WG_IO([c00] "+a"(acc[0][0]) VSTAB_COMMA [c10] "+a"(acc[1][0])));
+        }
+#undef VSTAB_WG_IO
+        __syncthreads();                            // as the C++ loop's last barrier: every wave is past its last fragment read
+    } else if (kt0 < kt1) {
         load_pt(kt0);
         dma_tile(kt0, 0);
         load_pt(kt0 + 1);

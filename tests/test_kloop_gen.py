@@ -70,3 +70,36 @@ def test_accumulator_chain_order_is_k_group_then_j():
                 mb, nb = int(acc[1]), int(acc[2])
                 a0, b0 = g.frag(s, f"A{mb}", 0), g.frag(s, f"B{nb}", 0)
                 assert ops == [(a0 + j, b0 + j) for j in range(4)]
+
+
+def test_wgrad_blocks_keep_the_same_invariants():
+    g = _gen()
+    for bn in (128, 64):
+        gen = g.WgradGen(bn)
+        lines = gen.generate()
+        text = "\n".join(lines)
+        bodies = re.split(r"\.Lvwg\d+_(?:body0|body1|tail0|tail1|end)_%=:", text)[1:5]
+        per_tile = 16 * 2 * (bn // 64)                                       # 16 k-steps x MB x NB
+        for i, b in enumerate(bodies):
+            assert b.count("v_mfma_f32_32x32x2_f32") == per_tile
+            assert b.count("s_barrier") == (1 if i < 2 else 0)
+            assert b.count("buffer_load_dwordx4") == ((4 + gen.BP) if i < 2 else 0)
+            assert b.count("global_load_dwordx3") == (4 if i < 2 else 0)       # the pixel-table entries of the tile after the next one
+        narrowed = False
+        for l in lines:
+            if l.startswith("v_cmpx") or (l.startswith("s_mov_b64 exec,") and "-1" not in l):
+                narrowed = True
+            elif l.startswith("s_mov_b64 exec, -1"):
+                narrowed = False
+            elif l.startswith(("buffer_load", "global_load", "v_mfma", "ds_read", "s_barrier", "s_cbranch", "s_branch")):
+                assert not narrowed, l
+        # per accumulator the fragments come in k-step order
+        for s in (0, 1):
+            seq = {}
+            for l in gen.mfmas(s):
+                m = re.match(r"v_mfma_f32_32x32x2_f32 %\[(c\d\d)\], v(\d+), v(\d+),", l)
+                seq.setdefault(m.group(1), []).append((int(m.group(2)), int(m.group(3))))
+            base = gen.FR + 16 * s
+            for acc, ops in seq.items():
+                mb, nb = int(acc[1]), int(acc[2])
+                assert ops == [(base + 4 * mb + i, base + 8 + 4 * nb + i) for i in range(4)]

@@ -273,6 +273,160 @@ class RowWinGen:
         return [f"v{i}" for i in range(self.A[0], self.B[1] + 16)]
 
 
+class WgradGen:
+    """wgrad_mfma_kernel<BN> (filter gradient; BN = 128, 64): K-tile = 32 output pixels, 16 k-steps of MB x NB = 2 x (BN/64) MFMAs.
+
+    hipcc issued the fragment reads of k-step ks+1 and waited for them (`s_waitcnt lgkmcnt(0)`) in front of the MFMAs of k-step ks:
+    an LDS round trip every four MFMAs (0.73 of the pipe).  Here the 16 k-steps run as four groups of four on two register sets,
+    the reads of group g+1 (ds_read2st64_b32: one instruction fetches the same fragment of two consecutive k-steps) issued at the
+    start of group g; the fetch of tile t+1 (pixel-table entries loaded a tile ahead, validity by EXEC narrowing,
+    `buffer_load_dwordx4 ... lds`) sits between the MFMAs of group 0, then the table entries of tile t+2 are requested; the
+    barrier comes four MFMAs into group 3 behind `s_waitcnt vmcnt(4)` (the DMA has landed, the table loads may still fly)."""
+    FR = 96            # fragment sets: 16 registers each (a0 x4, a1 x4, b0 x4, b1 x4)
+    PT = 80            # pixel-table entries of the next tile: 4 x {x, y, z} at PT + 4 j
+
+    def __init__(self, BN):
+        self.BN = BN
+        self.NB = BN // 64
+        self.G = 4 * 2 * self.NB                 # MFMAs per group of four k-steps
+        self.BP = 4 if BN == 128 else 2          # DMA passes of the B tile
+        self.BR = 8 if BN == 128 else 16         # B rows per pass
+        self.B_STAGE = 32 * BN * 4               # bytes per stage of the B ring
+        self.out = []
+
+    def e(self, s):
+        self.out.append(s)
+
+    def reads(self, buf, g, s):
+        """fragment reads of k-steps 4g .. 4g+3 out of stage buf into set s"""
+        base = self.FR + 16 * s
+        r = []
+        a_u, b_u = buf * 64, buf * (self.B_STAGE // 256)
+        bstep = (2 * self.BN * 4) // 256          # 256-byte units per k-step in the B tile
+        for half in range(2):
+            ks = 4 * g + 2 * half
+            r.append(f"ds_read2st64_b32 v[{base + 2 * half}:{base + 2 * half + 1}], %[ra0] offset0:{a_u + ks * 4} offset1:{a_u + (ks + 1) * 4}")
+            r.append(f"ds_read2st64_b32 v[{base + 8 + 2 * half}:{base + 8 + 2 * half + 1}], %[rb0] offset0:{b_u + ks * bstep} offset1:{b_u + (ks + 1) * bstep}")
+            r.append(f"ds_read2st64_b32 v[{base + 4 + 2 * half}:{base + 4 + 2 * half + 1}], %[ra1] offset0:{a_u + ks * 4} offset1:{a_u + (ks + 1) * 4}")
+            if self.NB == 2:
+                r.append(f"ds_read2st64_b32 v[{base + 12 + 2 * half}:{base + 12 + 2 * half + 1}], %[rb1] offset0:{b_u + ks * bstep} offset1:{b_u + (ks + 1) * bstep}")
+        return r
+
+    def mfmas(self, s):
+        base = self.FR + 16 * s
+        m = []
+        for i in range(4):
+            for mb in range(2):
+                for nb in range(self.NB):
+                    m.append(f"v_mfma_f32_32x32x2_f32 %[c{mb}{nb}], v{base + 4 * mb + i}, v{base + 8 + 4 * nb + i}, %[c{mb}{nb}]")
+        return m
+
+    def fetch_chunks(self, nxt):
+        c = []
+        for j in range(4):                        # A: 8 pixel rows per pass
+            vo = f"%[vo{j & 1}]"
+            pt = self.PT + 4 * j
+            c.append([f"s_add_i32 m0, %[ma], {nxt * 16384 + j * 4096}",
+                      f"v_mov_b32 {vo}, 0xc0000000",
+                      "s_mov_b64 exec, %[mok]",
+                      f"v_add_u32 %[vt], {8 * j}, %[vk]",
+                      "v_cmpx_gt_u32 vcc, %[kk], %[vt]",
+                      f"v_add_u32 %[vt], v{pt + 1}, %[vky]",
+                      "v_cmpx_gt_u32 vcc, %[hi], %[vt]",
+                      f"v_add_u32 %[vt], v{pt + 2}, %[vkx]",
+                      "v_cmpx_gt_u32 vcc, %[wi], %[vt]",
+                      f"v_add_lshl_u32 {vo}, v{pt}, %[vad], 2",
+                      "s_mov_b64 exec, -1",
+                      f"buffer_load_dwordx4 {vo}, %[rx], 0 offen lds"])
+        for j in range(self.BP):
+            vo = f"%[vo{j & 1}]"
+            ch = [f"s_add_i32 m0, %[mb], {nxt * self.B_STAGE + j * 4096}",
+                  f"v_mov_b32 {vo}, 0xc0000000",
+                  "s_mov_b64 exec, %[nok]",
+                  f"v_add_u32 %[vt], {self.BR * j}, %[vkb]",
+                  "v_cmpx_gt_u32 vcc, %[kk], %[vt]"]
+            if j == 0:
+                ch.append(f"v_mov_b32 {vo}, %[vbo]")
+            else:
+                ch += [f"s_mul_i32 %[t], %[brow], {j}", f"v_add_u32 {vo}, %[t], %[vbo]"]
+            ch += ["s_mov_b64 exec, -1", f"buffer_load_dwordx4 {vo}, %[rg], 0 offen lds"]
+            c.append(ch)
+        # the table entries of the tile after the next one, then the cursors move on
+        for j in range(4):
+            pt = self.PT + 4 * j
+            c.append([f"v_add_u32 %[vt], {32 + 8 * j}, %[vk]",
+                      "v_min_u32 %[vt], %[km1], %[vt]",
+                      "v_lshlrev_b32 %[vt], 4, %[vt]",
+                      f"global_load_dwordx3 v[{pt}:{pt + 2}], %[vt], %[ptab]"])
+        c.append(["v_add_u32 %[vk], 32, %[vk]", "v_add_u32 %[vkb], 32, %[vkb]", "v_add_u32 %[vbo], %[btile], %[vbo]"])
+        return c
+
+    def group(self, pre, mf, chunks_at, post=()):
+        for l in pre:
+            self.e(l)
+        for i, m in enumerate(mf):
+            self.e(m)
+            for l in chunks_at.get(i, ()):
+                self.e(l)
+        for l in post:
+            self.e(l)
+
+    def body(self, b, exit_label, next_label):
+        nxt = b ^ 1
+        G = self.G
+        chunks = self.fetch_chunks(nxt)
+        at = {}
+        if len(chunks) <= G - 1:
+            for i, c in enumerate(chunks):
+                at.setdefault(i, []).extend(c)
+        else:                                     # the 64-column shape: 8 MFMAs per group, 11 chunks -- two per slot where needed
+            for i, c in enumerate(chunks):
+                at.setdefault(i * (G - 1) // len(chunks), []).extend(c)
+        # group 0 waits for the fragments AND for the table entries this tile's fetch reads
+        self.group(["s_waitcnt vmcnt(0) lgkmcnt(0)"] + self.reads(b, 1, 1), self.mfmas(0), at)
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 2, 0), self.mfmas(1), {})
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 3, 1), self.mfmas(0), {})
+        k = max(G // 4, 2)
+        at3 = {k - 1: ["s_waitcnt vmcnt(4)", "s_barrier"] + self.reads(nxt, 0, 0), k: ["s_sub_u32 %[n], %[n], 1"]}
+        post = ["s_cmp_eq_u32 %[n], 0", f"s_cbranch_scc1 {exit_label}"]
+        if next_label:
+            post.append(f"s_branch {next_label}")
+        self.group(["s_waitcnt lgkmcnt(0)"], self.mfmas(1), at3, post)
+
+    def tail(self, b, end_label):
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 1, 1), self.mfmas(0), {})
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 2, 0), self.mfmas(1), {})
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 3, 1), self.mfmas(0), {})
+        self.group(["s_waitcnt lgkmcnt(0)"], self.mfmas(1), {}, [f"s_branch {end_label}"] if end_label else [])
+
+    def generate(self):
+        L = lambda n: f".Lvwg{self.BN}_{n}_%="
+        self.e("s_nop 4")
+        for j in range(4):                        # the table entries of tile kt0 + 1, fetched by the C++ prologue, into their fixed registers
+            for c, nm in enumerate("xyz"):
+                self.e(f"v_mov_b32 v{self.PT + 4 * j + c}, %[p{nm}{j}]")
+        for l in self.reads(0, 0, 0):
+            self.e(l)
+        self.e("s_cmp_eq_u32 %[n], 0")
+        self.e(f"s_cbranch_scc1 {L('tail0')}")
+        self.e(L("body0") + ":")
+        self.body(0, L("tail1"), None)
+        self.e(L("body1") + ":")
+        self.body(1, L("tail0"), L("body0"))
+        self.e(L("tail0") + ":")
+        self.tail(0, L("end"))
+        self.e(L("tail1") + ":")
+        self.tail(1, None)
+        self.e(L("end") + ":")
+        self.e("s_waitcnt vmcnt(0)")              # table loads of a tile that will not come
+        self.e("s_nop 15")
+        self.e("s_nop 7")
+        return self.out
+
+    def clobbers(self):
+        return [f"v{i}" for i in range(self.FR, self.FR + 32)] + [f"v{self.PT + 4 * j + c}" for j in range(4) for c in range(3)]
+
+
 def render():
     o = ["// GENERATED by tools/gen_conv_kloop.py -- do not edit; see that file for the schedule this encodes.",
          "// clang-format off"]
@@ -292,6 +446,14 @@ def render():
     o.append("    \"\"")
     o.append("#define VSTAB_ROWWIN_CLOBBERS " + ", ".join(f'"{c}"' for c in r.clobbers()))
     o.append("#define VSTAB_ROWWIN_BUF_BYTES " + str(RowWinGen.BUF))
+    for BN in (128, 64):
+        w = WgradGen(BN)
+        o.append(f"#define VSTAB_WGRAD_ASM_{BN} \\")
+        for l in w.generate():
+            o.append(f'    "{l}\\n" \\')
+        o.append("    \"\"")
+        if BN == 128:
+            o.append("#define VSTAB_WGRAD_CLOBBERS " + ", ".join(f'"{c}"' for c in w.clobbers()))
     o.append("// clang-format on")
     return "\n".join(o) + "\n"
 
