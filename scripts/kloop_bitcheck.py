@@ -28,3 +28,16 @@ def walk(name, o):
 
 
 walk("out", outs)
+
+# the filter-gradient kernel's loop (both tile widths, split-K and not)
+from coupe.optical_flow_based_deep_video_stabilization_amd import training   # noqa: E402
+
+for name, Bn, Hi, Wi, cin, cout, k, s_, p_ in (("wgrad conv3", 8, 128, 128, 128, 256, 5, 2, 2), ("wgrad conv1-like", 2, 64, 64, 28, 64, 7, 2, 3),
+                                              ("wgrad conv6_1", 8, 8, 8, 1024, 1024, 3, 1, 1)):
+    gg = torch.Generator().manual_seed(7)
+    Ho, Wo = (Hi + 2 * p_ - k) // s_ + 1, (Wi + 2 * p_ - k) // s_ + 1
+    x = torch.randn(Bn, Hi, Wi, cin, generator=gg).cuda()
+    go = torch.randn(Bn, Ho, Wo, cout, generator=gg).cuda()
+    dW, db = training.conv_wgrad(x, go, k, s_, p_)
+    torch.cuda.synchronize()
+    walk("out." + name.replace(" ", "_"), [dW, db])
