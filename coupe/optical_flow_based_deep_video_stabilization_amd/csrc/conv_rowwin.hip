@@ -53,7 +53,9 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
     // 7-row input windows overlap by five rows
     unsigned bx_, by_, bz_;
     xcd_remap(bx_, by_, bz_);
-    const int oy = (int)bx_, ox0 = p.ox_base + (int)by_ * (64 * MB), n = (int)bz_;
+    const int stream_r = (MB == 2 && p.asm_loop) ? p.stream_rows : 0;          // > 0: this workgroup computes output rows oy .. oy + stream_r - 1
+    int oy = stream_r > 0 ? (int)bx_ * stream_r : (int)bx_;
+    const int ox0 = p.ox_base + (int)by_ * (64 * MB), n = (int)bz_;
     const int pix_step = p.s_in * p.Cs_in;
     const int row_floats = p.Wi * p.Cs_in;
     const int g0 = pix_step * ox0 + p.e_off - p.w_a;       // window start, floats from the row start (multiple of 4)
@@ -165,6 +167,38 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
             int s_koff = 0, s_nrows = p.KH - 1;
             unsigned v_t0, v_t1;
             long long s_mask;
+            if (stream_r > 0) {
+                // the stream form (tools/gen_conv_kloop.py, RowWinStreamGen): stream_r tiles back to back, every tile but the last stored from
+                // registers under the next tile's first filter row; the last tile's accumulators come back for the epilogue below
+                const unsigned long long aout = (unsigned long long)(size_t)p.out;
+                i32x4 dout;
+                dout.x = __builtin_amdgcn_readfirstlane((int)(unsigned)aout);
+                dout.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(aout >> 32) & 0xffffu));
+                dout.z = __builtin_amdgcn_readfirstlane((int)((unsigned)p.B * (unsigned)p.Ho * (unsigned)p.Wo * (unsigned)p.Cs_out * 4u));
+                dout.w = 0x00020000;
+                const unsigned vout = (unsigned)((wm * 64 + 4 * lh) * p.Cs_out + p.c_off + wn * 32 + li) * 4u;
+                const float bias_l = p.bias[wn * 32 + li];
+                const float slope = p.act == 1 ? 0.1f : (p.act == 0 ? 1.0f : 0.0f);      // max(v, slope * v): leaky relu / identity / relu
+                int s_ntiles = stream_r, s_obase = (((n * p.Ho + oy) * p.Wo + ox0) * p.Cs_out) * 4, s_st;
+                float o[32];
+                asm volatile(VSTAB_ROWWIN_STREAM_ASM_KPR6
+                             : [a0c] "+v"(a0c), [a1c] "+v"(a1c), [a0n] "+v"(a0n), [a1n] "+v"(a1n),
+                               [mn] "+s"(m_n), [iy] "+s"(s_iy), [soff] "+s"(s_soff), [koff] "+s"(s_koff), [nrows] "+s"(s_nrows), [ntiles] "+s"(s_ntiles),
+                               [obase] "+s"(s_obase), [st] "=&s"(s_st), [vt0] "=&v"(v_t0), [vt1] "=&v"(v_t1), [mask] "=&s"(s_mask),
+                               [o0] "=&v"(o[0]), [o1] "=&v"(o[1]), [o2] "=&v"(o[2]), [o3] "=&v"(o[3]), [o4] "=&v"(o[4]), [o5] "=&v"(o[5]), [o6] "=&v"(o[6]),
+                               [o7] "=&v"(o[7]), [o8] "=&v"(o[8]), [o9] "=&v"(o[9]), [o10] "=&v"(o[10]), [o11] "=&v"(o[11]), [o12] "=&v"(o[12]),
+                               [o13] "=&v"(o[13]), [o14] "=&v"(o[14]), [o15] "=&v"(o[15]), [o16] "=&v"(o[16]), [o17] "=&v"(o[17]), [o18] "=&v"(o[18]),
+                               [o19] "=&v"(o[19]), [o20] "=&v"(o[20]), [o21] "=&v"(o[21]), [o22] "=&v"(o[22]), [o23] "=&v"(o[23]), [o24] "=&v"(o[24]),
+                               [o25] "=&v"(o[25]), [o26] "=&v"(o[26]), [o27] "=&v"(o[27]), [o28] "=&v"(o[28]), [o29] "=&v"(o[29]), [o30] "=&v"(o[30]),
+                               [o31] "=&v"(o[31])
+                             : [vb] "v"(vb), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]),
+                               [din] "s"(din), [dwt] "s"(dwt), [mx] "s"(m_x), [hi] "s"(p.Hi), [rowbytes] "s"(row_floats * 4), [kstride] "s"(ktile_stride * 4),
+                               [bias] "v"(bias_l), [slope] "s"(slope), [cs4] "s"(p.Cs_out * 4), [ostep] "s"(p.Wo * p.Cs_out * 4), [vout] "v"(vout), [dout] "s"(dout)
+                             : "memory", "scc", VSTAB_ROWWIN_STREAM_CLOBBERS);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[0][r] = o[r]; acc[MB - 1][r] = o[16 + r]; }
+                oy += stream_r - 1;                   // the epilogue below stores the stream's last tile
+            } else
             asm volatile(VSTAB_ROWWIN_ASM_KPR6
                          : [c0] "+a"(acc[0]), [c1] "+a"(acc[MB - 1]), [a0c] "+v"(a0c), [a1c] "+v"(a1c), [a0n] "+v"(a0n), [a1n] "+v"(a1n),
                            [mn] "+s"(m_n), [iy] "+s"(s_iy), [soff] "+s"(s_soff), [koff] "+s"(s_koff), [nrows] "+s"(s_nrows),
@@ -286,6 +320,21 @@ hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEven
 #ifdef VSTAB_NO_ASM_KLOOP
     q.asm_loop = 0;                              // A/B builds only (scripts/build_variant_lib.sh)
 #endif
+    // stream form: exactly two workgroups per CU, each walking down Ho / nchunk rows of one x tile of one sample; needs whole 128-pixel tiles,
+    // all 64 output channels and a plain activation
+    q.stream_rows = 0;
+    if (q.asm_loop && p.KH == 7 && p.N == 64 && p.act >= 0 && p.act <= 2 && p.ox_base + ntx * 128 <= p.Wo &&
+        (unsigned long long)p.B * p.Ho * p.Wo * p.Cs_out * 4ull < 0x100000000ull) {
+        const long long tiles = (long long)p.Ho * ntx * p.B;
+        if (tiles % 512 == 0) {
+            const int R = (int)(tiles / 512);
+            if (R >= 2 && p.Ho % R == 0) q.stream_rows = R;
+        }
+    }
+#ifdef VSTAB_NO_ROWWIN_STREAM
+    q.stream_rows = 0;                           // A/B builds only
+#endif
+    if (q.stream_rows > 0) grid.x = (unsigned)(p.Ho / q.stream_rows);
     const size_t lds2 = q.asm_loop ? (size_t)2 * VSTAB_ROWWIN_BUF_BYTES : (size_t)2 * p.WLEN * 4;
     const bool timed = ev_start || ev_stop;      // timestamps of the kernel's own dispatch packet, no marker packets (see conv_mfma.hip); a
                                                  // launch that is one half of a pair carries only the start or only the stop event

@@ -273,6 +273,124 @@ class RowWinGen:
         return [f"v{i}" for i in range(self.A[0], self.B[1] + 16)]
 
 
+class RowWinStreamGen(RowWinGen):
+    """The same kernel as a STREAM of tiles: a workgroup keeps its x tile and sample and walks down R consecutive output rows.
+
+    The per-lane window offsets never change; the first window of the next tile is one more LDS-DMA with the row cursor moved back
+    by five rows (next tile's first input row = this tile's last + 1 - 5... i.e. iy0 + 2), fetched during the last filter row of the
+    current tile ('bridge' row) like any other window; the weights' K-tile cursor wraps to 0 in that row's last K-tile.  When a tile's
+    last MFMA has issued, its 32 accumulators are copied to registers (after the 18 wait states an XDL write needs), the next tile's
+    first MFMAs take srcC = 0, and the 32 four-byte stores per lane (bias, leaky relu as max(v, slope * v), scalar offset per pixel
+    row) are issued between the MFMAs of K-tiles 1..5 of the next tile's first filter row -- the window buffers never serve as a
+    staging area, the stream has no seams.  The last tile's values are handed back to the kernel's C++ epilogue.
+    Accumulators are a[0:31] by name (operands cannot address single accumulator registers)."""
+
+    ACC = ("a[0:15]", "a[16:31]")
+
+    def mfmas(self, P, zero=False):
+        m = []
+        for s in range(16):
+            for mb in range(2):
+                c = "0" if (zero and s == 0) else self.ACC[mb]
+                m.append(f"v_mfma_f32_32x32x2_f32 {self.ACC[mb]}, v{self.A[P] + 16 * mb + s}, v{self.B[P] + s}, {c}")
+        return m
+
+    def tile(self, P, wait_vm, chunks, barrier_after=None, zero=False):
+        self.e(f"s_waitcnt vmcnt({wait_vm}) lgkmcnt(0)")
+        first = 0 if barrier_after is None else barrier_after + 1
+        for i, m in enumerate(self.mfmas(P, zero)):
+            self.e(m)
+            if barrier_after is not None and i == barrier_after:
+                self.e("s_barrier")
+            k = i - first
+            if 0 <= k < len(chunks):
+                for l in chunks[k]:
+                    self.e(l)
+        assert len(chunks) <= 32 - first, (len(chunks), first)
+
+    def store_chunk(self, i):
+        mb, r = divmod(i, 16)
+        px = mb * 32 + (r & 3) + 8 * (r >> 2)
+        o = f"%[o{i}]"
+        return [f"v_add_f32 {o}, {o}, %[bias]",
+                f"v_mul_f32 %[vt0], %[slope], {o}",
+                f"v_max_f32 {o}, {o}, %[vt0]",
+                f"s_mul_i32 %[st], %[cs4], {px}",
+                "s_add_i32 %[st], %[st], %[obase]",
+                f"buffer_store_dword {o}, %[vout], %[dout], %[st] offen"]
+
+    def flush(self):
+        self.e("s_nop 15")
+        self.e("s_nop 7")
+        for i in range(32):
+            self.e(f"v_accvgpr_read_b32 %[o{i}], a{i}")
+
+    def row(self, kind):
+        n = self.kpr
+        stores = list(range(32))
+        per = [0, 7, 7, 7, 7, 4]                                # deferred stores per K-tile of a tile's first filter row
+        for t in range(n):
+            P, Q = t & 1, (t & 1) ^ 1
+            last = t == n - 1
+            if last and kind == "final":
+                self.tile(P, 0, [])
+                continue
+            bl = self.b_loads(Q)
+            if last and kind == "bridge":
+                bl[0] = ["s_mov_b32 %[koff], 0"] + bl[0]        # the next tile starts at the weights' first K-tile
+            chunks = bl + self.a_reads(Q, 0 if last else t + 1, last)
+            if t == 0 and kind != "final":
+                d = self.dma()
+                if kind == "bridge":                            # next tile's first input row = this tile's first + 2 = (cursor) - 5
+                    d[0] = ["s_mul_i32 %[st], %[rowbytes], 5", "s_sub_u32 %[soff], %[soff], %[st]", "s_sub_u32 %[iy], %[iy], 5"] + d[0]
+                chunks += d
+            if kind == "first_s" and per[t]:
+                for _ in range(per[t]):
+                    chunks.append(self.store_chunk(stores.pop(0)))
+            self.tile(P, 7 if (t == 1 and kind != "final") else 0, chunks, barrier_after=3 if last else None,
+                      zero=(t == 0 and kind in ("first", "first_s")))
+        assert not (kind == "first_s" and stores)
+
+    def swap(self):
+        self.e("v_swap_b32 %[a0c], %[a0n]")
+        self.e("v_swap_b32 %[a1c], %[a1n]")
+        self.e("s_xor_b32 %[mn], %[mn], %[mx]")
+
+    def generate(self):
+        L = lambda n: f".Lvrs_{n}_%="
+        self.e("s_nop 4")
+        for c in self.b_loads(0) + self.a_reads(0, 0, False):
+            for l in c:
+                self.e(l)
+        self.row("first")
+        self.swap()
+        self.e(L("tile") + ":")
+        self.e("s_mov_b32 %[nrows], 5")
+        self.e(L("more") + ":")
+        self.row("more")
+        self.swap()
+        self.e("s_sub_u32 %[nrows], %[nrows], 1")
+        self.e("s_cmp_lg_u32 %[nrows], 0")
+        self.e(f"s_cbranch_scc1 {L('more')}")
+        self.e("s_sub_u32 %[ntiles], %[ntiles], 1")
+        self.e("s_cmp_eq_u32 %[ntiles], 0")
+        self.e(f"s_cbranch_scc1 {L('final')}")
+        self.row("bridge")
+        self.flush()
+        self.swap()
+        self.row("first_s")
+        self.swap()
+        self.e("s_add_i32 %[obase], %[obase], %[ostep]")
+        self.e(f"s_branch {L('tile')}")
+        self.e(L("final") + ":")
+        self.row("final")
+        self.flush()
+        return self.out
+
+    def clobbers(self):
+        return RowWinGen.clobbers(self) + [f"a{i}" for i in range(32)]
+
+
 class WgradGen:
     """wgrad_mfma_kernel<BN> (filter gradient; BN = 128, 64): K-tile = 32 output pixels, 16 k-steps of MB x NB = 2 x (BN/64) MFMAs.
 
@@ -446,6 +564,12 @@ def render():
     o.append("    \"\"")
     o.append("#define VSTAB_ROWWIN_CLOBBERS " + ", ".join(f'"{c}"' for c in r.clobbers()))
     o.append("#define VSTAB_ROWWIN_BUF_BYTES " + str(RowWinGen.BUF))
+    rs = RowWinStreamGen(6)
+    o.append("#define VSTAB_ROWWIN_STREAM_ASM_KPR6 \\")
+    for l in rs.generate():
+        o.append(f'    "{l}\\n" \\')
+    o.append("    \"\"")
+    o.append("#define VSTAB_ROWWIN_STREAM_CLOBBERS " + ", ".join(f'"{c}"' for c in rs.clobbers()))
     for BN in (128, 64):
         w = WgradGen(BN)
         o.append(f"#define VSTAB_WGRAD_ASM_{BN} \\")
