@@ -320,15 +320,22 @@ hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEven
 #ifdef VSTAB_NO_ASM_KLOOP
     q.asm_loop = 0;                              // A/B builds only (scripts/build_variant_lib.sh)
 #endif
-    // stream form: exactly two workgroups per CU, each walking down Ho / nchunk rows of one x tile of one sample; needs whole 128-pixel tiles,
-    // all 64 output channels and a plain activation
+    // stream form (a workgroup walks down R consecutive output rows of one x tile of one sample; prologue and epilogue once per R tiles):
+    // needs whole 128-pixel tiles, all 64 output channels, a plain activation, 7 filter rows.  R = the divisor of Ho that minimises a
+    // small cost model in units of one tile's time with two workgroups per CU: rounds of 512 workgroups x (R + F), F = the fixed
+    // prologue + epilogue (0.08: 13 k of 172 k cycles); a launch of at most 256 workgroups has a CU to each (0.53 per tile).  B=8
+    // 512x512: R = 8, 512 workgroups, one round; B=8 1080p: R = 30, 1008 workgroups.
     q.stream_rows = 0;
     if (q.asm_loop && p.KH == 7 && p.N == 64 && p.act >= 0 && p.act <= 2 && p.ox_base + ntx * 128 <= p.Wo &&
         (unsigned long long)p.B * p.Ho * p.Wo * p.Cs_out * 4ull < 0x100000000ull) {
-        const long long tiles = (long long)p.Ho * ntx * p.B;
-        if (tiles % 512 == 0) {
-            const int R = (int)(tiles / 512);
-            if (R >= 2 && p.Ho % R == 0) q.stream_rows = R;
+        const double F = 0.08;
+        const long long cols = (long long)ntx * p.B;
+        double best = (double)((cols * p.Ho + 511) / 512) * (1.0 + F);          // one tile per workgroup
+        for (int R = 2; R <= 32 && R <= p.Ho; ++R) {
+            if (p.Ho % R) continue;
+            const long long wgs = cols * (p.Ho / R);
+            const double c = wgs <= 256 ? 0.53 * R + F : (double)((wgs + 511) / 512) * (R + F);
+            if (c < best * 0.995) { best = c; q.stream_rows = R; }
         }
     }
 #ifdef VSTAB_NO_ROWWIN_STREAM

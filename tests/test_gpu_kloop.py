@@ -103,3 +103,26 @@ def test_predict2_tap_table_rejects_bad_arguments():
     assert L.vstab_predict2_tap_table(x.data_ptr(), 0, tab.data_ptr(), T.data_ptr(), None) != 0
     assert L.vstab_predict2_tap_table(x.data_ptr(), 3_000_000, tab.data_ptr(), T.data_ptr(), None) != 0       # 2.35e9 bytes of rows
     assert L.vstab_predict2_tap_table(x.data_ptr() + 4, 32, tab.data_ptr(), T.data_ptr(), None) != 0
+
+
+# ----------------------------------------------------------------------------- the first layer's stream form (conv_rowwin.hip, stream_rows > 0)
+@pytest.mark.parametrize("B,H,W", [(4, 512, 512), (2, 512, 1024), (16, 128, 512)])
+def test_first_layer_stream_form_vs_oracle(B, H, W):
+    """launches whose 128-pixel tiles are a multiple of 512 run the first layer as streams of consecutive output rows per
+    workgroup (4 rows each; tiles stored from registers under the next tile's first filter row, the last one by the ordinary epilogue): conv1 against
+    the oracle's, top / bottom rows (filter rows outside the image) and every seam between two tiles of a stream included"""
+    import numpy as np
+    from coupe.optical_flow_based_deep_video_stabilization_amd import runtime, weights as wts
+    import coupe.optical_flow_based_deep_video_stabilization_amd as vs
+    from oracle import vstab_oracle as vo
+    w = wts.synthetic_weights(seed=11, cin=27, random_bn=True, flow_gain=1.0)
+    feats = np.random.default_rng(B + W).random((B, H, W, 27), dtype=np.float32)
+    runtime.reset()
+    vs.assign_weights(w)
+    vs.flownetS_pyramid(torch.from_numpy(feats).cuda(), B, is_train=False)
+    torch.cuda.synchronize()
+    conv1 = runtime.get_context().internals(B, H, W, 27)["conv1"].double().cpu()
+    _, ref_int = vo.flownetS_pyramid(feats, w, torch.float32, return_internals=True)
+    ref = torch.as_tensor(np.asarray(ref_int["conv1"])).double()
+    assert conv1.shape == ref.shape
+    assert float((conv1 - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
