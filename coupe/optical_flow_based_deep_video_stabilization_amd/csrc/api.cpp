@@ -451,6 +451,7 @@ extern "C" int vstab_create(vstab_ctx **out, int device)
     HIP_TRY(nullptr, conv_set_attributes());
     HIP_TRY(nullptr, rowwin_set_attributes());
     HIP_TRY(nullptr, tap_panel_set_attributes());
+    HIP_TRY(nullptr, wino_gemm_stream_set_attributes());
     vstab_ctx *c = new (std::nothrow) vstab_ctx();
     if (!c) return fail(nullptr, VSTAB_E_NOMEM, "vstab_create: out of host memory");
     c->device = device;
@@ -811,8 +812,15 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
             HIP_TRY(ctx, launch_wino_input(buf(ENC_IO[i].in_buf), B, pl.eh[i], pl.ew[i], ENC_IO[i].cs_in, 0, cin_i, buf(B_WINO_V), stream));
             q.in = buf(B_WINO_V); q.out = buf(B_WINO_M);
             q.wpk = dw + ctx->wino_w[i]; q.bias = dw + ctx->zero_b; q.partial = buf(B_PARTIAL);
-            HIP_TRY(ctx, launch_conv(q, pl.wtile[i], true, stream, EV_A(i), EV_B(i)));
-            ctx->prof_kernel[i] = conv_kernel_name(pl.wtile[i], true);
+            const int T_i = ((pl.eh[i] + 1) / 2) * ((pl.ew[i] + 1) / 2);
+            const int P_i = wino_gemm_stream_positions(B, T_i, cin_i, ENC[i].cout);
+            if (P_i > 0) {       // streams of positions (wino_gemm_stream.hip): B=8 512x512 conv3_1 (8 positions per workgroup), conv4_1 (4)
+                HIP_TRY(ctx, launch_wino_gemm_stream(q.in, q.wpk, q.out, B, T_i, cin_i, ENC[i].cout, P_i, stream, EV_A(i), EV_B(i)));
+                ctx->prof_kernel[i] = "wino_gemm_stream_kernel";
+            } else {
+                HIP_TRY(ctx, launch_conv(q, pl.wtile[i], true, stream, EV_A(i), EV_B(i)));
+                ctx->prof_kernel[i] = conv_kernel_name(pl.wtile[i], true);
+            }
             HIP_TRY(ctx, launch_wino_output(buf(B_WINO_M), B, pl.eh[i], pl.ew[i], ENC[i].cout, dw + ctx->enc_b[i], 1, buf(ENC_IO[i].out_buf),
                                             ENC_IO[i].cs_out, 0, stream));
             continue;

@@ -154,6 +154,12 @@ void pack_conv_rowwin(const float *W, const double *scale, int kh, int kw, int c
 // gradient -> [B][16][TH*TW][C]; dg = G^T dU G from the 16 position gradients dU [16][cin][cout] -> HWIO [3][3][cin][cout]
 hipError_t launch_wino_outgrad(const float *dy, int B, int H, int W, int Cs, int c_off, int C, float *dM, hipStream_t stream);
 hipError_t launch_wino_filter_grad(const float *dU, int cin, int cout, float *dW, hipStream_t stream);
+// the 16 Winograd-domain GEMMs of a stage as streams of positions (wino_gemm_stream.hip): positions per workgroup for B samples x T
+// tiles, or 0 when the stage does not qualify (the 16-phase launch_conv then)
+int wino_gemm_stream_positions(int B, int T, int cin, int cout);
+hipError_t launch_wino_gemm_stream(const float *V, const float *wpk, float *M, int B, int T, int cin, int cout, int P, hipStream_t stream,
+                                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+hipError_t wino_gemm_stream_set_attributes();
 hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_off, int C, float *V, hipStream_t stream,
                              bool pos_major = false);       // pos_major: V as [16][B*tiles][C] instead of [B][16][tiles][C]
 // device-side weight transform for training: Wt [16][K][N] from W [3,3,cin,cout]; transpose = the input gradient's operand

@@ -103,3 +103,25 @@ def test_wgrad_blocks_keep_the_same_invariants():
             for acc, ops in seq.items():
                 mb, nb = int(acc[1]), int(acc[2])
                 assert ops == [(base + 4 * mb + i, base + 8 + 4 * nb + i) for i in range(4)]
+
+
+def test_stream_blocks_keep_their_invariants():
+    """stream forms (first layer, Winograd-domain GEMMs): every tile's MFMA count, no memory instruction or MFMA under a narrowed
+    EXEC, all 32 accumulators flushed at every seam, every flushed value stored exactly once per seam"""
+    g = _gen()
+    rs = g.RowWinStreamGen(6).generate()
+    text = "\\n".join(rs)
+    assert text.count("v_accvgpr_read_b32") == 2 * 32                          # the seam's flush and the final one
+    assert text.count("buffer_store_dword") == 32
+    assert text.count("v_mfma_f32_32x32x2_f32") == 5 * 6 * 32                   # five row bodies (first, more, bridge, first + stores, final)
+    assert sum(1 for l in rs if l.startswith("v_mfma") and l.endswith(", 0")) == 2 * 2      # two accumulators x two zero-start rows
+    gs = g.GemmStreamGen().generate()
+    text = "\\n".join(gs)
+    assert text.count("v_accvgpr_read_b32") == 2 * 32
+    assert text.count("buffer_store_dword") == 32
+    assert text.count("v_mfma_f32_32x32x2_f32") == 6 * 32                       # first, first + stores, mid x 2, last, final
+    assert text.count("s_barrier") == 5                                         # every body but the final one
+    for lines in (rs, gs):
+        for i, l in enumerate(lines):
+            if l.startswith("buffer_load") and l.endswith("lds"):
+                assert any(x.startswith("s_add_i32 m0") for x in lines[max(0, i - 4):i]) and not lines[i - 1].startswith("s_add_i32 m0")

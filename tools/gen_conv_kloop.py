@@ -169,6 +169,117 @@ class Gen:
         return [f"v{FR + i}" for i in range(32)]     # the B1 tuples of the 64-column shape stay unused: one list for both shapes
 
 
+class GemmStreamGen(Gen):
+    """The Winograd-domain GEMMs of one stage (16 positions, each a [tiles x C_in] . [C_in x C_out] product with its own weights) as
+    STREAMS: a workgroup keeps its 128 x 64 output tile and walks through P consecutive positions, kps K-tiles each.
+
+    A position's reduction is short (8 or 16 K-tiles), so as one workgroup per (position, tile) the prologue (first operands' memory
+    latency) and the epilogue (LDS transpose + store burst) are 40 % of a workgroup's life.  Here the K-tile stream simply runs on
+    across positions -- the operand cursor jumps by one position plane when a position's K-tiles are through, the packed weights of
+    consecutive positions are contiguous anyway -- and at a position's end the 32 accumulators are copied to registers, the next
+    position starts with srcC = 0 and the finished tile leaves as 32 four-byte stores per lane between the MFMAs of k-groups 1 and
+    2 of the next position's first K-tile.  All rows and K chunks are valid by construction (the launcher checks), so the fetch is
+    a bare `buffer_load_dwordx4 ... lds` per row with the cursor in the scalar offset.  kps is even, so every position starts on
+    buffer 0 and ends on buffer 1: bodies first (buffer 0; plain or with the previous tile's stores), mid (1, 0), last (1), final
+    (1, nothing left to fetch).  Accumulators are a[0:31] by name."""
+
+    ACC = {"c00": "a[0:15]", "c10": "a[16:31]"}
+
+    def __init__(self):
+        Gen.__init__(self, 64)
+
+    def mfmas(self, s, zero=False):
+        m = []
+        for jj in range(4):
+            for mb in range(self.MB):
+                acc = self.ACC[f"c{mb}0"]
+                a = frag(s, f"A{mb}", 0) + jj
+                b = frag(s, "B0", 0) + jj
+                m.append(f"v_mfma_f32_32x32x2_f32 {acc}, v{a}, v{b}, {'0' if (zero and jj == 0) else acc}")
+        return m
+
+    def fetch_chunks(self, nxt):
+        c = []
+        for j in range(self.A_ROWS):
+            c.append([f"s_add_i32 m0, %[ma], {nxt * self.A_BUF + j * 4096}", "s_nop 0",
+                      f"buffer_load_dwordx4 %[x{j}], %[rin], %[soff] offen lds"])
+        for jb in range(self.B_PASS):
+            c.append([f"s_add_i32 m0, %[mb], {nxt * self.B_BUF + jb * 4096}", f"s_add_i32 %[t], %[soffw], {jb * 4096}",
+                      "buffer_load_dwordx4 %[wv], %[rwt], %[t] offen lds"])
+        # the cursor: next K-tile of this position, or the first of the next position's plane
+        c.append(["s_add_i32 %[soffw], %[soffw], %[wstep]", "s_add_i32 %[soff], %[soff], 128", "s_add_i32 %[kc], %[kc], 1",
+                  "s_cmp_eq_u32 %[kc], %[kps]", "s_cselect_b32 %[t], %[posjump], 0", "s_cselect_b32 %[kc], 0, %[kc]",
+                  "s_add_i32 %[soff], %[soff], %[t]"])
+        return c
+
+    def store_chunk(self, i):
+        mb, r = divmod(i, 16)
+        row = mb * 32 + (r & 3) + 8 * (r >> 2)
+        return [f"v_add_f32 %[o{i}], 0, %[o{i}]",                # the zero bias the implicit-GEMM epilogue adds: -0 becomes +0 there too
+                f"s_mul_i32 %[t], %[cs4], {row}", "s_add_i32 %[t], %[t], %[obase]",
+                f"buffer_store_dword %[o{i}], %[vout], %[dout], %[t] offen"]
+
+    def flush(self):
+        self.e("s_nop 15")
+        self.e("s_nop 7")
+        for i in range(32):
+            self.e(f"v_accvgpr_read_b32 %[o{i}], a{i}")
+
+    def body(self, b, role):
+        nxt = b ^ 1
+        G = self.G
+        at0 = {}
+        if role != "final":
+            for i, c in enumerate(self.fetch_chunks(nxt)):
+                at0.setdefault(i, []).extend(c)
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 1, 1), self.mfmas(0, zero=role in ("first", "first_s")), at0)
+        st = [self.store_chunk(i) for i in range(32)] if role == "first_s" else []
+        at1, at2 = {}, {}
+        for i, c in enumerate(st[:16]):
+            at1.setdefault(i // 2, []).extend(c)
+        for i, c in enumerate(st[16:]):
+            at2.setdefault(i // 2, []).extend(c)
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 2, 0), self.mfmas(1), at1)
+        self.group(["s_waitcnt lgkmcnt(0)"] + self.reads(b, 3, 1), self.mfmas(0), at2)
+        if role == "final":
+            self.group(["s_waitcnt lgkmcnt(0)"], self.mfmas(1), {})
+        else:
+            k = G // 4
+            self.group(["s_waitcnt lgkmcnt(0)"], self.mfmas(1), {k - 1: ["s_waitcnt vmcnt(0)", "s_barrier"] + self.reads(nxt, 0, 0)})
+
+    def generate(self):
+        L = lambda n: f".Lvgs_{n}_%="
+        self.e("s_nop 4")
+        for l in self.reads(0, 0, 0):
+            self.e(l)
+        self.body(0, "first")
+        self.e(f"s_branch {L('mids')}")
+        self.e(L("pos") + ":")
+        self.body(0, "first_s")
+        self.e("s_add_i32 %[obase], %[obase], %[ostep]")
+        self.e(L("mids") + ":")
+        self.e("s_mov_b32 %[n], %[npairs]")
+        self.e(L("pair") + ":")
+        self.body(1, "mid")
+        self.body(0, "mid")
+        self.e("s_sub_u32 %[n], %[n], 1")
+        self.e("s_cmp_lg_u32 %[n], 0")
+        self.e(f"s_cbranch_scc1 {L('pair')}")
+        self.e("s_sub_u32 %[npos], %[npos], 1")
+        self.e("s_cmp_eq_u32 %[npos], 0")
+        self.e(f"s_cbranch_scc1 {L('final')}")
+        self.body(1, "last")
+        self.flush()
+        self.e(f"s_branch {L('pos')}")
+        self.e(L("final") + ":")
+        self.body(1, "final")
+        self.flush()
+        return self.out
+
+    def clobbers(self):
+        return [f"v{FR + i}" for i in range(32)] + [f"a{i}" for i in range(32)]
+
+
 class RowWinGen:
     """conv_rowwin_kernel<7, 2> (the network's first layer): KH filter rows x KPR K-tiles, wave tile 64 pixels x 32 channels.
 
@@ -564,6 +675,12 @@ def render():
     o.append("    \"\"")
     o.append("#define VSTAB_ROWWIN_CLOBBERS " + ", ".join(f'"{c}"' for c in r.clobbers()))
     o.append("#define VSTAB_ROWWIN_BUF_BYTES " + str(RowWinGen.BUF))
+    gs = GemmStreamGen()
+    o.append("#define VSTAB_GEMM_STREAM_ASM \\")
+    for l in gs.generate():
+        o.append(f'    "{l}\\n" \\')
+    o.append("    \"\"")
+    o.append("#define VSTAB_GEMM_STREAM_CLOBBERS " + ", ".join(f'"{c}"' for c in gs.clobbers()))
     rs = RowWinStreamGen(6)
     o.append("#define VSTAB_ROWWIN_STREAM_ASM_KPR6 \\")
     for l in rs.generate():
