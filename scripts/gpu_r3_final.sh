@@ -2,7 +2,7 @@
 # round 3: records of the final build: headline line with the CPU baseline, sustained 2000 steps, the other BASELINE
 # shapes, latency and real-video modes, sharded clip and training lines (self-launched, RCCL world 1), sampler bench, rocprofv3 stats + PMC
 set -u
-tag=${1:-r03k}
+tag=${1:-r03p}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 o=gpurun_out
 run() { name=$1; shift; timeout -k 10 600 "$@" > $o/${name}_$tag.json 2> $o/${name}_$tag.err || { echo "$name failed"; tail -5 $o/${name}_$tag.err; return 1; }; python3 -c "
