@@ -245,7 +245,10 @@ class GemmStreamGen(Gen):
             self.group(["s_waitcnt lgkmcnt(0)"], self.mfmas(1), {})
         else:
             k = G // 4
-            self.group(["s_waitcnt lgkmcnt(0)"], self.mfmas(1), {k - 1: ["s_waitcnt vmcnt(0)", "s_barrier"] + self.reads(nxt, 0, 0)})
+            # (a counted wait that lets the previous tile's 32 stores fly on -- vmcnt(32) in the K-tile that carries them -- measured
+            # 1 % on these launches and rests on loads and stores completing in issue order: not taken)
+            vm = 0
+            self.group(["s_waitcnt lgkmcnt(0)"], self.mfmas(1), {k - 1: [f"s_waitcnt vmcnt({vm})", "s_barrier"] + self.reads(nxt, 0, 0)})
 
     def generate(self):
         L = lambda n: f".Lvgs_{n}_%="
