@@ -23,8 +23,6 @@
 // the image are loaded as zeros via the buffer descriptor's range check (no branches).
 // Requires (s*C_in) even, (W*C_in) % 4 == 0, 16-byte aligned input; otherwise the generic
 // scalar-gather kernel runs instead.
-#include <cstdlib>
-
 #include <hip/hip_ext.h>
 
 #include "vstab_internal.h"
