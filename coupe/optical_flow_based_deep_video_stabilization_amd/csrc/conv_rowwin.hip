@@ -51,7 +51,11 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
     // 7-row input windows overlap by five rows
     unsigned bx_, by_, bz_;
     xcd_remap(bx_, by_, bz_);
-    const int stream_r = (MB == 2 && p.asm_loop) ? p.stream_rows : 0;          // > 0: this workgroup computes output rows oy .. oy + stream_r - 1
+    const int stream_r = (MB == 2 && p.asm_loop) ? p.stream_rows : 0;          // > 0: this workgroup computes stream_r output rows (oy, oy + S, oy + 2 S ...)
+    // rows between a stream's tiles.  1: the stream walks down CONSECUTIVE rows.  (Interleaving a column's streams -- stride = their
+    // number, so that they work on adjacent rows at any time and share input rows in L2 -- brings the launch's HBM reads from 3.2x to 1.9x
+    // the one-tile-per-workgroup launch's, and measures the same at B=8 512x512 but 2.5 % SLOWER at 720p / 1080p: profiles/README.md r03p)
+    const int stream_s = 1;
     int oy = stream_r > 0 ? (int)bx_ * stream_r : (int)bx_;
     const int ox0 = p.ox_base + (int)by_ * (64 * MB), n = (int)bz_;
     const int pix_step = p.s_in * p.Cs_in;
@@ -191,11 +195,12 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
                                [o31] "=&v"(o[31])
                              : [vb] "v"(vb), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]),
                                [din] "s"(din), [dwt] "s"(dwt), [mx] "s"(m_x), [hi] "s"(p.Hi), [rowbytes] "s"(row_floats * 4), [kstride] "s"(ktile_stride * 4),
-                               [bias] "v"(bias_l), [slope] "s"(slope), [cs4] "s"(p.Cs_out * 4), [ostep] "s"(p.Wo * p.Cs_out * 4), [vout] "v"(vout), [dout] "s"(dout)
+                               [bias] "v"(bias_l), [slope] "s"(slope), [cs4] "s"(p.Cs_out * 4), [ostep] "s"(stream_s * p.Wo * p.Cs_out * 4), [vout] "v"(vout),
+                               [dout] "s"(dout), [fwd] "s"(stream_s * p.s_in - p.KH)
                              : "memory", "scc", VSTAB_ROWWIN_STREAM_CLOBBERS);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc[0][r] = o[r]; acc[MB - 1][r] = o[16 + r]; }
-                oy += stream_r - 1;                   // the epilogue below stores the stream's last tile
+                oy += (stream_r - 1) * stream_s;      // the epilogue below stores the stream's last tile
             } else
             asm volatile(VSTAB_ROWWIN_ASM_KPR6
                          : [c0] "+a"(acc[0]), [c1] "+a"(acc[MB - 1]), [a0c] "+v"(a0c), [a1c] "+v"(a1c), [a0n] "+v"(a0n), [a1n] "+v"(a1n),

@@ -388,11 +388,11 @@ class RowWinGen:
 
 
 class RowWinStreamGen(RowWinGen):
-    """The same kernel as a STREAM of tiles: a workgroup keeps its x tile and sample and walks down R consecutive output rows.
+    """The same kernel as a STREAM of tiles: a workgroup keeps its x tile and sample and walks down R output rows (S rows apart; the
+    kernel uses S = 1, consecutive rows: interleaving a column's streams measured slower at the large shapes).
 
-    The per-lane window offsets never change; the first window of the next tile is one more LDS-DMA with the row cursor moved back
-    by five rows (next tile's first input row = this tile's last + 1 - 5... i.e. iy0 + 2), fetched during the last filter row of the
-    current tile ('bridge' row) like any other window; the weights' K-tile cursor wraps to 0 in that row's last K-tile.  When a tile's
+    The per-lane window offsets never change; the first window of the next tile is one more LDS-DMA with the row cursor moved by
+    fwd = S * stride - 7 rows, fetched during the last filter row of the current tile ('bridge' row) like any other window; the weights' K-tile cursor wraps to 0 in that row's last K-tile.  When a tile's
     last MFMA has issued, its 32 accumulators are copied to registers (after the 18 wait states an XDL write needs), the next tile's
     first MFMAs take srcC = 0, and the 32 four-byte stores per lane (bias, leaky relu as max(v, slope * v), scalar offset per pixel
     row) are issued between the MFMAs of K-tiles 1..5 of the next tile's first filter row -- the window buffers never serve as a
@@ -455,8 +455,9 @@ class RowWinStreamGen(RowWinGen):
             chunks = bl + self.a_reads(Q, 0 if last else t + 1, last)
             if t == 0 and kind != "final":
                 d = self.dma()
-                if kind == "bridge":                            # next tile's first input row = this tile's first + 2 = (cursor) - 5
-                    d[0] = ["s_mul_i32 %[st], %[rowbytes], 5", "s_sub_u32 %[soff], %[soff], %[st]", "s_sub_u32 %[iy], %[iy], 5"] + d[0]
+                if kind == "bridge":                            # the cursor stands 7 rows below this tile's first input row; the next
+                    d[0] = ["s_mul_i32 %[st], %[rowbytes], %[fwd]",       # tile's first one is 2 * (rows between the stream's tiles) below it
+                            "s_add_i32 %[soff], %[soff], %[st]", "s_add_i32 %[iy], %[iy], %[fwd]"] + d[0]
                 chunks += d
             if kind == "first_s" and per[t]:
                 for _ in range(per[t]):
