@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
     };
     // byte stride of the two window buffers: the assembly loop fetches windows by LDS-DMA, whole 4 KB wave chunks (lanes past the
     // window's end land zeros), so its buffers are a whole number of chunks apart
-    const int wstride = (MB == 2 && p.asm_loop) ? VSTAB_ROWWIN_BUF_BYTES / 4 : p.WLEN;
+    constexpr int ASM_BUF = MB == 2 ? VSTAB_ROWWIN_BUF_BYTES : VSTAB_ROWWIN1_BUF_BYTES;
+    const int wstride = p.asm_loop ? ASM_BUF / 4 : p.WLEN;
     auto store_window = [&](int buf) {
         float *d = win + buf * wstride;
 #pragma unroll
@@ -133,19 +134,21 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
 
     load_window(0);
     store_window(0);
-    if (MB == 2 && p.asm_loop) {
+    if (p.asm_loop) {
         // The K loop as one assembly block (conv_kloop_gfx950.inc; tools/gen_conv_kloop.py documents the schedule): same MFMA order per
         // accumulator as the C++ loop below, so the same bits; fragments of K-tile t+1 are requested under the MFMAs of tile t,
         // the next filter row's window arrives by LDS-DMA, one barrier per filter row.
-        if constexpr (MB == 2) {
+        {
             __syncthreads();
             const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)win;
             unsigned a0c = lds0 + (unsigned)a_off0 * 4u, a1c = lds0 + (unsigned)a_off1 * 4u;
-            unsigned a0n = a0c + VSTAB_ROWWIN_BUF_BYTES, a1n = a1c + VSTAB_ROWWIN_BUF_BYTES;
+            unsigned a0n = a0c + ASM_BUF, a1n = a1c + ASM_BUF;
             const unsigned vb = (unsigned)((wn * 32 + li) * 32 + lh * 4) * 4u;
             unsigned w[7];                            // per-lane byte offset of its 16 bytes of every window chunk inside the input row, or out of range
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
+            for (int j = 0; j < 7; ++j) w[j] = OOB;
+#pragma unroll
+            for (int j = 0; j < NWIN4; ++j) {
                 const int c4 = tid + 256 * j;
                 const int g = g0 + 4 * c4;
                 w[j] = (g >= 0 && g < row_floats && 4 * c4 < p.WLEN) ? (unsigned)g * 4u : OOB;
@@ -162,14 +165,14 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
             dwt.w = 0x00020000;
             const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
             const int m_cur = __builtin_amdgcn_readfirstlane((int)lds0 + wave_u * 1024);
-            int m_n = m_cur + VSTAB_ROWWIN_BUF_BYTES;                     // the first fetch goes to buffer 1
+            int m_n = m_cur + ASM_BUF;                                    // the first fetch goes to buffer 1
             const int m_x = m_cur ^ m_n;
             int s_iy = oy * p.s_in + p.off_y + 1;                         // the next filter row to fetch
             int s_soff = ((n * p.Hi + s_iy) * p.Wi) * p.Cs_in * 4;
             int s_koff = 0, s_nrows = p.KH - 1;
             unsigned v_t0, v_t1;
             long long s_mask;
-            if (stream_r > 0) {
+            if (MB == 2 && stream_r > 0) {
                 // the stream form (tools/gen_conv_kloop.py, RowWinStreamGen): stream_r tiles back to back, every tile but the last stored from
                 // registers under the next tile's first filter row; the last tile's accumulators come back for the epilogue below
                 const unsigned long long aout = (unsigned long long)(size_t)p.out;
@@ -201,6 +204,15 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc[0][r] = o[r]; acc[MB - 1][r] = o[16 + r]; }
                 oy += (stream_r - 1) * stream_s;      // the epilogue below stores the stream's last tile
+            } else if constexpr (MB == 1) {
+                asm volatile(VSTAB_ROWWIN1_ASM_KPR6
+                             : [c0] "+a"(acc[0]), [a0c] "+v"(a0c), [a0n] "+v"(a0n),
+                               [mn] "+s"(m_n), [iy] "+s"(s_iy), [soff] "+s"(s_soff), [koff] "+s"(s_koff), [nrows] "+s"(s_nrows),
+                               [vt0] "=&v"(v_t0), [vt1] "=&v"(v_t1), [mask] "=&s"(s_mask)
+                             : [vb] "v"(vb), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]),
+                               [din] "s"(din), [dwt] "s"(dwt), [mx] "s"(m_x), [hi] "s"(p.Hi), [rowbytes] "s"(row_floats * 4), [kstride] "s"(ktile_stride * 4)
+                             : "memory", "scc", VSTAB_ROWWIN1_CLOBBERS);
+                (void)a1c; (void)a1n;
             } else
             asm volatile(VSTAB_ROWWIN_ASM_KPR6
                          : [c0] "+a"(acc[0]), [c1] "+a"(acc[MB - 1]), [a0c] "+v"(a0c), [a1c] "+v"(a1c), [a0n] "+v"(a0n), [a1n] "+v"(a1n),
@@ -319,7 +331,7 @@ hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEven
     RowWinParams q = p;
     // the staged epilogue needs 16-byte friendly output rows and the [tile][64] staging area inside the two window buffers
     q.out_vec4 = (((uintptr_t)p.out & 15) == 0 && (p.Cs_out & 3) == 0 && (p.c_off & 3) == 0 && 2 * p.WLEN >= tile * 64) ? 1 : 0;
-    q.asm_loop = (p.MB == 2 && (p.SEGP >> 5) == 6 && p.KH >= 1 && 4 * p.WLEN <= VSTAB_ROWWIN_BUF_BYTES) ? 1 : 0;
+    q.asm_loop = ((p.SEGP >> 5) == 6 && p.KH >= 1 && 4 * p.WLEN <= (p.MB == 2 ? VSTAB_ROWWIN_BUF_BYTES : VSTAB_ROWWIN1_BUF_BYTES)) ? 1 : 0;
 #ifdef VSTAB_NO_ASM_KLOOP
     q.asm_loop = 0;                              // A/B builds only (scripts/build_variant_lib.sh)
 #endif
@@ -329,7 +341,7 @@ hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEven
     // prologue + epilogue (0.08: 13 k of 172 k cycles); a launch of at most 256 workgroups has a CU to each (0.53 per tile).  B=8
     // 512x512: R = 8, 512 workgroups, one round; B=8 1080p: R = 30, 1008 workgroups.
     q.stream_rows = 0;
-    if (q.asm_loop && p.KH == 7 && p.N == 64 && p.act >= 0 && p.act <= 2 && p.ox_base + ntx * 128 <= p.Wo &&
+    if (q.asm_loop && p.MB == 2 && p.KH == 7 && p.N == 64 && p.act >= 0 && p.act <= 2 && p.ox_base + ntx * 128 <= p.Wo &&
         (unsigned long long)p.B * p.Ho * p.Wo * p.Cs_out * 4ull < 0x100000000ull) {
         const double F = 0.08;
         const long long cols = (long long)ntx * p.B;
@@ -345,15 +357,15 @@ hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEven
     q.stream_rows = 0;                           // A/B builds only
 #endif
     if (q.stream_rows > 0) grid.x = (unsigned)(p.Ho / q.stream_rows);
-    const size_t lds2 = q.asm_loop ? (size_t)2 * VSTAB_ROWWIN_BUF_BYTES : (size_t)2 * p.WLEN * 4;
+    const size_t lds2 = q.asm_loop ? (size_t)2 * (p.MB == 2 ? VSTAB_ROWWIN_BUF_BYTES : VSTAB_ROWWIN1_BUF_BYTES) : (size_t)2 * p.WLEN * 4;
     const bool timed = ev_start || ev_stop;      // timestamps of the kernel's own dispatch packet, no marker packets (see conv_mfma.hip); a
                                                  // launch that is one half of a pair carries only the start or only the stop event
     if (p.MB == 2) {
         if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<7, 2>), grid, block, lds2, stream, ev_start, ev_stop, 0, q);
         else conv_rowwin_kernel<7, 2><<<grid, block, lds2, stream>>>(q);
     } else {
-        if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<4, 1>), grid, block, (size_t)2 * p.WLEN * 4, stream, ev_start, ev_stop, 0, q);
-        else conv_rowwin_kernel<4, 1><<<grid, block, (size_t)2 * p.WLEN * 4, stream>>>(q);
+        if (timed) hipExtLaunchKernelGGL((conv_rowwin_kernel<4, 1>), grid, block, lds2, stream, ev_start, ev_stop, 0, q);
+        else conv_rowwin_kernel<4, 1><<<grid, block, lds2, stream>>>(q);
     }
     return hipGetLastError();
 }

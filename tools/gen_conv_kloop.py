@@ -296,8 +296,12 @@ class RowWinGen:
     B = (128, 144)        # B fragment sets
     BUF = 7 * 4096        # byte stride of the two window buffers
 
-    def __init__(self, kpr=6):
+    def __init__(self, kpr=6, MB=2):
         self.kpr = kpr
+        self.MB = MB
+        self.NWIN = 7 if MB == 2 else 4            # 4 KB wave chunks per window
+        if MB == 1:                               # 64-pixel tiles (wave tile 32 x 32): half the A registers, lower so that four waves fit a SIMD
+            self.A, self.B, self.BUF = (48, 64), (80, 96), 4 * 4096
         assert kpr % 2 == 0
         self.out = []
 
@@ -307,7 +311,7 @@ class RowWinGen:
     def mfmas(self, P):
         m = []
         for s in range(16):
-            for mb in range(2):
+            for mb in range(self.MB):
                 m.append(f"v_mfma_f32_32x32x2_f32 %[c{mb}], v{self.A[P] + 16 * mb + s}, v{self.B[P] + s}, %[c{mb}]")
         return m
 
@@ -319,7 +323,7 @@ class RowWinGen:
     def a_reads(self, Q, kc, nxt):
         r = []
         for i in range(4):
-            for mb in range(2):
+            for mb in range(self.MB):
                 base = self.A[Q] + 16 * mb + 4 * i
                 addr = f"%[a{mb}{'n' if nxt else 'c'}]"
                 r.append([f"ds_read2_b64 v[{base}:{base + 3}], {addr} offset0:{16 * kc + 4 * i} offset1:{16 * kc + 4 * i + 2}"])
@@ -327,7 +331,7 @@ class RowWinGen:
 
     def dma(self):
         c = [["s_cmp_lt_u32 %[iy], %[hi]", "s_cselect_b64 %[mask], -1, 0"]]
-        for j in range(7):
+        for j in range(self.NWIN):
             vt = f"%[vt{j & 1}]"
             c.append([f"s_add_i32 m0, %[mn], {j * 4096}",
                       f"v_cndmask_b32_e64 {vt}, -2.0, %[w{j}], %[mask]",
@@ -338,15 +342,16 @@ class RowWinGen:
     def tile(self, P, wait_vm, chunks, barrier_after=None):
         self.e(f"s_waitcnt vmcnt({wait_vm}) lgkmcnt(0)")
         first = 0 if barrier_after is None else barrier_after + 1
+        n = 16 * self.MB
+        per = -(-len(chunks) // (n - first))          # chunks per MFMA slot (1 for the 128-pixel form)
         for i, m in enumerate(self.mfmas(P)):
             self.e(m)
             if barrier_after is not None and i == barrier_after:
                 self.e("s_barrier")
             k = i - first
-            if 0 <= k < len(chunks):
-                for l in chunks[k]:
+            for c in chunks[k * per:(k + 1) * per] if k >= 0 else ():
+                for l in c:
                     self.e(l)
-        assert len(chunks) <= 32 - first
 
     def row(self, more):
         n = self.kpr
@@ -359,10 +364,16 @@ class RowWinGen:
             chunks = self.b_loads(Q) + self.a_reads(Q, 0 if last else t + 1, last)
             if t == 0 and more:
                 chunks += self.dma()
-            self.tile(P, 7 if (t == 1 and more) else 0, chunks, barrier_after=3 if last else None)
+            self.tile(P, self.NWIN if (t == 1 and more) else 0, chunks, barrier_after=(3 if self.MB == 2 else 1) if last else None)
+
+    def swap(self):
+        self.e("v_swap_b32 %[a0c], %[a0n]")
+        if self.MB == 2:
+            self.e("v_swap_b32 %[a1c], %[a1n]")
+        self.e("s_xor_b32 %[mn], %[mn], %[mx]")          # mx = m_cur ^ m_nxt: toggles between the two buffers' DMA bases
 
     def generate(self):
-        L = lambda n: f".Lvrw_{n}_%="
+        L = lambda n: f".Lvrw{self.MB}_{n}_%="
         self.e("s_nop 4")
         for c in self.b_loads(0) + self.a_reads(0, 0, False):
             for l in c:
@@ -371,9 +382,7 @@ class RowWinGen:
         self.e(f"s_cbranch_scc1 {L('last')}")
         self.e(L("more") + ":")
         self.row(True)
-        self.e("v_swap_b32 %[a0c], %[a0n]")
-        self.e("v_swap_b32 %[a1c], %[a1n]")
-        self.e("s_xor_b32 %[mn], %[mn], %[mx]")          # mx = m_cur ^ m_nxt: toggles between the two buffers' DMA bases
+        self.swap()
         self.e("s_sub_u32 %[nrows], %[nrows], 1")
         self.e("s_cmp_lg_u32 %[nrows], 0")
         self.e(f"s_cbranch_scc1 {L('more')}")
@@ -672,6 +681,13 @@ def render():
         o.append("    \"\"")
         if BN == 128:
             o.append("#define VSTAB_KLOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in g.clobbers()))
+    r1 = RowWinGen(6, MB=1)
+    o.append("#define VSTAB_ROWWIN1_ASM_KPR6 \\")
+    for l in r1.generate():
+        o.append(f'    "{l}\\n" \\')
+    o.append("    \"\"")
+    o.append("#define VSTAB_ROWWIN1_CLOBBERS " + ", ".join(f'"{c}"' for c in r1.clobbers()))
+    o.append("#define VSTAB_ROWWIN1_BUF_BYTES " + str(r1.BUF))
     r = RowWinGen(6)
     o.append("#define VSTAB_ROWWIN_ASM_KPR6 \\")
     for l in r.generate():
