@@ -106,7 +106,7 @@ def test_predict2_tap_table_rejects_bad_arguments():
 
 
 # ----------------------------------------------------------------------------- the first layer's stream form (conv_rowwin.hip, stream_rows > 0)
-@pytest.mark.parametrize("B,H,W", [(4, 512, 512), (2, 512, 1024), (16, 128, 512)])
+@pytest.mark.parametrize("B,H,W", [(4, 512, 512), (2, 512, 1024), (16, 128, 512), (16, 512, 512)])
 def test_first_layer_stream_form_vs_oracle(B, H, W):
     """launches whose 128-pixel tiles are a multiple of 512 run the first layer as streams of consecutive output rows per
     workgroup (4 rows each; tiles stored from registers under the next tile's first filter row, the last one by the ordinary epilogue): conv1 against
