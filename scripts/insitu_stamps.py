@@ -27,8 +27,9 @@ L.vstab_debug_stamp_reset()
 vs.flownetS_pyramid(feats, B)
 torch.cuda.synchronize()
 # launch order of conv_mfma launches in a forward (conv1 runs on the row-window kernel): see api.cpp forward_chunk
-names = ["conv2", "conv3", "conv3_1 gemm", "conv4", "conv4_1 gemm", "conv5", "conv5_1 gemm", "conv6", "conv6_1 gemm",
-         "pf6 taps", "deconv5", "pf5 taps", "deconv4", "pf4 taps", "deconv3", "pf3 taps", "deconv2", "pf2 taps"]
+# (conv3_1 / conv4_1's GEMMs run on wino_gemm_stream_kernel and predict_flow2's taps on tap_panel_kernel at B=8 512x512: no stamps in those)
+names = ["conv2", "conv3", "conv4", "conv5", "conv5_1 gemm", "conv6", "conv6_1 gemm",
+         "pf6 taps", "deconv5", "pf5 taps", "deconv4", "pf4 taps", "deconv3", "pf3 taps", "deconv2"]
 buf = np.zeros(8 * 8192, dtype=np.uint64)
 print(f"{'launch':<14}{'wgs':>6}{'prologue':>10}{'loop':>10}{'epilogue':>10}{'total':>10}{'MHz':>7}{'span us':>9}   first-to-last start us / end us")
 for slot, name in enumerate(names):
@@ -43,7 +44,7 @@ for slot, name in enumerate(names):
     span = (s[:, 5].max() - s[:, 4].min()) / 100.0
     print(f"{name:<14}{len(s):>6}{np.median(pro):>10.0f}{np.median(loop):>10.0f}{np.median(epi):>10.0f}{np.median(tot):>10.0f}{clk:>7.0f}{span:>9.1f}   "
           f"{(s[:, 4].max() - s[:, 4].min()) / 100.0:.1f} / {(s[:, 5].max() - s[:, 5].min()) / 100.0:.1f}")
-    if name in ("conv2", "conv3", "deconv2", "conv3_1 gemm", "conv4"):      # where does the span go?  start-time and lifetime distributions
+    if name in ("conv2", "conv3", "deconv2", "conv4", "deconv3"):      # where does the span go?  start-time and lifetime distributions
         st = (s[:, 4] - s[:, 4].min()) / 100.0
         life = (s[:, 5] - s[:, 4]) / 100.0
         q = lambda v: " ".join(f"{np.percentile(v, k):7.1f}" for k in (0, 10, 25, 50, 75, 90, 100))
