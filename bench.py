@@ -182,6 +182,11 @@ def main():
     ap.add_argument("--st-warp", choices=("none", "affine", "projective", "homography"), default="none",
                     help="BASELINE configs[2]'s spatial_transformer leg: also warp the stabilised frame with AffineTransformer / "
                          "ProjectiveTransformer (spatial_transformer.py:400-452, 539-608) or warp.transformImage (warp.py:46-86) inside the step")
+    ap.add_argument("--plan-flags", type=int, default=0,
+                    help="vstab_set_plan_flags bits for A/B runs: 1 = few-row layers on the tiled kernel + combine launch (no weight-stream "
+                         "kernel: the round-3 schedule)")
+    ap.add_argument("--plan-batch", type=int, default=0,
+                    help="vstab_set_plan_batch: pin the arithmetic-changing plan decisions to this batch (0 = plan for --batch itself)")
     ap.add_argument("--vgg16", action="store_true",
                     help="BASELINE config 5: also run the VGG16 trunk (preprocess + 13 conv + 5 pool) on the warped frames")
     args = ap.parse_args()
@@ -223,6 +228,10 @@ def main():
     feats = torch.rand(B, H, W, Cin, generator=g).cuda()
     frame = torch.rand(B, H, W, 3, generator=g).cuda()
     ctx = runtime.get_context()
+    if args.plan_flags:
+        ctx.set_plan_flags(args.plan_flags)
+    if args.plan_batch:
+        ctx.set_plan_batch(args.plan_batch)
     if args.roctx:
         runtime.trace_ranges(True)
 
@@ -533,7 +542,7 @@ def main():
                    "batch_per_gpu": B, "height": H, "width": W, "cin": Cin,
                    "gflop_per_sample": round(netspec.gflop_per_sample(H, W, Cin), 2),
                    "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL, schedule " + args.gather_schedule + f", one collective per {G} step(s)") if gather is not None else False,
-                   "vgg16_trunk": bool(args.vgg16), "st_warp": args.st_warp,
+                   "vgg16_trunk": bool(args.vgg16), "st_warp": args.st_warp, "plan_flags": args.plan_flags, "plan_batch": args.plan_batch,
                    "host_calls_per_step": "1 (vstab_stabilise_originalsize, outputs pre-allocated)" if stab is not None else "2 + 7 allocations"},
         "roofline": roofline,
         "roofline_hbm": roofline_hbm,

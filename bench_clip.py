@@ -36,6 +36,11 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: ranks may share one GPU and frames are reassembled through host memory -- a rehearsal of the N>1 control "
                          "flow (ragged shards, overlapped gather) on a one-GPU box; its numbers mean nothing")
+    ap.add_argument("--check", action="store_true",
+                    help="every frame gets its own seeded input (all of them generated on every rank: use small frames), and rank 0 also "
+                         "computes the UNSHARDED sequence with the same micro-batch and compares the reassembled clip with it bit for bit "
+                         "(`sharded_equals_unsharded` in the JSON line; a mismatch is exit code 3)")
+    ap.add_argument("--no-plan-pin", action="store_true", help="do not pin the launch plan to the micro-batch (ragged tails then differ in the last bits)")
     args = ap.parse_args()
     import importlib.util
     spec = importlib.util.spec_from_file_location(
@@ -70,11 +75,22 @@ def main():
 
     F_, H, W, Cin, MB = args.frames, args.height, args.width, args.cin, args.micro_batch
     vs.initialize_global_variables(seed=1, cin=Cin)
+    # a shard's last micro-batch is ragged (125 frames per rank in micro-batches of 8 end with one of 5): the launch plan is pinned to
+    # the full micro-batch, so every frame comes out bit-identical to the unsharded run whatever it is batched with (vstab_set_plan_batch)
+    if not args.no_plan_pin:
+        runtime.get_context().set_plan_batch(MB)
     lo, hi = vdist.shard_range(F_, rank, world)
     n_local = hi - lo
-    g = torch.Generator().manual_seed(2000 + rank)
-    feats = torch.rand(MB, H, W, Cin, generator=g).cuda()            # one synthetic micro-batch, reused
-    frame = torch.rand(MB, H, W, 3, generator=g).cuda()
+    if args.check:
+        g = torch.Generator().manual_seed(4242)                      # the SAME clip on every rank; a rank works on frames [lo, hi)
+        all_feats = torch.rand(F_, H, W, Cin, generator=g)
+        all_frame = torch.rand(F_, H, W, 3, generator=g)
+        clip_feats, clip_frame = all_feats[lo:hi].cuda(), all_frame[lo:hi].cuda()
+        feats, frame = clip_feats[:MB].contiguous(), clip_frame[:MB].contiguous()
+    else:
+        g = torch.Generator().manual_seed(2000 + rank)
+        feats = torch.rand(MB, H, W, Cin, generator=g).cuda()            # one synthetic micro-batch, reused
+        frame = torch.rand(MB, H, W, 3, generator=g).cuda()
     L = _lib.lib()
     host = args.backend == "gloo"
     seq = vdist.SequenceGatherer(F_, (H, W, 3), torch.uint8, torch.device("cpu") if host else torch.device("cuda", local_rank)) if use_dist else None
@@ -85,7 +101,10 @@ def main():
         """Micro-batches of this rank's shard through the HIP path; every finished micro-batch of the part all shards have in
         common is all-gathered into its place of the full clip at once, beside the next micro-batch's kernels."""
         def compute(b0, bc):
-            _, _, warped = vs.stabilise_originalsize(feats[:bc], frame[:bc])
+            if args.check:
+                _, _, warped = vs.stabilise_originalsize(clip_feats[b0:b0 + bc].contiguous(), clip_frame[b0:b0 + bc].contiguous())
+            else:
+                _, _, warped = vs.stabilise_originalsize(feats[:bc], frame[:bc])
             _lib.check(L.vstab_quantise_output(warped.data_ptr(), bc * H * W, shard[b0:b0 + bc].data_ptr(), runtime.stream_ptr()))
 
         for b0 in range(0, common, MB):
@@ -97,7 +116,7 @@ def main():
             compute(common, n_local - common)
 
     # warm-up: one micro-batch (kernels loaded, workspaces allocated)
-    vs.stabilise_originalsize(feats, frame)
+    vs.stabilise_originalsize(feats[:min(MB, max(n_local, 1))], frame[:min(MB, max(n_local, 1))])
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -116,17 +135,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_compute = float(t[0]), float(t[1])
     assert full.shape[0] == F_
+    same = None
+    if args.check and rank == 0:          # the unsharded sequence: one rank, the same micro-batch size, the clip from frame 0
+        ref = torch.empty((F_, H, W, 3), dtype=torch.uint8, device="cuda")
+        for b0 in range(0, F_, MB):
+            bc = min(MB, F_ - b0)
+            _, _, warped = vs.stabilise_originalsize(all_feats[b0:b0 + bc].cuda(), all_frame[b0:b0 + bc].cuda())
+            _lib.check(L.vstab_quantise_output(warped.data_ptr(), bc * H * W, ref[b0:b0 + bc].data_ptr(), runtime.stream_ptr()))
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ref.cpu(), full.cpu()))
     if rank == 0:
         print(json.dumps({
             "metric": f"stabilised frames/sec, {F_}-frame {H}x{W} clip sharded over {world} GPU(s), all-gather reassembly",
             "value": round(F_ / elapsed, 2), "unit": "frames/s", "n_gpus": world, "higher_is_better": True,
             "scaling": "strong", "dtype": "f32", "data": "synthetic, teacher-forced history",
             "seconds_total": round(elapsed, 4), "seconds_compute_and_overlapped_gather": round(t_compute, 4),
-            "seconds_host_issue": round(t_issue, 4),
+            "seconds_host_issue": round(t_issue, 4), "sharded_equals_unsharded": same, "plan_batch": 0 if args.no_plan_pin else MB,
             "config": {"workload": f"{F_} frames {H}x{W}x{Cin}, micro-batch {MB}, uint8 frames all-gathered per micro-batch, overlapped with compute",
                        "gathered_bytes": int(F_) * H * W * 3}}), file=real_stdout, flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if same is False:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -20,6 +20,55 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA
+
+
+def cpu_baseline(weights, H, W, seconds_budget=25.0):
+    """One optimiser step of the reference's training graph (main:176-335) as the oracle restates it, timed on the host cores: train-mode
+    forward (BatchNorm on batch statistics), loss_main, torch autograd backward through the restated graph, Adam -- on a bounded sample
+    (batch 1 of the same frame size; the GPU number is per sample too).  kind = "port": TensorFlow 1.10 cannot exist on this box."""
+    import numpy as np
+    from oracle import vstab_oracle as vo
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    threads = max(1, min(n, 16))
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    feats, gt, un = torch.rand(1, H, W, 27, generator=g), torch.rand(1, H, W, 3, generator=g), torch.rand(1, H, W, 3, generator=g)
+    Wt = {k: torch.tensor(v, dtype=torch.float32, requires_grad=("moving_" not in k)) for k, v in weights.items()}
+    m = {k: torch.zeros_like(v) for k, v in Wt.items() if v.requires_grad}
+    v2 = {k: torch.zeros_like(v) for k, v in Wt.items() if v.requires_grad}
+
+    def step(t):
+        flows = vo.flownetS_pyramid(feats, Wt, torch.float32, is_train=True)
+        loss = vo.loss_main(flows, gt, un, torch.float32)
+        loss.backward()
+        with torch.no_grad():
+            for k, p in Wt.items():
+                if p.grad is None:
+                    continue
+                m[k].mul_(0.9).add_(p.grad, alpha=0.1)
+                v2[k].mul_(0.999).addcmul_(p.grad, p.grad, value=0.001)
+                p.sub_(1e-4 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t) * m[k] / (v2[k].sqrt() + 1e-8))
+                p.grad = None
+        return float(loss.detach())
+
+    t0 = time.perf_counter()
+    step(1)
+    warm = time.perf_counter() - t0
+    times = []
+    while len(times) < 3 and sum(times) + warm < seconds_budget:
+        t0 = time.perf_counter()
+        step(len(times) + 2)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times or [warm]))
+    return {"value": round(1.0 / med, 3), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times) or 1} timed optimiser steps on ONE {H}x{W}x27 sample (train-mode forward, loss_main, autograd backward, Adam), "
+                      "torch-CPU fp32 restatement of the TF training graph"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
@@ -27,6 +76,8 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the three extra steps with an event pair around every conv-family call")
     ap.add_argument("--phases", action="store_true", help="also time forward / loss+backward / Adam separately (adds syncs)")
     ap.add_argument("--gpus", type=int, default=1, help="data-parallel replicas to start when not already under a launcher")
     args = ap.parse_args()
@@ -88,6 +139,35 @@ def main():
             tf += b - a; tb += c - b; ta += d - c
         phases = {"forward_ms": round(tf / args.steps * 1e3, 3), "loss_backward_ms": round(tb / args.steps * 1e3, 3),
                   "adam_ms": round(ta / args.steps * 1e3, 3)}
+    # ---- roofline of the step's MFMA-bound calls: three more steps with an event pair (on the launch stream) around every conv-family
+    # library call; a call's time includes its helper launches (operand packing, split-K combine, pixel tables), so the fractions are
+    # lower bounds on the MFMA kernels' own.  flops = 2*MAC of the layer each call computes (forward, input gradient and filter gradient
+    # of a layer cost the same; Winograd-form calls are priced as the direct 3x3 convolution)
+    roofline = None
+    if not args.no_roofline:
+        tr.profile_calls(True)
+        for _ in range(3):
+            tr.step(feats, gt, un, lr=1e-4)
+        fam = tr.profile_read()
+        tr.profile_calls(False)
+        if fam:
+            rows = {k: {"ms_per_step": round(ms / 3, 4), "calls_per_step": n // 3, "gflop_per_step": round(fl / 3 / 1e9, 2),
+                        "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+                    for k, (ms, fl, n) in fam.items() if ms > 0}
+            dom = max(rows, key=lambda k: rows[k]["ms_per_step"])
+            tot_ms = sum(ms for ms, _, _ in fam.values()) / 3
+            tot_fl = sum(fl for _, fl, _ in fam.values()) / 3
+            kern = {"conv_wgrad": "wgrad_mfma_kernel<128> / <64> (+ pixel table, split-K combine)",
+                    "conv_dgrad": "conv_mfma_kernel (input gradients and DeConv2dLayer forwards; + operand packing, split-K combine)",
+                    "conv_forward": "conv_mfma_kernel / conv_rowwin_kernel (+ operand packing, split-K combine)",
+                    "conv3x3_winograd": "winograd transforms + 16-position conv_mfma_kernel launch", "conv3x3_winograd_wgrad": "winograd transforms + batched wgrad_mfma_kernel"}
+            roofline = {"bound": "mfma", "achieved": rows[dom]["achieved"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rows[dom]["frac"],
+                        "traffic": None, "kernel": kern.get(dom, dom), "family": dom, "families": rows,
+                        "all_mfma_calls": {"ms_per_step": round(tot_ms, 3), "gflop_per_step": round(tot_fl / 1e9, 1),
+                                           "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                           "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
+                        "note": "event pairs around whole library calls (helper launches included): lower bounds on the MFMA kernels' own fractions; "
+                                "Winograd-form calls priced as direct 3x3 convolutions"}
     gf = netspec.gflop_per_sample(H, W, 27)
     if rank != 0:
         if use_dist:
@@ -98,7 +178,8 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": "f32",
         "data": "synthetic (uniform [0,1) frames, seeded He-normal weights)", "final_loss": float(loss),
-        "approx_tflops": round(3.0 * gf * B * world / dt / 1e3, 2), "phases": phases,
+        "approx_tflops": round(3.0 * gf * B * world / dt / 1e3, 2), "phases": phases, "roofline": roofline,
+        "cpu_baseline": (cpu_baseline(w, H, W) if (world == 1 and not args.no_cpu_baseline) else None),
         "config": {"workload": f"batch={B} per GPU {H}x{W}x27: train-mode forward + loss_main + backward + Adam (38.7 M parameters)"
                                + ("; gradients averaged with one RCCL all-reduce of a 155 MB bucket" if use_dist else "")}}), file=real_stdout, flush=True)
     if use_dist:

@@ -29,6 +29,9 @@ EXPORTS = {
     "vstab_load_weights": (C.c_int, [C.c_void_p, C.POINTER(VstabTensor), C.c_int]),
     "vstab_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "vstab_workspace_layout": (C.c_int, [C.c_int] * 4 + [C.POINTER(VstabWsEntry), C.c_int]),
+    "vstab_set_plan_batch": (C.c_int, [C.c_void_p, C.c_int]),
+    "vstab_set_plan_flags": (C.c_int, [C.c_void_p, C.c_uint]),
+    "vstab_workspace_bytes_ctx": (C.c_size_t, [C.c_void_p] + [C.c_int] * 4),
     "vstab_flownets_forward": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 +
                                [C.c_void_p, C.c_size_t, C.c_void_p]),
     "vstab_flow_resize_scale": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
@@ -47,6 +50,7 @@ EXPORTS = {
     "vstab_st_bilinear_interp": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_st_meshgrid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vstab_homography_warp": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vstab_transform_image": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p]),
     "vstab_vec2mtrx": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vstab_vgg16_load": (C.c_int, [C.c_void_p, C.POINTER(VstabTensor), C.c_int]),
     "vstab_vgg16_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
@@ -112,6 +116,7 @@ EXPORTS = {
     "vstab_profile_read_direct": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "vstab_profile_kernel_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "vstab_host_layer_plan": (C.c_int, [C.c_int] * 5 + [c_int32_p, C.c_int]),
+    "vstab_host_layer_plan_pinned": (C.c_int, [C.c_int, C.c_uint] + [C.c_int] * 5 + [c_int32_p, C.c_int]),
     "vstab_host_pack_layer": (C.c_longlong, [C.c_int, C.c_int, c_float_p, C.POINTER(C.c_double), c_float_p,
                                              C.c_longlong]),
 }

@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvstab_hip.so")
-SOURCES = ("conv_mfma.hip", "conv_rowwin.hip", "tap_panel.hip", "wino_gemm_stream.hip", "flow_ops.hip", "sampler_ops.hip", "nldf_ops.hip", "clip_ops.hip", "train_ops.hip", "wgrad_mfma.hip", "winograd_ops.hip", "homography_ops.hip", "pack.cpp", "api.cpp", "nldf_api.cpp", "train_api.cpp")
+SOURCES = ("conv_mfma.hip", "conv_rowwin.hip", "conv_skinny.hip", "tap_panel.hip", "wino_gemm_stream.hip", "flow_ops.hip", "sampler_ops.hip", "nldf_ops.hip", "clip_ops.hip", "train_ops.hip", "wgrad_mfma.hip", "winograd_ops.hip", "homography_ops.hip", "pack.cpp", "api.cpp", "nldf_api.cpp", "train_api.cpp")
 HEADERS = ("vstab_internal.h", "api_internal.h", "hbm_profile.h", "conv_kloop_gfx950.inc", os.path.join("..", "..", "..", "include", "vstab.h"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-result"]

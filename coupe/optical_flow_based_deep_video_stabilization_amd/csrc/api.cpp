@@ -2,6 +2,8 @@
 // FlowNetS-pyramid forward schedule (model.py:786-893) and the glue/warp entry points.
 #include <cstdlib>
 #include <map>
+#include <memory>
+#include <new>
 
 #include "api_internal.h"
 
@@ -105,11 +107,18 @@ struct Plan {
     ConvParams cp[19];
     ConvTile tile[19];
     bool vec4[19];
+    bool skinny[19];        // few-row layers as weight streams (conv_skinny.hip): tile[i] == TILE_SKINNY, cp[i].ksplit = its own factor
     // Winograd F(2x2,3x3) form of the 3x3 stride-1 encoder stages (cp[i] stays the direct form: host-plan tests, fallback)
     bool wino[10];
     ConvParams wcp[10];
     ConvTile wtile[10];
 };
+
+// What a context pins about its launch plans (vstab_set_plan_batch / vstab_set_plan_flags).  batch > 0: every per-layer decision that
+// changes the ARITHMETIC of a sample -- split-K factors, Winograd or direct form, weight-stream or tiled kernel -- is taken for a
+// batch of `batch` samples and reused for any smaller batch, so a sample's results do not depend on what it is batched with
+// (sharded clips with ragged tails: main:553-558's samples are independent).
+struct PlanPin { int batch = 0; unsigned flags = 0; };
 
 bool level_sizes(int H, int W, int *eh, int *ew)
 {
@@ -194,6 +203,16 @@ ConvTile choose_tile_split(ConvParams &p, ConvTile tile, bool vec4)
     return tile;
 }
 
+// Few rows per phase (one sample's 1/32 and 1/64 levels, the first decoder steps): the layer is a weight stream (conv_skinny.hip).
+// Returns true and sets p.ksplit to that kernel's own factor.
+bool choose_skinny(ConvParams &p, bool vec4, unsigned flags)
+{
+    if (flags & VSTAB_PLAN_NO_SKINNY) return false;
+    if (!conv_skinny_applicable(p, vec4)) return false;
+    p.ksplit = conv_skinny_split(p, (flags & 4u) ? 8 : 16);          // (bit 4: an experiment of the round, see profiles/README.md)
+    return true;
+}
+
 namespace {
 KLayout enc_layout(int i, int cin_first)
 {
@@ -255,11 +274,28 @@ bool wino_applies(int B, int H, int W, int cin, int cout)
 }
 
 namespace {
-bool make_plan(int B, int H, int W, int Cin, Plan &pl)
+int max_chunk(int B, int H, int W, int Cin);
+
+bool make_plan(int B, int H, int W, int Cin, Plan &pl, const PlanPin *pin = nullptr)
 {
     if (B < 1 || Cin < 1 || Cin > 4096) return false;
     pl.B = B; pl.H = H; pl.W = W; pl.Cin = Cin;
     if (!level_sizes(H, W, pl.eh, pl.ew)) return false;
+    const unsigned flags = pin ? pin->flags : 0u;
+    // a pinned plan batch: the decisions come from the plan of (one chunk of) that batch
+    std::unique_ptr<Plan> ref;
+    if (pin && pin->batch > 0) {
+        if (B > pin->batch) return false;
+        const int cmax = max_chunk(pin->batch, H, W, Cin);
+        if (cmax < 1) return false;
+        const int nch = (pin->batch + cmax - 1) / cmax, rb = (pin->batch + nch - 1) / nch;
+        if (B > rb) return false;                       // callers process a pinned batch in chunks of rb (vstab_flownets_forward)
+        if (B != rb) {
+            ref.reset(new (std::nothrow) Plan);
+            PlanPin unpinned; unpinned.flags = flags;
+            if (!ref || !make_plan(rb, H, W, Cin, *ref, &unpinned)) return false;
+        }
+    }
     // every tensor must stay below 2^31 BYTES: the kernels address through buffer descriptors with
     // 32-bit byte offsets and use 0xC0000000 as the "reads as zero" offset (larger batches are
     // processed in chunks by vstab_flownets_forward)
@@ -313,7 +349,12 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         p.Mmax = p.ph[0].M;
         pl.vec4[i] = (p.Cs_in % 4 == 0) && (p.SEG % 4 == 0);
         set_ranges(p);
-        pl.tile[i] = choose_tile_split(p, pl.tile[i], pl.vec4[i]);
+        if (ref) { pl.tile[i] = ref->tile[i]; pl.skinny[i] = ref->skinny[i]; p.ksplit = ref->cp[i].ksplit; }
+        else {
+            pl.tile[i] = choose_tile_split(p, pl.tile[i], pl.vec4[i]);
+            pl.skinny[i] = i > 0 && choose_skinny(p, pl.vec4[i], flags);
+            if (pl.skinny[i]) pl.tile[i] = TILE_SKINNY;
+        }
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
     }
     // ---- Winograd form of the 3x3 stride-1 stages: a 16-phase 1x1 GEMM over the transformed tiles (winograd_ops.hip)
@@ -321,9 +362,9 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
     for (int i = 0; i < 10; ++i) {
         pl.wino[i] = false;
         const Enc &e = ENC[i];
-        if (e.k != 3 || e.s != 1 || e.p != 1) continue;
+        if (e.k != 3 || e.s != 1 || e.p != 1 || pl.skinny[i]) continue;
         const int cin_i = ENC[i - 1].cout;
-        if (ENC_IO[i].cs_in != cin_i || !wino_applies(B, pl.eh[i], pl.ew[i], cin_i, e.cout)) continue;      // plain input buffer
+        if (ref ? !ref->wino[i] : (ENC_IO[i].cs_in != cin_i || !wino_applies(B, pl.eh[i], pl.ew[i], cin_i, e.cout))) continue;      // plain input buffer
         const int TH = (pl.eh[i] + 1) / 2, TW = (pl.ew[i] + 1) / 2;
         fill_wino_gemm(pl.wcp[i], B, pl.eh[i], pl.ew[i], cin_i, e.cout);
         // The reduction is short (K = C_in: 8..32 K-tiles), so a workgroup's prologue and epilogue weigh in.  Stages with at least
@@ -332,7 +373,7 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         // co-resident workgroups per CU (conv5_1 40 vs 41.3 us, conv6_1 44.5 vs 68.5)
         {
             const long long t128 = 16LL * ((pl.wcp[i].Mmax + 127) / 128) * (e.cout / 128);
-            pl.wtile[i] = t128 >= 1024 ? TILE_128x128 : TILE_128x64;
+            pl.wtile[i] = t128 >= 1024 ? TILE_128x128 : TILE_128x64;         // (a tile shape changes no sum: not pinned)
         }
         wino_v = std::max(wino_v, (size_t)B * 16 * TH * TW * cin_i);
         wino_m = std::max(wino_m, (size_t)B * 16 * TH * TW * e.cout);
@@ -370,7 +411,12 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
             }
         pl.vec4[10 + l] = true;
         set_ranges(p);
-        pl.tile[10 + l] = choose_tile_split(p, pl.tile[10 + l], true);
+        if (ref) { pl.tile[10 + l] = ref->tile[10 + l]; pl.skinny[10 + l] = ref->skinny[10 + l]; p.ksplit = ref->cp[10 + l].ksplit; }
+        else {
+            pl.tile[10 + l] = choose_tile_split(p, pl.tile[10 + l], true);
+            pl.skinny[10 + l] = choose_skinny(p, true, flags);
+            if (pl.skinny[10 + l]) pl.tile[10 + l] = TILE_SKINNY;
+        }
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad);
     }
     // ---- predict2 tap table: 1x1 conv concat2 -> 18 (pad 32) columns
@@ -384,7 +430,7 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
         p.N = 32; p.Npad = 32; p.act = 0; p.nphase = 1; p.ksplit = 1;
         p.ph[0].Hg = p.Hi; p.ph[0].Wg = p.Wi; p.ph[0].M = B * p.Hi * p.Wi; p.Mmax = p.ph[0].M;
         // (launched as tap_panel_kernel, tap_panel.hip: the parameters here only feed the flop / byte accounting of the reports)
-        pl.tile[14] = TILE_128x32; pl.vec4[14] = true;
+        pl.tile[14] = TILE_128x32; pl.vec4[14] = true; pl.skinny[14] = false;
         set_ranges(p);
     }
     // ---- predict6..3 tap tables: 1x1 conv of the level's (concat) tensor -> 18 (pad 32) columns
@@ -399,9 +445,10 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
             p.Ho = p.Hi; p.Wo = p.Wi; p.Cs_out = 32; p.c_off = 0;
             p.N = 32; p.Npad = 32; p.act = 0; p.nphase = 1;
             p.ph[0].Hg = p.Hi; p.ph[0].Wg = p.Wi; p.ph[0].M = B * p.Hi * p.Wi; p.Mmax = p.ph[0].M;
-            pl.tile[15 + l] = TILE_128x32; pl.vec4[15 + l] = true;
+            pl.tile[15 + l] = TILE_128x32; pl.vec4[15 + l] = true; pl.skinny[15 + l] = false;
             set_ranges(p);
-            choose_split(p, 32);   // A/B on one box: split-K + combine beats 4..256 long-running workgroups by ~90 us/step
+            if (ref) p.ksplit = ref->cp[15 + l].ksplit;
+            else choose_split(p, 32);   // A/B on one box: split-K + combine beats 4..256 long-running workgroups by ~90 us/step
             if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
             (void)dst;
         }
@@ -414,6 +461,19 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl)
     }
     pl.total = off;
     return true;
+}
+
+// Largest batch whose every tensor stays below 2 GiB (0 if even one sample does not fit).
+int max_chunk(int B, int H, int W, int Cin)
+{
+    Plan pl;
+    int lo = 0, hi = B;                     // invariant: lo fits (or 0), hi+1.. do not
+    if (make_plan(B, H, W, Cin, pl)) return B;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (make_plan(mid, H, W, Cin, pl)) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }
 
 }  // namespace
@@ -455,6 +515,14 @@ extern "C" int vstab_create(vstab_ctx **out, int device)
     vstab_ctx *c = new (std::nothrow) vstab_ctx();
     if (!c) return fail(nullptr, VSTAB_E_NOMEM, "vstab_create: out of host memory");
     c->device = device;
+    // ticket words of the in-launch split-K reductions (conv_skinny.hip): zero here, and every launch leaves them zero
+    hipError_t te = hipMalloc(reinterpret_cast<void **>(&c->tickets), SKINNY_MAX_TILES * sizeof(unsigned));
+    if (te == hipSuccess) te = hipMemset(c->tickets, 0, SKINNY_MAX_TILES * sizeof(unsigned));
+    if (te != hipSuccess) {
+        if (c->tickets) (void)hipFree(c->tickets);
+        delete c;
+        return fail(nullptr, VSTAB_E_NOMEM, "vstab_create: ticket words: %s", hipGetErrorString(te));
+    }
     *out = c;
     return VSTAB_OK;
 }
@@ -463,6 +531,7 @@ extern "C" void vstab_destroy(vstab_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->dev_weights) (void)hipFree(ctx->dev_weights);
+    if (ctx->tickets) (void)hipFree(ctx->tickets);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->vgg_weights) (void)hipFree(ctx->vgg_weights);
     vstab_nldf_free(ctx->nldf);
@@ -487,13 +556,56 @@ extern "C" int vstab_level_sizes(int H, int W, int32_t *hw20)
     return VSTAB_OK;
 }
 
-static int max_chunk(int B, int H, int W, int Cin);
-
 extern "C" size_t vstab_workspace_bytes(int B, int H, int W, int Cin)
 {
     Plan pl;
     const int chunk = B >= 1 ? max_chunk(B, H, W, Cin) : 0;
     if (chunk < 1 || !make_plan(chunk, H, W, Cin, pl)) { fail(nullptr, VSTAB_E_SHAPE, "unsupported problem %dx%dx%dx%d", B, H, W, Cin); return 0; }
+    return pl.total;
+}
+
+// ---- pinned plans (vstab.h): decisions of a batch of `batch` samples for every smaller batch
+static PlanPin pin_of(const vstab_ctx *ctx)
+{
+    PlanPin pin;
+    if (ctx) { pin.batch = ctx->plan_batch; pin.flags = ctx->plan_flags; }
+    return pin;
+}
+
+// chunk size the forward processes a batch of B in: every tensor below 2 GiB, chunks equalised; under a pinned plan batch the
+// chunk size of THAT batch (ragged chunks then share its decisions)
+static int chunk_size(const PlanPin &pin, int B, int H, int W, int Cin)
+{
+    const int ref = pin.batch > 0 ? pin.batch : B;
+    const int cmax = ref >= 1 ? max_chunk(ref, H, W, Cin) : 0;
+    if (cmax < 1) return 0;
+    const int nch = (ref + cmax - 1) / cmax;
+    return std::min(B, (ref + nch - 1) / nch);
+}
+
+extern "C" int vstab_set_plan_batch(vstab_ctx *ctx, int batch)
+{
+    if (!ctx) return fail(nullptr, VSTAB_E_STATE, "set_plan_batch: ctx is NULL");
+    if (batch < 0) return fail(ctx, VSTAB_E_SHAPE, "set_plan_batch: batch must be >= 0 (0 = plan for the batch of each call)");
+    ctx->plan_batch = batch;
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags)
+{
+    if (!ctx) return fail(nullptr, VSTAB_E_STATE, "set_plan_flags: ctx is NULL");
+    if (flags & ~(unsigned)(VSTAB_PLAN_NO_SKINNY | 4u)) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
+    ctx->plan_flags = flags;
+    return VSTAB_OK;
+}
+
+extern "C" size_t vstab_workspace_bytes_ctx(const vstab_ctx *ctx, int B, int H, int W, int Cin)
+{
+    Plan pl;
+    const PlanPin pin = pin_of(ctx);
+    if (pin.batch > 0 && B > pin.batch) { fail(nullptr, VSTAB_E_SHAPE, "batch %d exceeds the pinned plan batch %d", B, pin.batch); return 0; }
+    const int chunk = B >= 1 ? chunk_size(pin, B, H, W, Cin) : 0;
+    if (chunk < 1 || !make_plan(chunk, H, W, Cin, pl, &pin)) { fail(nullptr, VSTAB_E_SHAPE, "unsupported problem %dx%dx%dx%d", B, H, W, Cin); return 0; }
     return pl.total;
 }
 
@@ -524,15 +636,21 @@ static const int LAYER_OUT[19] = {B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV
 
 extern "C" int vstab_host_layer_plan(int B, int H, int W, int Cin, int layer, int32_t *out, int cap)
 {
+    return vstab_host_layer_plan_pinned(0, 0u, B, H, W, Cin, layer, out, cap);
+}
+
+extern "C" int vstab_host_layer_plan_pinned(int plan_batch, unsigned flags, int B, int H, int W, int Cin, int layer, int32_t *out, int cap)
+{
     Plan pl;
-    if (!out || layer < 0 || layer > 18 || !make_plan(B, H, W, Cin, pl))
+    PlanPin pin; pin.batch = plan_batch; pin.flags = flags;
+    if (!out || layer < 0 || layer > 18 || plan_batch < 0 || !make_plan(B, H, W, Cin, pl, &pin))
         return fail(nullptr, VSTAB_E_SHAPE, "layer_plan: bad arguments");
     const ConvParams &p = pl.cp[layer];
     const int need = 26 + 7 * p.nphase;
     if (cap < need) return fail(nullptr, VSTAB_E_NOMEM, "layer_plan: need %d ints", need);
     const int v[26] = {p.B, p.Hi, p.Wi, p.Cs_in, p.KH, p.NSEG, p.SEG, p.SEGP, p.SEG_STRIDE, p.s_in, p.s_out, p.Ho, p.Wo,
                        p.Cs_out, p.c_off, p.N, p.Npad, p.act, p.nphase, p.ksplit, p.Mmax, (int)pl.tile[layer],
-                       (int)pl.vec4[layer], LAYER_IN[layer], LAYER_OUT[layer], 0};
+                       (int)pl.vec4[layer], LAYER_IN[layer], LAYER_OUT[layer], (layer < 10 && pl.wino[layer]) ? 1 : 0};
     for (int i = 0; i < 26; ++i) out[i] = v[i];
     for (int k = 0; k < p.nphase; ++k) {
         const ConvPhase &ph = p.ph[k];
@@ -679,19 +797,6 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
 }
 
 // ------------------------------------------------------------------------- forward
-// Largest batch whose every tensor stays below 2 GiB (0 if even one sample does not fit).
-static int max_chunk(int B, int H, int W, int Cin)
-{
-    Plan pl;
-    int lo = 0, hi = B;                     // invariant: lo fits (or 0), hi+1.. do not
-    if (make_plan(B, H, W, Cin, pl)) return B;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) / 2;
-        if (make_plan(mid, H, W, Cin, pl)) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
 static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5,
                          float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_);
 static std::string conv_kernel_name(ConvTile t, bool vec4);
@@ -706,12 +811,12 @@ extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B,
     if (!feats || !pf6 || !pf5 || !pf4 || !pf3 || !pf2 || !workspace) return fail(ctx, VSTAB_E_STATE, "forward: NULL buffer");
     int eh[10], ew[10];
     if (B < 1 || !level_sizes(H, W, eh, ew)) return fail(ctx, VSTAB_E_SHAPE, "forward: unsupported problem %dx%dx%dx%d", B, H, W, Cin);
-    const int cmax = max_chunk(B, H, W, Cin);
-    if (cmax < 1) return fail(ctx, VSTAB_E_SHAPE, "forward: one %dx%dx%d sample exceeds the 2 GiB tensor limit", H, W, Cin);
+    const PlanPin pin = pin_of(ctx);
+    if (pin.batch > 0 && B > pin.batch) return fail(ctx, VSTAB_E_SHAPE, "forward: batch %d exceeds the pinned plan batch %d (vstab_set_plan_batch)", B, pin.batch);
     // samples are independent: process the batch in (equalised) chunks that keep every tensor below
-    // 2 GiB; equal chunks share one launch plan, so their results are bit-identical
-    const int nchunks = (B + cmax - 1) / cmax;
-    const int chunk = (B + nchunks - 1) / nchunks;
+    // 2 GiB; equal chunks share one launch plan, so their results are bit-identical -- and so are ragged ones under a pinned plan batch
+    const int chunk = chunk_size(pin, B, H, W, Cin);
+    if (chunk < 1) return fail(ctx, VSTAB_E_SHAPE, "forward: one %dx%dx%d sample exceeds the 2 GiB tensor limit", H, W, Cin);
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int bc = std::min(chunk, B - b0);
         const int rc = forward_chunk(ctx, feats + (size_t)b0 * H * W * Cin, bc, H, W, Cin,
@@ -727,7 +832,8 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
                          float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_)
 {
     Plan pl;
-    if (!make_plan(B, H, W, Cin, pl)) return fail(ctx, VSTAB_E_SHAPE, "forward: unsupported problem %dx%dx%dx%d", B, H, W, Cin);
+    const PlanPin pin = pin_of(ctx);
+    if (!make_plan(B, H, W, Cin, pl, &pin)) return fail(ctx, VSTAB_E_SHAPE, "forward: unsupported problem %dx%dx%dx%d", B, H, W, Cin);
     if (workspace_bytes < pl.total) return fail(ctx, VSTAB_E_NOMEM, "forward: workspace %zu < %zu bytes", workspace_bytes, pl.total);
     if (((uintptr_t)workspace & 255) != 0) return fail(ctx, VSTAB_E_ALIGN, "forward: workspace must be 256-byte aligned");
     if (((uintptr_t)feats & 15) || ((uintptr_t)pf6 & 7) || ((uintptr_t)pf5 & 7) || ((uintptr_t)pf4 & 7) ||
@@ -830,6 +936,11 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         p.wpk = dw + ctx->enc_w[i];
         p.bias = dw + ctx->enc_b[i];
         p.partial = buf(B_PARTIAL);
+        if (pl.skinny[i]) {
+            HIP_TRY(ctx, launch_conv_skinny(p, ctx->tickets, stream, EV_A(i), EV_B(i)));
+            ctx->prof_kernel[i] = "conv_skinny_kernel<1, 4>";
+            continue;
+        }
         HIP_TRY(ctx, launch_conv(p, pl.tile[i], pl.vec4[i], stream, EV_A(i), EV_B(i)));
         ctx->prof_kernel[i] = conv_kernel_name(pl.tile[i], pl.vec4[i]);
     }
@@ -863,8 +974,13 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         p.wpk = dw + ctx->dec_w[l];
         p.bias = dw + ctx->dec_b[l];
         p.partial = buf(B_PARTIAL);
-        HIP_TRY(ctx, launch_conv(p, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l)));
-        ctx->prof_kernel[10 + l] = conv_kernel_name(pl.tile[10 + l], true);
+        if (pl.skinny[10 + l]) {
+            HIP_TRY(ctx, launch_conv_skinny(p, ctx->tickets, stream, EV_A(10 + l), EV_B(10 + l)));
+            ctx->prof_kernel[10 + l] = "conv_skinny_kernel<1, 4>";
+        } else {
+            HIP_TRY(ctx, launch_conv(p, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l)));
+            ctx->prof_kernel[10 + l] = conv_kernel_name(pl.tile[10 + l], true);
+        }
         }
         const int ph = pl.eh[lvl_enc[l]], pw = pl.ew[lvl_enc[l]];          // coarser level
         if (l < 3) { const int rc = predict_head(l + 1, pfs[l], ph, pw, pfs[l + 1]); if (rc != VSTAB_OK) return rc; }
@@ -1086,6 +1202,15 @@ extern "C" int vstab_homography_warp(const float *img, int B, int Hi, int Wi, in
     if (!img || !M || !out) return fail(nullptr, VSTAB_E_STATE, "homography_warp: NULL buffer");
     if (B < 1 || Hi < 1 || Wi < 1 || C < 1 || oh < 1 || ow < 1) return fail(nullptr, VSTAB_E_SHAPE, "homography_warp: bad shape");
     HIP_TRY(nullptr, launch_homography_warp(img, B, Hi, Wi, C, M, out, oh, ow, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_transform_image(const float *img, int B, int Hi, int Wi, int C, const float *ref, const float *pM, float *out, int oh,
+                                     int ow, void *stream)
+{
+    if (!img || !ref || !pM || !out) return fail(nullptr, VSTAB_E_STATE, "transform_image: NULL buffer");
+    if (B < 1 || Hi < 1 || Wi < 1 || C < 1 || oh < 1 || ow < 1) return fail(nullptr, VSTAB_E_SHAPE, "transform_image: bad shape");
+    HIP_TRY(nullptr, launch_homography_warp(img, B, Hi, Wi, C, pM, out, oh, ow, (hipStream_t)stream, ref));
     return VSTAB_OK;
 }
 

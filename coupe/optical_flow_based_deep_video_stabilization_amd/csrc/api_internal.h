@@ -27,6 +27,9 @@ struct vstab_ctx {
     size_t pred_w[4], pred_b[4];         // predict6,5,4,3
     size_t tab_wp, tab_b, pred2_b;       // predict2 tap table as plain [200][32] rows (tap_panel.hip); the zero bias the tap-table GEMMs of predict6..3 share; predict2's bias
     vstab::UpflowW up[4];
+    int plan_batch = 0;                  // vstab_set_plan_batch: > 0 pins every arithmetic-changing plan decision to that batch's
+    unsigned plan_flags = 0;             // vstab_set_plan_flags (VSTAB_PLAN_*)
+    unsigned *tickets = nullptr;         // SKINNY_MAX_TILES ticket words of the in-launch split-K reductions (conv_skinny.hip), zero between launches
     // profiling (vstab_profile_*): event pairs per conv-like launch, one row per forward
     bool prof = false;
     std::vector<hipEvent_t> prof_ev;     // [forward][15][2]

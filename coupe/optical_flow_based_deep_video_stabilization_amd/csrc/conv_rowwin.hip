@@ -342,7 +342,7 @@ hipError_t launch_conv_rowwin(const RowWinParams &p, hipStream_t stream, hipEven
     // 512x512: R = 8, 512 workgroups, one round; B=8 1080p: R = 30, 1008 workgroups.
     q.stream_rows = 0;
     if (q.asm_loop && p.MB == 2 && p.KH == 7 && p.N == 64 && p.act >= 0 && p.act <= 2 && p.ox_base + ntx * 128 <= p.Wo &&
-        (unsigned long long)p.B * p.Ho * p.Wo * p.Cs_out * 4ull < 0x100000000ull) {
+        (unsigned long long)p.B * p.Ho * p.Wo * p.Cs_out * 4ull < 0x80000000ull) {       // its byte offsets are signed 32-bit, like the input side's
         const double F = 0.08;
         const long long cols = (long long)ntx * p.B;
         double best = (double)((cols * p.Ho + 511) / 512) * (1.0 + F);          // one tile per workgroup

@@ -384,9 +384,11 @@ hipError_t launch_pf2(const float *T, int B, int h2, int w2, const float *bias2,
 // quarter-rate reciprocal, refinement, fix-up) ten times per pixel -- it made the stand-alone glue ALU-bound (0.67 -> 0.40 of
 // 8 TB/s at 1080p).  With r = RN(1/d) from the host the same correctly rounded quotient takes five: q = x*r, then two
 // residual corrections q += (x - d*q)*r with fused multiply-adds -- the tail of the hardware's own sequence (Markstein: the last
-// correction of a quotient already within one ulp rounds correctly unless d's significand is all ones).  Checked against `/`
-// on the device for EVERY fp32 x whose quotient is a normal number (vstab_selftest_div_const, tests/test_gpu_parity.py);
-// divisors outside 1 <= d <= 2^24 or with an all-ones significand take the plain division; x = +-inf is passed through.
+// correction of a quotient already within one ulp rounds correctly unless d's significand is all ones).  A quotient that does not
+// come out as a normal number -- zero (the corrections would turn -0 into +0), a denormal (their residuals underflow), x = +-inf
+// (they make NaN) -- takes the plain division, a branch that flows never take.  Checked bit for bit against `/` on the device for
+// EVERY non-NaN fp32 x, signed zeros, denormal quotients and infinities included (vstab_selftest_div_const,
+// tests/test_gpu_parity.py); divisors outside 1 <= d <= 2^24 or with an all-ones significand take the plain division throughout.
 struct GlueParams { int h, w; float nh, dh, mx, dx, my, dy, ry, rx; float rdh, rdx, rdy; int fast; };
 __device__ __forceinline__ float div_const(float x, float d, float r, bool fast)
 {
@@ -394,7 +396,8 @@ __device__ __forceinline__ float div_const(float x, float d, float r, bool fast)
     float q = x * r;
     q = __builtin_fmaf(__builtin_fmaf(-d, q, x), r, q);
     q = __builtin_fmaf(__builtin_fmaf(-d, q, x), r, q);
-    return __builtin_isinf(x) ? x : q;                  // +-inf / d (d > 0) = +-inf; the corrections would turn it into NaN
+    if (__builtin_expect(!(fabsf(q) >= 1.17549435e-38f), 0)) q = x / d;      // zero, denormal, NaN (x = +-inf or NaN): the IEEE division itself
+    return q;
 }
 __device__ __forceinline__ float glue_pre(float t, const GlueParams &G) { return div_const(t * G.nh, G.dh, G.rdh, G.fast); }
 __device__ __forceinline__ float glue_post_x(float v, const GlueParams &G) { return div_const(v * G.mx, G.dx, G.rdx, G.fast); }
@@ -413,15 +416,15 @@ __host__ inline GlueParams glue_params(int h, int w, int oh, int ow, int net_h, 
     return G;
 }
 
-// device self-test of div_const against the IEEE division: every fp32 bit pattern x in [first, first + count) whose quotient is
-// finite and normal; counts the mismatches
+// device self-test of div_const against the IEEE division: every non-NaN fp32 bit pattern x in [first, first + count) -- zero, denormal
+// and infinite quotients included; counts the bit mismatches
 __global__ __launch_bounds__(256) void div_const_selftest_kernel(float d, float r, unsigned first, unsigned long long count, unsigned long long *bad)
 {
     unsigned long long n = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256) {
         const float x = __builtin_bit_cast(float, (unsigned)(first + i));
         const float want = x / d;
-        if (x != x || !(fabsf(want) >= 1.17549435e-38f)) continue;              // NaN numerators and denormal / zero quotients are not compared
+        if (x != x) continue;                                                    // NaN numerators: both are NaN, payloads are not compared
         const float got = div_const(x, d, r, true);
         if (__builtin_bit_cast(unsigned, got) != __builtin_bit_cast(unsigned, want)) ++n;
     }

@@ -104,9 +104,19 @@ __global__ __launch_bounds__(256) void st_meshgrid_kernel(float *__restrict__ ou
 // /(z+1e-8), floor/ceil taps, taps outside the image read an appended zero row.
 // M = refMtrx . pMtrx, row-major [B,9].
 // ---------------------------------------------------------------------------------
+// M = refMtrx . pMtrx (warp.py:48-49's tf.matmul) composed here when `ref` is given: every product and sum its own fp32 operation,
+// (r0*p0 + r1*p1) + r2*p2, like the grid products below -- no library GEMM in front of the launch
+__device__ __forceinline__ void compose3(const float *__restrict__ ref, const float *__restrict__ p, float *m)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) m[3 * i + j] = (ref[3 * i] * p[j] + ref[3 * i + 1] * p[3 + j]) + ref[3 * i + 2] * p[6 + j];
+}
+
 __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__restrict__ img, int B, int Hi, int Wi, int C,
-                                                              const float *__restrict__ M, float *__restrict__ out, int oh,
-                                                              int ow)
+                                                              const float *__restrict__ M, const float *__restrict__ ref,
+                                                              float *__restrict__ out, int oh, int ow)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)B * oh * ow) return;
@@ -115,7 +125,12 @@ __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__res
     const int oy = rem / ow, ox = rem - oy * ow;
     const float X = ow > 1 ? (float)(-1.0 + (double)ox * (2.0 / (double)(ow - 1))) : -1.0f;
     const float Y = oh > 1 ? (float)(-1.0 + (double)oy * (2.0 / (double)(oh - 1))) : -1.0f;
-    const float *m = M + (long long)n * 9;
+    float m[9];
+    if (ref) compose3(ref, M + (long long)n * 9, m);
+    else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m[k] = M[(long long)n * 9 + k];
+    }
     const float xh = (m[0] * X + m[1] * Y) + m[2];
     const float yh = (m[3] * X + m[4] * Y) + m[5];
     const float zh = (m[6] * X + m[7] * Y) + m[8];
@@ -161,7 +176,7 @@ enum { FAM_ST_THETA = 0, FAM_ST_COORDS = 1, FAM_HOMOG = 2 };
 struct __attribute__((packed, aligned(4))) rgb3 { float r, g, b; };
 // theta [B,tdim] (M [B,9] for FAM_HOMOG) or x, y [B*oh*ow]; the grid steps 2/(n-1) are divided once on the host (the same IEEE
 // quotient lin11 / homography_warp_kernel compute per pixel): fp32 for tf.linspace, fp64 for np.linspace
-struct StSrc { const float *theta; const float *x; const float *y; int tdim; float sx, sy; double dsx, dsy; };
+struct StSrc { const float *theta; const float *x; const float *y; int tdim; float sx, sy; double dsx, dsy; const float *ref; };      // ref: FAM_HOMOG's refMtrx (theta = pMtrx then) or null
 
 constexpr int ST_TW = 32, ST_TH = 16, ST_PPT = 2, ST_WW = 16, ST_WH = 4, ST_PPR = ST_TW / ST_WW;
 static_assert(ST_WH * (4 * ST_PPT) / ST_PPR == ST_TH, "tile shape");
@@ -244,6 +259,12 @@ __global__ __launch_bounds__(256) void st3_tile_kernel(const float *__restrict__
         const float *tp = S.theta + (long long)n * S.tdim;       // wave-uniform: scalar loads
 #pragma unroll
         for (int k = 0; k < 9; ++k) th[k] = k < S.tdim ? tp[k] : 1.0f;
+        if (FAM == FAM_HOMOG && S.ref) {                           // M = refMtrx . pMtrx, here instead of a GEMM launch in front
+            float pm[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) pm[k] = th[k];
+            compose3(S.ref, pm, th);
+        }
     }
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -355,7 +376,7 @@ hipError_t launch_st_interp(const float *img, int B, int H, int W, int C, const 
     const int npix = oh * ow;
     const long long total = (long long)B * npix;
     if (C == 3) {
-        const hipError_t e = launch_st3<FAM_ST_COORDS>(HBM_SLOT_ST, img, B, H, W, StSrc{nullptr, x, y, 0, 0.f, 0.f, 0., 0.}, out, oh, ow, stream);
+        const hipError_t e = launch_st3<FAM_ST_COORDS>(HBM_SLOT_ST, img, B, H, W, StSrc{nullptr, x, y, 0, 0.f, 0.f, 0., 0., nullptr}, out, oh, ow, stream);
         if (e != hipErrorNotSupported) return e;
     }
     st_interp_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, B, H, W, C, x, y, npix, out);
@@ -367,7 +388,7 @@ hipError_t launch_st_transform(const float *img, int B, int H, int W, int C, con
 {
     const long long total = (long long)B * oh * ow;
     if (C == 3) {
-        const hipError_t e = launch_st3<FAM_ST_THETA>(HBM_SLOT_ST, img, B, H, W, StSrc{theta, nullptr, nullptr, tdim, 0.f, 0.f, 0., 0.}, out, oh, ow, stream);
+        const hipError_t e = launch_st3<FAM_ST_THETA>(HBM_SLOT_ST, img, B, H, W, StSrc{theta, nullptr, nullptr, tdim, 0.f, 0.f, 0., 0., nullptr}, out, oh, ow, stream);
         if (e != hipErrorNotSupported) return e;
     }
     st_transform_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, B, H, W, C, theta, tdim, out, oh, ow);
@@ -381,14 +402,14 @@ hipError_t launch_st_meshgrid(float *out, int oh, int ow, hipStream_t stream)
 }
 
 hipError_t launch_homography_warp(const float *img, int B, int Hi, int Wi, int C, const float *M, float *out, int oh, int ow,
-                                  hipStream_t stream)
+                                  hipStream_t stream, const float *ref)
 {
     const long long total = (long long)B * oh * ow;
     if (C == 3) {
-        const hipError_t e = launch_st3<FAM_HOMOG>(HBM_SLOT_HOMOG, img, B, Hi, Wi, StSrc{M, nullptr, nullptr, 9, 0.f, 0.f, 0., 0.}, out, oh, ow, stream);
+        const hipError_t e = launch_st3<FAM_HOMOG>(HBM_SLOT_HOMOG, img, B, Hi, Wi, StSrc{M, nullptr, nullptr, 9, 0.f, 0.f, 0., 0., ref}, out, oh, ow, stream);
         if (e != hipErrorNotSupported) return e;
     }
-    homography_warp_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, B, Hi, Wi, C, M, out, oh, ow);
+    homography_warp_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(img, B, Hi, Wi, C, M, ref, out, oh, ow);
     return hipGetLastError();
 }
 

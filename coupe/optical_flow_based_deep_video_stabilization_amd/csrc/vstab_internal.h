@@ -96,7 +96,8 @@ struct ConvParams {
     ConvPhase ph[16];       // 4 transposed-conv phases, or the 16 positions of a Winograd-domain GEMM
 };
 
-enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 = 3, TILE_64x64 = 4, TILE_256x32 = 5 };
+enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 = 3, TILE_64x64 = 4, TILE_256x32 = 5,
+                TILE_SKINNY = 6 };     // conv_skinny.hip: 32/64 rows x 32 columns per workgroup, weights streamed through registers
 
 // Launch the implicit-GEMM kernel (and the split-K combine when p.ksplit > 1).
 // ev_start/ev_stop (optional) are recorded immediately around the GEMM kernel itself.
@@ -105,6 +106,20 @@ hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool combine = true);
 hipError_t conv_set_attributes();   // raises the dynamic-LDS limit once per process
 bool conv_uses_lds_dma(ConvTile tile, bool vec4);   // which instantiation launch_conv picks (for reports)
+
+// ---------------------------------------------------------------------------------
+// Few-row layers as weight streams (conv_skinny.hip): the same ConvParams (phases, K layout, packed weights, slabs), a
+// 32 x 32 tile per workgroup whose four waves split the workgroup's K slice, fragments loaded straight into registers,
+// and the split-K reduction finished inside the launch by the workgroup that draws a tile's last ticket.
+// ---------------------------------------------------------------------------------
+constexpr int SKINNY_MAX_ROWS = 64;         // GEMM rows per phase up to which a layer is a weight stream rather than a tiled GEMM (measured: profiles/README.md r04)
+constexpr int SKINNY_MAX_TILES = 4096;      // ticket words a context holds (vstab_create)
+bool conv_skinny_applicable(const ConvParams &p, bool vec4);
+long long skinny_tiles(const ConvParams &p);
+int conv_skinny_split(const ConvParams &p, int cap = 16);
+// counters: SKINNY_MAX_TILES zeroed words that are zero again when the launch has finished (needed when p.ksplit > 1)
+hipError_t launch_conv_skinny(const ConvParams &p, unsigned *counters, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                              hipEvent_t ev_stop = nullptr);
 
 // ---------------------------------------------------------------------------------
 // Row-window convolution (conv_rowwin.hip): first layer, one output-row segment of 128
@@ -224,8 +239,9 @@ hipError_t launch_st_interp(const float *img, int B, int H, int W, int C, const 
 hipError_t launch_st_transform(const float *img, int B, int H, int W, int C, const float *theta, int tdim,
                                float *out, int oh, int ow, hipStream_t stream);
 hipError_t launch_st_meshgrid(float *out, int oh, int ow, hipStream_t stream);
+// ref != null: M holds pMtrx [B,9] and the kernels compose refMtrx . pMtrx themselves (warp.py:48-49)
 hipError_t launch_homography_warp(const float *img, int B, int Hi, int Wi, int C, const float *M, float *out,
-                                  int oh, int ow, hipStream_t stream);
+                                  int oh, int ow, hipStream_t stream, const float *ref = nullptr);
 hipError_t launch_vec2mtrx(const float *p, int B, int dim, int approx, float *out, hipStream_t stream);
 
 // clip driver helpers (clip_ops.hip)

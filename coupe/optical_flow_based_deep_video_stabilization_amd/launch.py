@@ -84,6 +84,9 @@ def launch_command(script: str, argv: List[str], nproc: int, env=None, run_id: O
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"      # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", str(rank_threads(nproc)))
     env["VSTAB_SELF_LAUNCHED"] = "1"
+    # the ranks re-use the agent's rendezvous store (which bound 127.0.0.1:0) instead of a MASTER_PORT the agent would pick by
+    # bind-then-close: set it, whatever the environment or the installed torch's default says
+    env["TORCHELASTIC_USE_AGENT_STORE"] = "True"
     run_id = run_id or uuid.uuid4().hex[:12]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0", f"--rdzv-id={run_id}", "--local-addr", "127.0.0.1",
@@ -91,12 +94,25 @@ def launch_command(script: str, argv: List[str], nproc: int, env=None, run_id: O
     return cmd, env
 
 
-def _ask_for_sigterm_when_parent_dies():          # runs in the child between fork and exec
+def _resolve_prctl():
+    """libc's prctl, looked up in the PARENT: between fork and exec of a process that has threads (torch is imported) only the call
+    itself is made -- no import, no dlopen."""
     try:
         import ctypes
-        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG
+        return ctypes.CDLL(None, use_errno=True).prctl
     except Exception:
-        pass
+        return None
+
+
+_PRCTL = _resolve_prctl()
+
+
+def _ask_for_sigterm_when_parent_dies():          # runs in the child between fork and exec
+    if _PRCTL is not None:
+        try:
+            _PRCTL(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG
+        except Exception:
+            pass
 
 
 def _kill_group(proc: subprocess.Popen, sig: int):

@@ -72,7 +72,12 @@ class OriginalSizeStabiliser:
         if feats.dtype != torch.float32 or frame.dtype != torch.float32 or not feats.is_cuda or not frame.is_cuda \
                 or not feats.is_contiguous() or not frame.is_contiguous():
             raise ValueError("feats and frame must be contiguous float32 CUDA tensors")
+        if (feats.data_ptr() | frame.data_ptr()) & 15:
+            # a batch-sliced odd-sized frame: the one-call path ends in the fused glue + warp launch, which needs 16-byte rows
+            # (stabilise_originalsize falls back to two launches for such views; here the buffers are fixed, so say so up front)
+            raise ValueError("feats and frame must be 16-byte aligned (pass a contiguous copy of a batch-sliced view)")
         B, Hn, Wn, Cin = self.shape
-        _lib.check(self._fn(self.ctx._h, feats.data_ptr(), B, Hn, Wn, Cin, frame.data_ptr(), self.frame_shape[1], self.frame_shape[2],
-                            *self._tail, runtime.stream_ptr()), self.ctx._h)
+        with torch.cuda.device(self.ctx.device):          # the stream named below is this device's current stream
+            _lib.check(self._fn(self.ctx._h, feats.data_ptr(), B, Hn, Wn, Cin, frame.data_ptr(), self.frame_shape[1], self.frame_shape[2],
+                                *self._tail, runtime.stream_ptr()), self.ctx._h)
         return self.result

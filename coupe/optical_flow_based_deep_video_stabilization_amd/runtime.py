@@ -54,6 +54,22 @@ class Context:
         _lib.check(_lib.lib().vstab_create(C.byref(self._h), device))
         self.cin: Optional[int] = None
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self.plan_batch = 0
+        self.plan_flags = 0
+
+    def set_plan_batch(self, batch: int):
+        """Pin every plan decision that changes the order of a sample's sums (split-K factors, Winograd or direct form,
+        weight-stream or tiled kernel) to what a batch of `batch` samples gets: any call with B <= batch then gives each sample
+        bit-identical results whatever it is batched with (ragged tails of a sharded clip).  0 unpins."""
+        _lib.check(_lib.lib().vstab_set_plan_batch(self._h, int(batch)), self._h)
+        self.plan_batch = int(batch)
+        self._ws.clear()
+
+    def set_plan_flags(self, flags: int):
+        """VSTAB_PLAN_* bits (1 = few-row layers stay on the tiled kernel + split-K combine launch: A/B runs and tests)."""
+        _lib.check(_lib.lib().vstab_set_plan_flags(self._h, int(flags)), self._h)
+        self.plan_flags = int(flags)
+        self._ws.clear()
 
     def close(self):
         if self._h:
@@ -82,10 +98,12 @@ class Context:
         self.cin = int(w["1/W_conv2d"].shape[2])
 
     def workspace(self, B, H, W, Cin) -> torch.Tensor:
+        if 0 < B <= self.plan_batch:
+            B = self.plan_batch            # one workspace for every batch of a pinned context (it suffices for all of them)
         key = (B, H, W, Cin)
         ws = self._ws.get(key)
         if ws is None:
-            n = _lib.lib().vstab_workspace_bytes(B, H, W, Cin)
+            n = _lib.lib().vstab_workspace_bytes_ctx(self._h, B, H, W, Cin)
             if n == 0:
                 raise ValueError(f"vstab: unsupported problem size {key}: "
                                  f"{_lib.lib().vstab_last_error(None).decode()}")

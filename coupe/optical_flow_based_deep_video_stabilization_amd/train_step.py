@@ -172,6 +172,32 @@ class Trainer:
     def _check(self, rc):
         _lib.check(rc)
 
+    # ---- per-call timing of the MFMA-bound calls (bench_train.py's roofline): an event pair on the stream the library launches on
+    # (torch's current stream, handed over as self.st) around every conv-family C call, with the flops of the layer it computes
+    calls = None
+
+    def profile_calls(self, on: bool):
+        self.calls = [] if on else None
+
+    def _timed(self, kind, flops, fn):
+        if self.calls is None:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.calls.append((kind, float(flops), a, b))
+        return r
+
+    def profile_read(self):
+        """{family: (ms summed, flops summed, calls)} of the calls recorded since profile_calls(True); synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for kind, fl, a, b in self.calls or []:
+            ms, f, n = out.get(kind, (0.0, 0.0, 0))
+            out[kind] = (ms + a.elapsed_time(b), f + fl, n + 1)
+        return out
+
     def _conv_fwd(self, x, cx_off, cin, W, b, k, s, p, y, cy_off, cout, act=0):
         B, Hi, Wi, cs_x = x.shape
         cs_y = y.shape[3]
@@ -180,8 +206,9 @@ class Trainer:
         if n == 0:
             raise ValueError("conv_forward: unsupported geometry")
         ws = self._workspace(n)
-        self._check(self.L.vstab_conv_forward(x.data_ptr(), B, Hi, Wi, cs_x, cx_off, cin, W.data_ptr(), b.data_ptr() if b is not None else None,
-                                              k, s, p, y.data_ptr(), Ho, Wo, cs_y, cy_off, cout, act, ws.data_ptr(), ws.numel(), self.st))
+        self._timed("conv_forward", 2.0 * B * Ho * Wo * k * k * cin * cout, lambda: self._check(self.L.vstab_conv_forward(
+            x.data_ptr(), B, Hi, Wi, cs_x, cx_off, cin, W.data_ptr(), b.data_ptr() if b is not None else None,
+            k, s, p, y.data_ptr(), Ho, Wo, cs_y, cy_off, cout, act, ws.data_ptr(), ws.numel(), self.st)))
 
     def _convT(self, g, cg_off, cout, W, b, k, s, p, dx, cx_off, cin, accumulate):
         """dx (+)= transposed conv of g with W [k,k,cin,cout] (conv input gradient; also DeConv2dLayer's forward)."""
@@ -191,9 +218,9 @@ class Trainer:
         if n == 0:
             raise ValueError("conv_dgrad: unsupported geometry")
         ws = self._workspace(n)
-        self._check(self.L.vstab_conv_dgrad(g.data_ptr(), B, Ho, Wo, cs_g, cg_off, cout, W.data_ptr(), b.data_ptr() if b is not None else None,
-                                            k, s, p, dx.data_ptr(), Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0, ws.data_ptr(),
-                                            ws.numel(), self.st))
+        self._timed("conv_dgrad", 2.0 * B * Ho * Wo * k * k * cin * cout, lambda: self._check(self.L.vstab_conv_dgrad(
+            g.data_ptr(), B, Ho, Wo, cs_g, cg_off, cout, W.data_ptr(), b.data_ptr() if b is not None else None,
+            k, s, p, dx.data_ptr(), Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0, ws.data_ptr(), ws.numel(), self.st)))
 
     def _wino(self, x, cx_off, W, transpose, bias, y, cy_off, act):
         """3x3 stride-1 stage (or its input gradient) in Winograd F(2x2,3x3) form; False when the geometry does not qualify."""
@@ -206,9 +233,10 @@ class Trainer:
         if n == 0:
             return False
         ws = self._workspace(n)
-        self._check(self.L.vstab_conv3x3_winograd(x.data_ptr(), B, H, Wd, cs_x, cx_off, W.data_ptr(), cin, cout, 1 if transpose else 0,
-                                                  bias.data_ptr() if bias is not None else None, y.data_ptr(), y.shape[3], cy_off, act,
-                                                  ws.data_ptr(), ws.numel(), self.st))
+        # flops as the direct 3x3 convolution SURVEY.md 8d prices (the Winograd form issues 4/9 of them)
+        self._timed("conv3x3_winograd", 2.0 * B * H * Wd * 9 * cin * cout, lambda: self._check(self.L.vstab_conv3x3_winograd(
+            x.data_ptr(), B, H, Wd, cs_x, cx_off, W.data_ptr(), cin, cout, 1 if transpose else 0,
+            bias.data_ptr() if bias is not None else None, y.data_ptr(), y.shape[3], cy_off, act, ws.data_ptr(), ws.numel(), self.st)))
         return True
 
     def _wgrad(self, x, cx_off, cin, g, cg_off, cout, k, s, p, dW, db):
@@ -216,8 +244,9 @@ class Trainer:
         _, Ho, Wo, cs_g = g.shape
         n = self.L.vstab_conv_wgrad_workspace_bytes(B, Ho, Wo, k, cin, cout)
         ws = self._workspace(n)
-        self._check(self.L.vstab_conv_wgrad(x.data_ptr(), B, Hi, Wi, cs_x, cx_off, cin, g.data_ptr(), Ho, Wo, cs_g, cg_off, cout, k, s, p,
-                                            dW.data_ptr(), db.data_ptr() if db is not None else None, 0, ws.data_ptr(), ws.numel(), self.st))
+        self._timed("conv_wgrad", 2.0 * B * Ho * Wo * k * k * cin * cout, lambda: self._check(self.L.vstab_conv_wgrad(
+            x.data_ptr(), B, Hi, Wi, cs_x, cx_off, cin, g.data_ptr(), Ho, Wo, cs_g, cg_off, cout, k, s, p,
+            dW.data_ptr(), db.data_ptr() if db is not None else None, 0, ws.data_ptr(), ws.numel(), self.st)))
 
     def _colsum(self, g, c_off, C, out):
         rows = g.shape[0] * g.shape[1] * g.shape[2]
@@ -250,8 +279,8 @@ class Trainer:
         if n == 0:
             return False
         ws = self._workspace(n)
-        self._check(self.L.vstab_conv3x3_winograd_wgrad(x.data_ptr(), B, H, Wd, cs_x, cx_off, cin, G.data_ptr(), G.shape[3], cg_off, cout,
-                                                        dW.data_ptr(), ws.data_ptr(), ws.numel(), self.st))
+        self._timed("conv3x3_winograd_wgrad", 2.0 * B * H * Wd * 9 * cin * cout, lambda: self._check(self.L.vstab_conv3x3_winograd_wgrad(
+            x.data_ptr(), B, H, Wd, cs_x, cx_off, cin, G.data_ptr(), G.shape[3], cg_off, cout, dW.data_ptr(), ws.data_ptr(), ws.numel(), self.st)))
         return True
 
     def _resize(self, x, out):

@@ -61,7 +61,9 @@ def vec2mtrx(config, p):
     return out
 
 
-def _warp(image, M, oh, ow):
+def warpImage(image, M, oh, ow):
+    """The warp of transformImage given the composed matrices M = refMtrx . pMtrx [B,3,3] (not a reference symbol: the reference
+    composes inside transformImage, as `transformImage` below does inside its launch)."""
     image = _f32_cuda(image, "image")
     B, Hi, Wi, Cc = image.shape
     M = _f32_cuda(M, "matrix").reshape(B, 9)
@@ -72,17 +74,25 @@ def _warp(image, M, oh, ow):
     return out
 
 
+def _warp_ref(image, ref, pMtrx, oh, ow):
+    """refMtrx . pMtrx (warp.py:48-49, 91-92: a tf.matmul in the reference) is composed inside the warp launch -- every product and
+    sum rounded to fp32 -- not by a library GEMM in front of it."""
+    image = _f32_cuda(image, "image")
+    B, Hi, Wi, Cc = image.shape
+    pM = _f32_cuda(pMtrx, "pMtrx").to(image.device).reshape(B, 9)
+    ref = _f32_cuda(ref, "refMtrx").to(image.device).reshape(9)
+    out = torch.empty((B, oh, ow, Cc), dtype=torch.float32, device=image.device)
+    with torch.cuda.device(image.device):
+        _lib.check(_lib.lib().vstab_transform_image(image.data_ptr(), B, Hi, Wi, Cc, ref.data_ptr(), pM.data_ptr(), out.data_ptr(),
+                                                    oh, ow, runtime.stream_ptr()))
+    return out
+
+
 def transformImage(config, image, pMtrx):
     """image [B,H,W,3] warped by refMtrx . pMtrx on the canonical [-1,1]^2 grid (warp.py:46-86)."""
-    pM = _f32_cuda(pMtrx, "pMtrx")
-    ref = _f32_cuda(config.refMtrx, "refMtrx").to(pM.device)
-    M = torch.matmul(ref.unsqueeze(0).expand(pM.shape[0], 3, 3), pM)
-    return _warp(image, M, int(config.height), int(config.width))
+    return _warp_ref(image, config.refMtrx, pMtrx, int(config.height), int(config.width))
 
 
 def transformCropImage(config, image, pMtrx):
     """As transformImage with refMtrx_b, source [B,dataH,dataW,3], output height x W (warp.py:89-129)."""
-    pM = _f32_cuda(pMtrx, "pMtrx")
-    ref = _f32_cuda(config.refMtrx_b, "refMtrx_b").to(pM.device)
-    M = torch.matmul(ref.unsqueeze(0).expand(pM.shape[0], 3, 3), pM)
-    return _warp(image, M, int(config.height), int(config.W))
+    return _warp_ref(image, config.refMtrx_b, pMtrx, int(config.height), int(config.W))

@@ -87,6 +87,19 @@ VSTAB_API int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *tensors, in
  * chunks of the largest batch that fits, and the workspace is sized for one chunk. */
 VSTAB_API size_t vstab_workspace_bytes(int B, int H, int W, int Cin);
 
+/* ---- pinned launch plans.  The forward takes a few per-layer decisions that change the ORDER of a sample's floating-point sums:
+ * split-K factors, Winograd or direct form of the 3x3 stride-1 stages, weight-stream or tiled kernel for few-row layers.  By default
+ * they are taken for the batch of each call, so the same sample can come out a few ulp different when it is batched differently (a
+ * ragged last micro-batch of a sharded clip: main:553-558's samples are independent).  vstab_set_plan_batch(ctx, P)
+ * pins them to what a batch of P samples gets: every call with B <= P then gives each sample bit-identical results, whatever B is
+ * (B > P is VSTAB_E_SHAPE).  P = 0 (default) unpins.  The workspace of a pinned context is sized by vstab_workspace_bytes_ctx
+ * (a workspace sized for P itself always suffices).  Flags: VSTAB_PLAN_NO_SKINNY keeps few-row layers on the tiled kernel with a
+ * split-K combine launch (the round-3 schedule; A/B measurements and tests). */
+#define VSTAB_PLAN_NO_SKINNY 1u
+VSTAB_API int vstab_set_plan_batch(vstab_ctx *ctx, int batch);
+VSTAB_API int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags);
+VSTAB_API size_t vstab_workspace_bytes_ctx(const vstab_ctx *ctx, int B, int H, int W, int Cin);
+
 /* Names/offsets of the intermediate tensors inside the workspace.  Returns the number
  * of entries written (<= max_entries) or a negative error. */
 VSTAB_API int vstab_workspace_layout(int B, int H, int W, int Cin, vstab_ws_entry *entries, int max_entries);
@@ -125,8 +138,9 @@ VSTAB_API int vstab_flow_resize_scale(const float *flow, int B, int h, int w, fl
                             int net_h, int net_w, void *stream);
 
 /* ---- device self-test of the glue's division by a launch constant (five fused operations on a host-side reciprocal instead
- * of a run-time IEEE division): compares it with `x / d` for the `count` fp32 bit patterns x starting at `first_bits` whose
- * quotient is finite and normal, and ADDS the number of mismatches to *bad_count_dev (device memory, 8-byte aligned).
+ * of a run-time IEEE division; quotients that do not come out normal -- signed zeros, denormals, infinities -- take the division
+ * itself): compares it BIT FOR BIT with `x / d` for the `count` fp32 bit patterns x starting at `first_bits` (NaN numerators
+ * skipped), and ADDS the number of mismatches to *bad_count_dev (device memory, 8-byte aligned).
  * VSTAB_E_SHAPE for a divisor the glue would divide plainly (outside [1, 2^24], or an all-ones significand). */
 VSTAB_API int vstab_selftest_div_const(float d, unsigned first_bits, unsigned long long count, unsigned long long *bad_count_dev,
                                        void *stream);
@@ -200,6 +214,10 @@ VSTAB_API int vstab_st_meshgrid(float *out, int oh, int ow, void *stream);
  * linspace(-1,1) grid of the OUTPUT size to source pixel coordinates; floor/ceil taps, zero outside. */
 VSTAB_API int vstab_homography_warp(const float *img, int B, int Hi, int Wi, int C, const float *M, float *out, int oh,
                                     int ow, void *stream);
+/* The same with the composition warp.py:48-49 makes in front of it (tf.matmul(refMtrx, pMtrx)) done by the kernel: ref [9] (device,
+ * one matrix for the batch), pM [B,9]; M = ref . pM with every product and sum rounded to fp32, (r0*p0 + r1*p1) + r2*p2. */
+VSTAB_API int vstab_transform_image(const float *img, int B, int Hi, int Wi, int C, const float *ref, const float *pM, float *out,
+                                    int oh, int ow, void *stream);
 /* warp.vec2mtrx (warp.py:25-43): p [B,8] (homography, sl(3) generator) or [B,6] (affine) -> [B,9]
  * Taylor matrix exponential with `warp_approx` terms. */
 VSTAB_API int vstab_vec2mtrx(const float *p, int B, int dim, int warp_approx, float *out, void *stream);
@@ -414,6 +432,9 @@ VSTAB_API int vstab_level_sizes(int H, int W, int32_t *hw20);
  *   Hg Wg M off_y off_x o_y o_x
  * (buffers index vstab_workspace_layout entries, -1 = feats).  Returns ints written. */
 VSTAB_API int vstab_host_layer_plan(int B, int H, int W, int Cin, int layer, int32_t *out, int cap);
+/* the same under a pinned plan batch / plan flags (vstab_set_plan_batch, vstab_set_plan_flags); `reserved` = 1 when the stage runs in
+ * Winograd form; tile 6 = the weight-stream kernel of few-row layers (conv_skinny.hip: 32- or 64-row x 32-column workgroups) */
+VSTAB_API int vstab_host_layer_plan_pinned(int plan_batch, unsigned flags, int B, int H, int W, int Cin, int layer, int32_t *out, int cap);
 
 /* Host-side weight packing exactly as vstab_load_weights does it for `layer` of a
  * Cin-channel network: W is the reference-layout tensor, scale (may be NULL = ones) the

@@ -431,6 +431,16 @@ def warp_vec2mtrx(p, warp_type: str, warp_approx: int):
     return pM
 
 
+def warp_compose(ref, pM):
+    """refMtrx . pMtrx of warp.py:48-49 / 91-92 (tf.matmul(refMtrx, pMtrx)) in fp32 with every product and sum rounded,
+    (r0*p0 + r1*p1) + r2*p2 -- TF does not specify the rounding sequence of its 3-term dot products; this is the one the HIP
+    kernels use.  ref [3,3], pM [B,3,3] -> [B,3,3]."""
+    ref = _t(ref, torch.float32).reshape(3, 3)
+    pM = _t(pM, torch.float32).reshape(-1, 3, 3)
+    r = ref.unsqueeze(0)
+    return (r[:, :, 0:1] * pM[:, 0:1, :] + r[:, :, 1:2] * pM[:, 1:2, :]) + r[:, :, 2:3] * pM[:, 2:3, :]
+
+
 def warp_transform_image(image, M, oh: int, ow: int, dtype=torch.float32, matmul="blas"):
     """warp.transformImage / transformCropImage (warp.py:46-86, 89-129) given M = refMtrx . pMtrx [B,3,3];
     image [B,Hi,Wi,C] -> [B,oh,ow,C].  `matmul` as in st_transform (warp.py:55, 98 are tf.matmul too)."""

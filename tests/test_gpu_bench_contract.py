@@ -78,3 +78,17 @@ def test_bench_clip_two_ranks_ragged_rehearsal():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gathered_bytes"] == 9 * 128 * 160 * 3
+
+
+@pytest.mark.parametrize("ranks,frames,mb", [(2, 11, 4), (3, 13, 4)])
+def test_sharded_clip_is_bit_equal_to_the_unsharded_one(ranks, frames, mb):
+    """SURVEY.md 4.4's multi-GPU test: an N-way sharded run, ragged tails included, reassembled over the process group, equals the
+    one-rank run bit for bit.  Self-launched gloo ranks sharing this box's GPU (the HIP kernels compute, host memory reassembles):
+    11 frames on 2 ranks = shards of 6 and 5 in micro-batches of 4 + 2 / 4 + 1; 13 frames on 3 ranks = 5 + 4 + 4.  The launch plan is
+    pinned to the micro-batch (vstab_set_plan_batch), so a frame's bits do not depend on its micro-batch's size; bench_clip.py --check
+    computes the unsharded sequence on rank 0 (micro-batches of 4 from frame 0) and compares."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_clip.py"), "--gpus", str(ranks), "--backend", "gloo", "--frames", str(frames),
+                        "--height", "256", "--width", "256", "--micro-batch", str(mb), "--check"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == ranks and d["plan_batch"] == mb and d["sharded_equals_unsharded"] is True

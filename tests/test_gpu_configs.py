@@ -95,6 +95,7 @@ def test_cfg3_sharded_clip_gather_world1_nccl(nccl_world1):
     F_, H, W, cin, MB = 10, 1080, 1920, 27, 4           # ragged: micro-batches of 4, 4, 2
     runtime.reset()
     vs.initialize_global_variables(seed=1, cin=cin)
+    runtime.get_context().set_plan_batch(MB)             # as bench_clip.py does
     g = torch.Generator(device="cuda").manual_seed(7)
     feats = torch.rand(F_, H, W, cin, generator=g, device="cuda")
     frame = torch.rand(F_, H, W, 3, generator=g, device="cuda")
@@ -106,15 +107,19 @@ def test_cfg3_sharded_clip_gather_world1_nccl(nccl_world1):
     torch.cuda.synchronize()
     assert full.dtype == torch.uint8 and tuple(full.shape) == (F_, H, W, 3)
     assert torch.equal(full, whole)
-    # what two ranks would each compute -- their shard_range blocks of the first 8 frames, i.e. one micro-batch of 4 each, the same
-    # batch composition as the unsharded run -- reassembled in rank order is bit for bit the same sequence (a different composition
-    # changes split-K plans, hence fp32 association, hence -- through tf_warp's truncating corners -- whole pixels: not compared)
-    parts = []
-    for r in range(2):
-        a, b = vdist.shard_range(8, r, 2)
-        assert b - a == MB
-        parts.append(_stabilise_u8(feats[a:b], frame[a:b], MB))
-    assert torch.equal(torch.cat(parts), whole[:8])
+    # what two and three ranks would each compute -- their shard_range blocks of the clip: 5 + 5 frames (micro-batches 4 + 1) and
+    # 4 + 3 + 3, none of them batched as in the unsharded run (4 + 4 + 2) -- reassembled in rank order is bit for bit the same
+    # sequence, uint8 frames and fp32 flows alike: the launch plan is pinned to the micro-batch (vstab_set_plan_batch), so split-K
+    # factors, Winograd or direct form and the kernel family do not depend on what a frame is batched with
+    for world in (2, 3):
+        parts = []
+        for r in range(world):
+            a, b = vdist.shard_range(F_, r, world)
+            parts.append(_stabilise_u8(feats[a:b], frame[a:b], MB))
+        assert torch.equal(torch.cat(parts), whole), world
+    pf_whole = torch.cat([vs.flownetS_pyramid(feats[b0:b0 + MB].contiguous(), min(MB, F_ - b0))["predict_flow2"] for b0 in range(0, F_, MB)])
+    pf_ragged = torch.cat([vs.flownetS_pyramid(feats[b0:b0 + 3].contiguous(), min(3, F_ - b0))["predict_flow2"] for b0 in range(0, F_, 3)])
+    assert torch.equal(pf_whole, pf_ragged)
     # overlapped reassembly (what bench_clip.py does): every micro-batch all-gathered into its place of the full clip as it finishes
     sg = vdist.SequenceGatherer(F_, (H, W, 3), torch.uint8, torch.device("cuda", 0))
     assert sg.common == F_

@@ -58,16 +58,23 @@ def test_cfg2_batch32_720p_chunked():
     _run_case(32, 720, 1280, 27, torch.float32)
 
 
-def test_unequal_chunks_agree_to_rounding():
-    # 23 samples at 720p -> chunks of 12 and 11 whose split-K plans may differ: same values up to
-    # fp32 summation order, far inside the flow tolerance
+def test_unequal_chunks_are_bit_equal_under_a_pinned_plan():
+    # 23 samples at 720p -> chunks of 12 and 11.  Unpinned, their split-K plans may differ (same values up to fp32 summation order,
+    # far inside the flow tolerance); with the plan pinned to the batch (vstab_set_plan_batch) both chunks take the decisions of a
+    # chunk of 12 and every copy of the sample comes out with the same bits
     w = wts.synthetic_weights(seed=1, cin=27, random_bn=False)
     runtime.reset()
     vs.assign_weights(w)
     one = torch.rand(1, 720, 1280, 27, device="cuda")
     feats = one.expand(23, -1, -1, -1).contiguous()
     pf2 = vs.flownetS_pyramid(feats, 23)["predict_flow2"]
-    assert float((pf2 - pf2[:1]).abs().max()) <= 5e-4          # half the 1e-3 flow tolerance
+    assert float((pf2 - pf2[:1]).abs().max()) <= 5e-4          # unpinned: half the 1e-3 flow tolerance
+    runtime.get_context().set_plan_batch(23)
+    pf2 = vs.flownetS_pyramid(feats, 23)["predict_flow2"]
+    assert torch.equal(pf2, pf2[:1].expand_as(pf2))
+    lone = vs.flownetS_pyramid(one, 1)["predict_flow2"]         # and a lone sample under the same pin
+    assert torch.equal(lone, pf2[:1])
+    runtime.reset()
 
 
 def test_cfg3_1080p_samples():

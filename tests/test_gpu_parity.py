@@ -95,8 +95,9 @@ def test_fused_glue_warp_bit_identical(B, hn, wn, oh, ow):
 def test_glue_division_by_launch_constants_is_the_ieee_quotient():
     # The glue divides by three constants of the launch (main:497-498: /382, /512, /384).  The kernels do it with five fused
     # operations on a host-side reciprocal instead of the ~11-instruction run-time division; this compares the two ON THE DEVICE:
-    # for the divisors of the reference's and BASELINE's sizes over EVERY fp32 bit pattern (2^32 numerators each), for every
-    # integer divisor up to 4096 over a stride through the patterns, and checks which divisors take the plain division.
+    # for the divisors of the reference's and BASELINE's sizes over EVERY fp32 bit pattern (2^32 numerators each: -0.0, denormal
+    # quotients and infinities are compared bit for bit too, only NaN numerators are skipped), for every integer divisor up to 4096
+    # over a stride through the patterns, and checks which divisors take the plain division.
     import ctypes as C
     L = _lib.lib()
     bad = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -111,6 +112,11 @@ def test_glue_division_by_launch_constants_is_the_ieee_quotient():
     assert int(bad.item()) == 0
     for d in (0.5, 16777215.0, float(1 << 25), float("nan")):          # < 1, all-ones significand, > 2^24: plain division there
         assert L.vstab_selftest_div_const(C.c_float(d), 0, 16, bad.data_ptr(), st) == -1
+    # the zero / denormal corner explicitly: the 2^24 patterns around +0 and around -0 (every denormal and the smallest normals)
+    for first in (0, 0x80000000):
+        _lib.check(L.vstab_selftest_div_const(C.c_float(382.0), first, 1 << 24, bad.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
     # and through the glue itself on values that once told the single-multiply form apart (tests/test_oracle_kat.py)
     pf2 = torch.linspace(-40.0, 40.0, 382 * 4).view(1, 382, 4, 1).repeat(1, 1, 1, 2).contiguous()
     assert torch.equal(vs.flow_to_output_res(pf2.cuda(), 384, 512, 382, 4).cpu(), vo.flow_to_output_res(pf2, 384, 512, 382, 4))
@@ -144,6 +150,15 @@ def test_one_call_stabiliser_bit_identical_and_reuses_its_buffers():
             stab(feats, frame.double())
     with pytest.raises(ValueError):
         vs.OriginalSizeStabiliser(1, 64, 64, 6, 64, 64)          # weights are for 27 channels
+    # a batch-sliced view of odd-sized frames is contiguous but not 16-byte aligned: refused BEFORE the network runs (the one-call path
+    # ends in the fused glue + warp launch; stabilise_originalsize takes the two-launch path for such a view)
+    big = torch.rand(3, 37, 53, 3, generator=g).cuda()
+    fe = torch.rand(2, 64, 96, 27, generator=g).cuda()
+    odd = vs.OriginalSizeStabiliser(2, 64, 96, 27, 37, 53)
+    assert big[1:].data_ptr() % 16 != 0 and big[1:].is_contiguous()
+    with pytest.raises(ValueError, match="16-byte"):
+        odd(fe, big[1:])
+    assert torch.equal(odd(fe, big[1:].clone())[2], vs.stabilise_originalsize(fe, big[1:])[2])
 
 
 def test_batch_sliced_odd_frame_takes_the_two_launch_path():

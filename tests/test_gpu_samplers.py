@@ -80,8 +80,11 @@ def test_transform_image_and_crop():
     p = (torch.rand(B, 8, generator=g) - 0.5) * 0.2
     pM = vwarp.vec2mtrx(cfg, p.cuda())
     out = vwarp.transformImage(cfg, im.cuda(), pM)
-    M = torch.matmul(torch.from_numpy(ref_m).unsqueeze(0).expand(B, 3, 3), pM.cpu())
+    M = vo.warp_compose(ref_m, pM.cpu())
+    assert float((M - torch.matmul(torch.from_numpy(ref_m).unsqueeze(0).expand(B, 3, 3), pM.cpu())).abs().max()) <= 1e-5      # a library GEMM's rounding
     assert maxabs(out, vo.warp_transform_image(im, M, H, W)) <= 2e-5
+    # the composed matrix given directly (vstab_homography_warp) = the composition made inside the launch (vstab_transform_image)
+    assert torch.equal(vwarp.warpImage(im.cuda(), M.cuda(), H, W), out)
     # identity parameters reproduce the image (pixel centres hit exactly up to rounding)
     ident = vwarp.transformImage(cfg, im.cuda(), torch.eye(3).repeat(B, 1, 1).cuda())
     assert maxabs(ident, im) <= 1e-4
@@ -172,7 +175,7 @@ def test_transform_image_tiled_bit_exact():
         p = (torch.rand(B, 8, generator=g) - 0.5) * 0.2
         pM = vwarp.vec2mtrx(cfg, p.cuda())
         out = vwarp.transformImage(cfg, im.cuda(), pM)
-        M = torch.matmul(ref_m.unsqueeze(0).expand(B, 3, 3).cuda(), pM).cpu()
+        M = vo.warp_compose(ref_m, pM.cpu())          # refMtrx . pMtrx as the kernel composes it: no GEMM launch, every product and sum rounded
         assert torch.equal(out.cpu(), vo.warp_transform_image(im, M, oh, ow, matmul="unfused"))
         # integer sample points (floor == ceil): identity at the source size
         cfg_i = _cfg(warpType="homography", warpApprox=20, batch_size=B, height=H, width=W, refMtrx=ref_m)
@@ -221,5 +224,5 @@ def test_cfg2_batch32_720p_transform_image():
     assert out.shape == (32, H, W, 3) and torch.isfinite(out).all()
     for i in range(32):
         assert torch.equal(out[i], out[int(pattern[i])]), i
-    M = torch.matmul(ref_m.unsqueeze(0).cuda(), pM[:1]).cpu()
+    M = vo.warp_compose(ref_m, pM[:1].cpu())
     assert torch.equal(out[:1].cpu(), vo.warp_transform_image(two[:1], M, H, W, matmul="unfused"))

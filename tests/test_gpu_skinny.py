@@ -1,0 +1,108 @@
+"""GPU tests of the round-4 one-sample path: few-row layers as weight streams with the split-K reduction finished inside the launch
+(csrc/conv_skinny.hip; model.py:838-852 at main:568-569's one sess.run per frame), and pinned plan batches (vstab_set_plan_batch:
+a sample's bits do not depend on what it is batched with; SURVEY.md 8e, main:553-558)."""
+import numpy as np
+import pytest
+import torch
+
+import coupe.optical_flow_based_deep_video_stabilization_amd as vs
+from coupe.optical_flow_based_deep_video_stabilization_amd import _lib, runtime, weights as wts
+from oracle import vstab_oracle as vo
+
+pytestmark = pytest.mark.gpu
+KEYS = ("predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3", "predict_flow2")
+NO_SKINNY = 1
+
+
+@pytest.fixture
+def ctx():
+    runtime.reset()
+    vs.assign_weights(wts.synthetic_weights(seed=1, cin=27, random_bn=True, flow_gain=2.0))
+    c = runtime.get_context()
+    yield c
+    runtime.reset()
+
+
+def layer_tiles(B, H, W, flags=0, plan_batch=0):
+    import ctypes
+    out = (ctypes.c_int32 * 200)()
+    tiles = []
+    for layer in range(19):
+        n = _lib.lib().vstab_host_layer_plan_pinned(plan_batch, flags, B, H, W, 27, layer, out, 200)
+        assert n > 0
+        tiles.append((out[21], out[19], out[25]))          # tile id, split-K factor, Winograd form
+    return tiles
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (1, 384, 512), (2, 96, 128), (1, 200, 264), (3, 64, 64), (4, 128, 128)])
+def test_weight_stream_layers_match_the_tiled_form_and_the_oracle(ctx, B, H, W):
+    # same layers through the two kernels: different association of the same sums -> equal up to fp32 rounding, far inside the
+    # flow budget; and the default (weight-stream) path against the fp64 restatement, every level
+    assert any(t[0] == 6 for t in layer_tiles(B, H, W)), "this shape should have weight-stream layers"
+    assert not any(t[0] == 6 for t in layer_tiles(B, H, W, NO_SKINNY))
+    g = torch.Generator().manual_seed(H * 7 + W)
+    feats = torch.rand(B, H, W, 27, generator=g)
+    a = vs.flownetS_pyramid(feats.cuda(), B)
+    ia = {k: v.clone() for k, v in ctx.internals(B, H, W, 27).items() if k in ("conv5", "concat5", "conv6", "conv6_1", "concat4")}
+    a = {k: a[k].clone() for k in KEYS}
+    ctx.set_plan_flags(NO_SKINNY)
+    b = vs.flownetS_pyramid(feats.cuda(), B)
+    ib = {k: v.clone() for k, v in ctx.internals(B, H, W, 27).items() if k in ia}
+    ctx.set_plan_flags(0)
+    for k in ia:
+        scale = max(1.0, float(ib[k].abs().max()))
+        assert float((ia[k] - ib[k]).abs().max()) <= 2e-5 * scale, k
+    ref = vo.flownetS_pyramid(feats.numpy(), wts.synthetic_weights(seed=1, cin=27, random_bn=True, flow_gain=2.0), torch.float64)
+    for k in KEYS:
+        assert float((a[k] - b[k]).abs().max()) <= 5e-4, k       # flows of up to ~200 px: a few ulp of the 8x upsampled predict_flow3
+        assert float((a[k].double().cpu() - ref[k]).abs().max()) <= 1e-3, k
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (384, 512)])
+def test_in_launch_split_k_reduction_is_reproducible_under_load(ctx, H, W):
+    # the last arriver of a tile must read every slab as its writers left it (agent-scope hand-off: cdna_hip_programming.md G16).
+    # Two different inputs alternate through the SAME slab and ticket memory, forty forwards back to back with no host waits in
+    # between: a stale slab line (L1 of the reducer's CU, a not-yet-written-through store) shows as a result that is not
+    # bit-identical to the first one of its input.
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.rand(1, H, W, 27, generator=g).cuda() for _ in range(2)]
+    first = [None, None]
+    outs = []
+    for it in range(40):
+        r = vs.flownetS_pyramid(xs[it & 1], 1)
+        outs.append((it & 1, {k: r[k].clone() for k in KEYS}))
+    torch.cuda.synchronize()
+    for which, r in outs:
+        if first[which] is None:
+            first[which] = r
+            continue
+        for k in KEYS:
+            assert torch.equal(r[k], first[which][k]), k
+    assert not torch.equal(first[0]["predict_flow2"], first[1]["predict_flow2"])
+    # and the ticket words are zero again (the library's invariant between launches): one more forward still agrees
+    r = vs.flownetS_pyramid(xs[0], 1)
+    assert torch.equal(r["predict_flow2"], first[0]["predict_flow2"])
+
+
+@pytest.mark.parametrize("P,H,W", [(8, 256, 256), (8, 512, 512), (5, 136, 200)])
+def test_pinned_plan_batch_makes_a_sample_independent_of_its_batch(ctx, P, H, W):
+    # split-K factors, Winograd or direct form and the kernel family are functions of the batch; pinned to the plan of P samples
+    # every smaller batch reproduces its samples bit for bit (what a ragged last micro-batch of a sharded clip needs)
+    g = torch.Generator().manual_seed(P * 31 + H)
+    feats = torch.rand(P, H, W, 27, generator=g).cuda()
+    unpinned = {b: layer_tiles(b, H, W) for b in (1, P)}
+    if H >= 256:
+        assert unpinned[1] != unpinned[P], "the shapes of this test should plan a lone sample differently"
+    ctx.set_plan_batch(P)
+    whole = vs.flownetS_pyramid(feats, P)
+    whole = {k: whole[k].clone() for k in KEYS}
+    for lo, hi in ((0, 1), (P - 1, P), (1, 4), (2, P), (0, P - 1)):
+        part = vs.flownetS_pyramid(feats[lo:hi].contiguous(), hi - lo)
+        for k in KEYS:
+            assert torch.equal(part[k], whole[k][lo:hi]), (k, lo, hi)
+    with pytest.raises(Exception):
+        vs.flownetS_pyramid(torch.cat([feats, feats[:1]]), P + 1)        # beyond the pinned batch
+    ctx.set_plan_batch(0)
+    again = vs.flownetS_pyramid(feats, P)                                   # unpinned at the batch itself = the pinned plan's own batch
+    for k in KEYS:
+        assert torch.equal(again[k], whole[k]), k

@@ -152,8 +152,11 @@ def test_split_k_plan_is_consistent():
                 assert p["N"] % 4 == 0 and p["Cs_out"] % 4 == 0 and p["c_off"] % 4 == 0
             if p["vec4"]:
                 assert p["Cs_in"] % 4 == 0 and p["SEG"] % 4 == 0 and p["SEG_STRIDE"] % 4 == 0
-            # tile ids: 128x128, 128x64, 128x32, 64x128, 64x64 (harness builds only), 256x32
-            assert p["tile"] != 4 and p["Npad"] % (128, 64, 32, 128, 64, 32)[p["tile"]] == 0
+            # tile ids: 128x128, 128x64, 128x32, 64x128, 64x64 (harness builds only), 256x32, weight-stream kernel (32 columns)
+            assert p["tile"] != 4 and p["Npad"] % (128, 64, 32, 128, 64, 32, 32)[p["tile"]] == 0
+            if p["tile"] == 6:                                           # few rows per phase, a ticket word per (phase, row tile, column block)
+                assert p["Mmax"] <= 64 and -(-p["Mmax"] // 32) * (p["Npad"] // 32) * p["nphase"] <= 4096
+                assert p["ksplit"] <= 16
 
 
 def test_workspace_layout_is_disjoint_and_aligned():
@@ -171,3 +174,29 @@ def test_workspace_layout_is_disjoint_and_aligned():
         assert a1 <= b0
     assert spans[-1][1] <= total
     assert L.vstab_workspace_bytes(1, 2, 2, 27) == 0                      # too small for the net
+
+
+def layer_tiles(B, H, W, flags=0, plan_batch=0):
+    out = (C.c_int32 * 200)()
+    tiles = []
+    for layer in range(19):
+        n = _lib.lib().vstab_host_layer_plan_pinned(plan_batch, flags, B, H, W, 27, layer, out, 200)
+        assert n > 0, (B, H, W, layer)
+        tiles.append((out[21], out[19], out[25]))          # tile id, split-K factor, Winograd form
+    return tiles
+
+
+def test_pinned_plan_is_the_plan_of_its_batch():
+    # vstab_set_plan_batch: every decision that changes the order of a sample's sums (split-K factor, Winograd or direct form, weight-stream
+    # or tiled kernel) of ANY batch up to the pinned one is the pinned batch's own (of one 2 GiB chunk of it: 16 x 1080p runs as 2 x 8)
+    for (P, H, W) in ((8, 512, 512), (4, 384, 512), (16, 1080, 1920)):
+        rb = 8 if H == 1080 else P
+        ref = layer_tiles(rb, H, W)
+        for b in (1, 3, rb):
+            got = layer_tiles(b, H, W, plan_batch=P)
+            assert [(t[1], t[2], t[0] == 6) for t in got] == [(t[1], t[2], t[0] == 6) for t in ref], (P, b)
+    assert layer_tiles(1, 512, 512) != layer_tiles(1, 512, 512, plan_batch=8)        # a lone sample plans differently by itself
+    out = (C.c_int32 * 200)()
+    assert _lib.lib().vstab_host_layer_plan_pinned(4, 0, 5, 384, 512, 27, 3, out, 200) < 0      # beyond the pinned batch
+    # flag 1: the round-3 schedule (few-row layers on the tiled kernel with a combine launch)
+    assert any(t[0] == 6 for t in layer_tiles(1, 256, 256)) and not any(t[0] == 6 for t in layer_tiles(1, 256, 256, flags=1))

@@ -40,6 +40,8 @@ def test_launch_command_and_env():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         assert k not in env                     # a stale rendezvous must not leak into the child job
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["VSTAB_SELF_LAUNCHED"] == "1"
+    assert env["TORCHELASTIC_USE_AGENT_STORE"] == "True"                 # also when the caller's environment says otherwise
+    assert L.launch_command("x.py", [], 2, env={"TORCHELASTIC_USE_AGENT_STORE": "0"})[1]["TORCHELASTIC_USE_AGENT_STORE"] == "True"
     with pytest.raises(ValueError):
         L.launch_command("/x/bench.py", [], 0)
 
