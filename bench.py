@@ -235,54 +235,34 @@ def main():
     if args.roctx:
         runtime.trace_ranges(True)
 
-    gather = None
+    gather = None            # fp32 frames: one collective per step, straight from the step's output tensor
+    grouped = None           # uint8 video frames (what the reference writes, main:625,630): `gather_every` steps per collective
     G = max(1, args.gather_every) if not args.gather_fp32 else 1       # steps per collective
     gdev = torch.device("cpu") if args.backend == "gloo" else torch.device("cuda", local_rank)
-    gdtype = torch.float32 if args.gather_fp32 else torch.uint8
+    host = args.backend == "gloo"
     if (world > 1 or force_dist) and not args.no_gather:
-        gather = vdist.FrameGatherer((G * B, H, W, 3), world, gdev, dtype=gdtype, schedule=args.gather_schedule)
-    quantise = None
-    group = {"g": 0, "slot": 0, "tails": {}}          # steps staged in the current group, its staging slot, gatherers for short tails
-    if gather is not None and not args.gather_fp32:
-        import ctypes as C
-        from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
-        u8 = [torch.empty((G, B, H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        if args.gather_fp32:
+            gather = vdist.FrameGatherer((B, H, W, 3), world, gdev, dtype=torch.float32, schedule=args.gather_schedule)
+        else:
+            # staging buffers and the gatherers of the short groups the warm-up and the timed region end with are allocated HERE:
+            # nothing allocates between the opening barrier and the closing synchronise
+            grouped = vdist.StepGroupGatherer(G, (B, H, W, 3), world, torch.device("cuda", local_rank), gdev, dtype=torch.uint8,
+                                              schedule=args.gather_schedule, tail_steps=(args.warmup, args.steps),
+                                              to_comm=(lambda t: t.cpu()) if host else None)
+            from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
 
-        def quantise(warped):           # np.uint8(cvtColor(warped*255)) as the reference's writer does (main:625,630)
-            if group["g"] == 0:
-                group["slot"] = gather.reserve()     # the collective that last read this staging buffer has completed
-            dst = u8[group["slot"]][group["g"]]
+    def submit_frames(warped):
+        """Hand one step's frames to the reassembly (overlapped with the next steps)."""
+        if grouped is not None:          # np.uint8(cvtColor(warped*255)) as the reference's writer does, into the group's staging buffer
+            dst = grouped.stage()
             _lib.check(_lib.lib().vstab_quantise_output(warped.data_ptr(), B * H * W, dst.data_ptr(), runtime.stream_ptr()))
-            return dst
-
-    def submit_group(frames_of_step):
-        """Stage one step's frames; every G-th step starts ONE all-gather of the whole group (overlapped with the next steps)."""
-        if quantise is None:                          # fp32 frames: one collective per step
-            gather.submit(frames_of_step.cpu() if args.backend == "gloo" else frames_of_step)
-            return
-        group["g"] += 1
-        if group["g"] == G:
-            buf = u8[group["slot"]].view(G * B, H, W, 3)
-            gather.submit(buf.cpu() if args.backend == "gloo" else buf)
-            group["g"] = 0
-
-    # gatherers for the short groups the warm-up and the timed region end with, allocated HERE: nothing allocates between the
-    # opening barrier and the closing synchronise
-    if gather is not None and quantise is not None:
-        for n_steps in (args.warmup, args.steps):
-            if n_steps % G and n_steps % G not in group["tails"]:
-                group["tails"][n_steps % G] = vdist.FrameGatherer(((n_steps % G) * B, H, W, 3), world, gdev, dtype=gdtype,
-                                                                  schedule=args.gather_schedule)
+            grouped.commit()
+        else:
+            gather.submit(warped.cpu() if host else warped)
 
     def flush_and_drain():
-        """Gather a group the step count left unfinished (one smaller collective), then wait for everything in flight."""
-        g = group["g"]
-        if gather is not None and quantise is not None and g > 0:
-            tail = group["tails"][g]
-            buf = u8[group["slot"]][:g].reshape(g * B, H, W, 3)
-            tail.submit(buf.cpu() if args.backend == "gloo" else buf)
-            tail.drain()
-            group["g"] = 0
+        if grouped is not None:
+            grouped.flush()
         if gather is not None:
             gather.drain()
 
@@ -325,18 +305,17 @@ def main():
             warped = st_fns[args.st_warp](warped)
         if vgg is not None:
             vgg.build(vvgg.preprocess(warped))
-        if gather is not None:
-            q = quantise(warped) if quantise is not None else warped
+        if gather is not None or grouped is not None:
             t2 = time.perf_counter()
-            submit_group(q)
+            submit_frames(warped)
             if dbg is not None:
-                dbg.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
+                dbg.append((t1 - t0, 0.0, time.perf_counter() - t2))
         nstep[0] += 1
         return flows, outflow, warped
 
     graph = None
     if args.graph:
-        if gather is not None:
+        if gather is not None or grouped is not None:
             raise SystemExit("--graph is for the single-GPU path (no collective inside the capture)")
         args.no_kernel_events = True
         step()                                   # allocate workspaces / load kernels outside the capture
@@ -367,7 +346,7 @@ def main():
 
     # W warm-up steps, then exactly K steps between barrier + synchronize pairs; elapsed = max over ranks (benchloop.py)
     elapsed, out = benchloop.timed_region(timed_step, args.steps, args.warmup, torch.cuda.synchronize, dist=dist,
-                                          drain=flush_and_drain if gather is not None else None, before_timed=profilers_on,
+                                          drain=flush_and_drain if (gather is not None or grouped is not None) else None, before_timed=profilers_on,
                                           device="cpu" if args.backend == "gloo" else "cuda")
 
     if dbg:
@@ -541,7 +520,7 @@ def main():
                                f"(5 flows) + flow resize/scale + tf_warp at {H}x{W}",
                    "batch_per_gpu": B, "height": H, "width": W, "cin": Cin,
                    "gflop_per_sample": round(netspec.gflop_per_sample(H, W, Cin), 2),
-                   "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL, schedule " + args.gather_schedule + f", one collective per {G} step(s)") if gather is not None else False,
+                   "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL, schedule " + args.gather_schedule + f", one collective per {G} step(s)") if (gather is not None or grouped is not None) else False,
                    "vgg16_trunk": bool(args.vgg16), "st_warp": args.st_warp, "plan_flags": args.plan_flags, "plan_batch": args.plan_batch,
                    "host_calls_per_step": "1 (vstab_stabilise_originalsize, outputs pre-allocated)" if stab is not None else "2 + 7 allocations"},
         "roofline": roofline,

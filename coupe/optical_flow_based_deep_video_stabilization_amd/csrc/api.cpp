@@ -209,7 +209,7 @@ bool choose_skinny(ConvParams &p, bool vec4, unsigned flags)
 {
     if (flags & VSTAB_PLAN_NO_SKINNY) return false;
     if (!conv_skinny_applicable(p, vec4)) return false;
-    p.ksplit = conv_skinny_split(p, (flags & 4u) ? 8 : 16);          // (bit 4: an experiment of the round, see profiles/README.md)
+    p.ksplit = conv_skinny_split(p);
     return true;
 }
 
@@ -594,7 +594,7 @@ extern "C" int vstab_set_plan_batch(vstab_ctx *ctx, int batch)
 extern "C" int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags)
 {
     if (!ctx) return fail(nullptr, VSTAB_E_STATE, "set_plan_flags: ctx is NULL");
-    if (flags & ~(unsigned)(VSTAB_PLAN_NO_SKINNY | 4u)) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(unsigned)VSTAB_PLAN_NO_SKINNY) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
     ctx->plan_flags = flags;
     return VSTAB_OK;
 }

@@ -170,6 +170,67 @@ class FrameGatherer:
             self._wait(s)
 
 
+class StepGroupGatherer:
+    """bench.py's reassembly of a STREAM of steps (weak scaling: every rank produces `B` uint8 frames per step): `every` steps' frames
+    are staged in one of two rotating buffers and reassembled with ONE collective (fewer, larger collectives: xGMI rings are
+    per-link bound), overlapped with the following steps.  A run whose step count is not a multiple of `every` ends in a shorter
+    group: its gatherer is allocated up front (`tail_steps`: the step counts the caller will flush at -- warm-up and timed region),
+    so nothing allocates between the benchmark's opening barrier and its closing synchronise.
+
+    Per step: `dst = stage()` -> write the step's frames into `dst` ([B, ...] view of the staging buffer; on the stream the
+    collective will be ordered after) -> `commit()`.  `flush()` gathers a group the step count left unfinished and waits for
+    everything in flight.  `to_comm(t)` maps a staging tensor to what the process group can move (gloo: a host copy)."""
+
+    def __init__(self, every: int, item_shape, world: int, stage_device, comm_device, dtype=torch.uint8, schedule: str = "allgather",
+                 tail_steps=(), group=None, to_comm=None):
+        if every < 1:
+            raise ValueError("every must be >= 1")
+        self.every, self.item_shape, self.world = every, tuple(item_shape), world
+        self.to_comm = to_comm or (lambda t: t)
+        self.main = FrameGatherer((every * self.item_shape[0],) + self.item_shape[1:], world, comm_device, dtype=dtype, schedule=schedule, group=group)
+        self.stagebufs = [torch.empty((every,) + self.item_shape, dtype=dtype, device=stage_device) for _ in range(2)]
+        self.tails = {}
+        for n in tail_steps:
+            r = n % every
+            if r and r not in self.tails:
+                self.tails[r] = FrameGatherer((r * self.item_shape[0],) + self.item_shape[1:], world, comm_device, dtype=dtype, schedule=schedule,
+                                              group=group)
+        self.g, self.slot = 0, 0
+        self.groups_submitted, self.tail_groups_submitted = 0, 0
+        self.last = None                    # (gatherer, slot) of the newest collective: result() reads it
+
+    def stage(self) -> torch.Tensor:
+        if self.g == 0:
+            self.slot = self.main.reserve()      # the collective that last read this staging buffer has completed
+        return self.stagebufs[self.slot][self.g]
+
+    def commit(self):
+        self.g += 1
+        if self.g == self.every:
+            buf = self.stagebufs[self.slot].view((self.every * self.item_shape[0],) + self.item_shape[1:])
+            self.last = (self.main, self.main.submit(self.to_comm(buf)))
+            self.groups_submitted += 1
+            self.g = 0
+
+    def flush(self):
+        """Gather a group the step count left unfinished (one smaller collective), then wait for everything in flight."""
+        if self.g > 0:
+            if self.g not in self.tails:
+                raise ValueError(f"a group of {self.g} steps was not announced in tail_steps")
+            tail = self.tails[self.g]
+            buf = self.stagebufs[self.slot][:self.g].reshape((self.g * self.item_shape[0],) + self.item_shape[1:])
+            self.last = (tail, tail.submit(self.to_comm(buf)))
+            tail.drain()
+            self.tail_groups_submitted += 1
+            self.g = 0
+        self.main.drain()
+
+    def result(self) -> torch.Tensor:
+        """Frames of the newest reassembled group: [world * steps_in_group * B, ...], rank-major."""
+        g, slot = self.last
+        return g.result(slot)
+
+
 class GradBucket:
     """One flat fp32 buffer; `views[name]` are tensors of the given shapes that alias consecutive pieces of it (each piece
     16-byte aligned).  `allreduce_mean()` averages the whole buffer over the process group in a single collective."""

@@ -69,7 +69,8 @@ def main():
             M3 = torch.cat([th8, torch.ones(B, 1, device="cuda")], 1).reshape(B, 3, 3)
             aff, proj = st.AffineTransformer((H, W)), st.ProjectiveTransformer((H, W))
             grid = aff.pixel_grid.reshape(3, -1)
-            T = torch.matmul(th6.reshape(B, 2, 3), grid.unsqueeze(0).expand(B, 3, -1))
+            t23 = th6.reshape(B, 2, 3)          # explicit coordinates for bilinear_interp, elementwise (no library GEMM in this script's trace)
+            T = (t23[:, :, 0:1] * grid[0] + t23[:, :, 1:2] * grid[1]) + t23[:, :, 2:3] * grid[2]
             xs, ys = T[:, 0].reshape(-1).contiguous(), T[:, 1].reshape(-1).contiguous()
             r = {"shape": sh, "pixels": px, "theta": kind}
             for name, fn, bpp in (

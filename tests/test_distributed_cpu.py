@@ -43,7 +43,7 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_total", [(2, 8), (2, 5), (3, 7)])
+@pytest.mark.parametrize("world,n_total", [(2, 8), (2, 5), (3, 7), (8, 1000), (8, 1003), (8, 5)])      # 8 = the node the scaling run uses
 def test_shard_and_gather_matches_unsharded(world, n_total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -99,7 +99,7 @@ def _bucket_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_grad_bucket_allreduce_mean(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -191,7 +191,7 @@ def _direct_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])         # 8: seven staggered peers per rank
 def test_direct_peer_schedule_equals_allgather(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -229,7 +229,7 @@ def _seq_worker(rank, world, port, n_total, mb, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_total,mb", [(2, 9, 2), (3, 10, 3), (2, 8, 8), (3, 2, 4)])
+@pytest.mark.parametrize("world,n_total,mb", [(2, 9, 2), (3, 10, 3), (2, 8, 8), (3, 2, 4), (8, 1000, 8), (8, 1003, 8), (8, 67, 4)])
 def test_sequence_gatherer_overlapped_reassembly(world, n_total, mb):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -238,6 +238,57 @@ def test_sequence_gatherer_overlapped_reassembly(world, n_total, mb):
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]
+
+
+def _group_worker(rank, world, port, schedule, q):
+    """bench.py's reassembly bookkeeping (distributed.StepGroupGatherer) as the scaling run drives it: `every` steps per collective,
+    a warm-up and a timed region that both end in a SHORTER group, two staging buffers rotating under collectives in flight."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        every, B, warm, steps = 4, 2, 6, 11                     # tails of 2 (warm-up) and 3 (timed region)
+        g = vd.StepGroupGatherer(every, (B, 3, 5, 3), world, "cpu", "cpu", dtype=torch.uint8, schedule=schedule, tail_steps=(warm, steps))
+        ok = sorted(g.tails) == [2, 3]
+        frames = lambda r, k: torch.full((B, 3, 5, 3), (r * 23 + k) & 255, dtype=torch.uint8)
+
+        def run(n, first):
+            for k in range(first, first + n):
+                g.stage().copy_(frames(rank, k))
+                g.commit()
+            g.flush()
+        run(warm, 0)
+        ok = ok and (g.groups_submitted, g.tail_groups_submitted) == (1, 1)
+        got = g.result().view(world, 2, B, 3, 5, 3)             # the warm-up's tail group: steps 4, 5 of every rank
+        ok = ok and all(torch.equal(got[r, j], frames(r, 4 + j)) for r in range(world) for j in range(2))
+        run(steps, 100)
+        ok = ok and (g.groups_submitted, g.tail_groups_submitted) == (3, 2)
+        got = g.result().view(world, 3, B, 3, 5, 3)             # the timed region's tail group: steps 108, 109, 110
+        ok = ok and all(torch.equal(got[r, j], frames(r, 108 + j)) for r in range(world) for j in range(3))
+        ok = ok and all(p is None for p in g.main.pending)
+        try:
+            g.stage(); g.commit(); g.flush()                   # a group length nobody announced must not allocate behind the barrier
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,schedule", [(2, "allgather"), (8, "allgather"), (8, "direct")])
+def test_step_group_gatherer_tails_and_rotation(world, schedule):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, schedule, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
