@@ -414,7 +414,9 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl, const PlanPin *pin = null
         if (ref) { pl.tile[10 + l] = ref->tile[10 + l]; pl.skinny[10 + l] = ref->skinny[10 + l]; p.ksplit = ref->cp[10 + l].ksplit; }
         else {
             pl.tile[10 + l] = choose_tile_split(p, pl.tile[10 + l], true);
-            pl.skinny[10 + l] = choose_skinny(p, true, flags);
+            // (with the two-problem launches a transposed convolution shares its launch with the flow head and its combine with
+            // predict_up: the weight-stream kernel's one advantage -- no combine launch -- is gone, so it serves the encoder only)
+            pl.skinny[10 + l] = (flags & VSTAB_PLAN_NO_DUAL) ? choose_skinny(p, true, flags) : false;
             if (pl.skinny[10 + l]) pl.tile[10 + l] = TILE_SKINNY;
         }
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad);
@@ -449,7 +451,10 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl, const PlanPin *pin = null
             set_ranges(p);
             if (ref) p.ksplit = ref->cp[15 + l].ksplit;
             else choose_split(p, 32);   // A/B on one box: split-K + combine beats 4..256 long-running workgroups by ~90 us/step
-            if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.ksplit * p.Mmax * p.Npad);
+            // the tap table runs in the SAME launch as the level's transposed convolution (conv_dual_kernel): their slabs sit side by side
+            const ConvParams &d = pl.cp[10 + l];
+            const size_t dec_slab = d.ksplit > 1 ? (size_t)d.nphase * d.ksplit * d.Mmax * d.Npad : 0;
+            if (p.ksplit > 1) partial_floats = std::max(partial_floats, dec_slab + (size_t)p.ksplit * p.Mmax * p.Npad);
             (void)dst;
         }
     }
@@ -594,7 +599,7 @@ extern "C" int vstab_set_plan_batch(vstab_ctx *ctx, int batch)
 extern "C" int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags)
 {
     if (!ctx) return fail(nullptr, VSTAB_E_STATE, "set_plan_flags: ctx is NULL");
-    if (flags & ~(unsigned)VSTAB_PLAN_NO_SKINNY) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(unsigned)(VSTAB_PLAN_NO_SKINNY | VSTAB_PLAN_NO_DUAL)) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
     ctx->plan_flags = flags;
     return VSTAB_OK;
 }
@@ -949,41 +954,53 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
     const int cat_buf[4] = {B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2};
     const int lvl_enc[5] = {9, 7, 5, 3, 1};              // encoder stage giving each level's size
     const int tab_src[4] = {B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3}, tab_dst[4] = {B_T6, B_T5, B_T4, B_T3};
-    // One head per level: tap-table GEMM (split-K slabs left uncombined), then ONE launch that sums the slabs, gathers
-    // predict_flowN, folds the upsampled coarser flow in and writes upsample_flowN into the next concat's flow channels.
-    auto predict_head = [&](int l, const float *prev, int ph_, int pw_, float *out) -> int {     // l: 0 = predict6 .. 3 = predict3
-        TraceRange head_range(HEAD_RANGE[l]);
-        ConvParams p = pl.cp[15 + l];
-        p.in = buf(tab_src[l]); p.out = buf(tab_dst[l]);
-        p.wpk = dw + ctx->pred_w[l]; p.bias = dw + ctx->tab_b; p.partial = buf(B_PARTIAL);
-        HIP_TRY(ctx, launch_conv(p, pl.tile[15 + l], true, stream, nullptr, nullptr, false));
-        const float *src = p.ksplit > 1 ? p.partial : p.out;
-        const int oh = pl.eh[lvl_enc[l + 1]], ow = pl.ew[lvl_enc[l + 1]];      // the finer level the flow is upsampled to
-        HIP_TRY(ctx, launch_predict_up(src, p.ksplit, (long long)p.Mmax * p.Npad, B, p.Hi, p.Wi, dw + ctx->pred_b[l], prev, ph_, pw_,
-                                       out, ctx->up[l], buf(cat_buf[l]), oh, ow, CONCAT_CS[l], CONCAT_C[l] - 2, stream));
-        return VSTAB_OK;
-    };
-    { const int rc = predict_head(0, nullptr, 0, 0, pf6); if (rc != VSTAB_OK) return rc; }
+    // One refinement level = its flow head (model.py:847-848 ...: 3x3 -> 2 conv as a tap-table GEMM whose split-K slabs stay uncombined,
+    // then predict_up: slab sum, tap gather, fold with the upsampled coarser flow, upsample_flowN into the next concat's flow channels)
+    // and its transposed convolution (model.py:850-851 ...).  Both read the SAME tensor and neither needs the other, so they run as
+    // TWO launches instead of four: conv_dual_kernel (deconv tiles + tap-table tiles side by side), then combine_predict_up_kernel
+    // (the deconv's split-K combine + predict_up side by side).  For one sample every one of the four was little more than a
+    // launch's fixed latency.  VSTAB_PLAN_NO_DUAL restores the four-launch sequence (A/B; same arithmetic, same bits).
     for (int l = 0; l < 4; ++l) {
-        ConvParams p = pl.cp[10 + l];
+        const float *prev = l == 0 ? nullptr : pfs[l - 1];
+        const int ph_ = l == 0 ? 0 : pl.eh[lvl_enc[l - 1]], pw_ = l == 0 ? 0 : pl.ew[lvl_enc[l - 1]];      // the coarser level's size
+        const int oh = pl.eh[lvl_enc[l + 1]], ow = pl.ew[lvl_enc[l + 1]];                                  // the finer level the flow is upsampled to
+        ConvParams pd = pl.cp[10 + l], pt = pl.cp[15 + l];
+        pd.in = buf(l == 0 ? B_CONV6_1 : cat_buf[l - 1]); pd.out = buf(cat_buf[l]);
+        pd.wpk = dw + ctx->dec_w[l]; pd.bias = dw + ctx->dec_b[l]; pd.partial = buf(B_PARTIAL);
+        const size_t dec_slab = pd.ksplit > 1 ? (size_t)pd.nphase * pd.ksplit * pd.Mmax * pd.Npad : 0;   // the tap table's slabs sit behind the deconv's
+        pt.in = buf(tab_src[l]); pt.out = buf(tab_dst[l]);
+        pt.wpk = dw + ctx->pred_w[l]; pt.bias = dw + ctx->tab_b; pt.partial = buf(B_PARTIAL) + dec_slab;
+        const float *tsrc = pt.ksplit > 1 ? pt.partial : pt.out;
+        bool dual = !(pin.flags & VSTAB_PLAN_NO_DUAL) && !pl.skinny[10 + l];
+        if (dual) {
+            TraceRange r2(DEC_RANGE[l]);
+            const hipError_t e = launch_conv_dual(pd, pl.tile[10 + l], pt, pl.tile[15 + l], stream, EV_A(10 + l), EV_B(10 + l));
+            if (e == hipErrorNotSupported) dual = false;
+            else {
+                HIP_TRY(ctx, e);
+                ctx->prof_kernel[10 + l] = "conv_dual_kernel: " + conv_kernel_name(pl.tile[10 + l], true) + " + <128, 32> tap table";
+            }
+        }
+        if (dual) {
+            TraceRange r3(HEAD_RANGE[l]);
+            HIP_TRY(ctx, launch_predict_up(tsrc, pt.ksplit, (long long)pt.Mmax * pt.Npad, B, pt.Hi, pt.Wi, dw + ctx->pred_b[l], prev, ph_, pw_,
+                                           pfs[l], ctx->up[l], buf(cat_buf[l]), oh, ow, CONCAT_CS[l], CONCAT_C[l] - 2, stream, &pd));
+            continue;
+        }
         {
+            TraceRange head_range(HEAD_RANGE[l]);
+            HIP_TRY(ctx, launch_conv(pt, pl.tile[15 + l], true, stream, nullptr, nullptr, false));
+            HIP_TRY(ctx, launch_predict_up(tsrc, pt.ksplit, (long long)pt.Mmax * pt.Npad, B, pt.Hi, pt.Wi, dw + ctx->pred_b[l], prev, ph_, pw_,
+                                           pfs[l], ctx->up[l], buf(cat_buf[l]), oh, ow, CONCAT_CS[l], CONCAT_C[l] - 2, stream));
+        }
         TraceRange layer_range(DEC_RANGE[l]);
-        const int ib = l == 0 ? B_CONV6_1 : cat_buf[l - 1];
-        p.in = buf(ib);
-        p.out = buf(cat_buf[l]);
-        p.wpk = dw + ctx->dec_w[l];
-        p.bias = dw + ctx->dec_b[l];
-        p.partial = buf(B_PARTIAL);
         if (pl.skinny[10 + l]) {
-            HIP_TRY(ctx, launch_conv_skinny(p, ctx->tickets, stream, EV_A(10 + l), EV_B(10 + l)));
+            HIP_TRY(ctx, launch_conv_skinny(pd, ctx->tickets, stream, EV_A(10 + l), EV_B(10 + l)));
             ctx->prof_kernel[10 + l] = "conv_skinny_kernel<1, 4>";
         } else {
-            HIP_TRY(ctx, launch_conv(p, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l)));
+            HIP_TRY(ctx, launch_conv(pd, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l)));
             ctx->prof_kernel[10 + l] = conv_kernel_name(pl.tile[10 + l], true);
         }
-        }
-        const int ph = pl.eh[lvl_enc[l]], pw = pl.ew[lvl_enc[l]];          // coarser level
-        if (l < 3) { const int rc = predict_head(l + 1, pfs[l], ph, pw, pfs[l + 1]); if (rc != VSTAB_OK) return rc; }
     }
     // full-resolution head (model.py:882-887)
     {

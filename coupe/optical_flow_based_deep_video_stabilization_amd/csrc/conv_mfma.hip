@@ -27,6 +27,7 @@
 //   * K order inside a tile is permuted so that ONE ds_read_b128 feeds four MFMA k-steps:
 //     lane (i, h) holds k = 8q + 4h + j for step (q, j) -- A and B use the same map;
 //   * split-K (grid.z) with fp32 slabs + a combine kernel for the small late layers.
+#include <algorithm>
 #include <cstdlib>
 
 #include <hip/hip_ext.h>
@@ -70,8 +71,10 @@ hipError_t conv_read_stamps(unsigned long long *host, size_t n) { return conv_re
 #define STAMP(i) do { } while (0)
 #endif
 
+// the whole workgroup program for tile (bx_, by_, bz_) of the launch described by p; a __global__ wrapper (one launch = one
+// problem, or conv_dual_kernel's two) supplies the tile coordinates
 template <int BM, int BN, int WM, int WN, bool VEC, bool DMA = false>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
+__device__ __forceinline__ void conv_mfma_body(const ConvParams &p, const unsigned bx_, const unsigned by_, const unsigned bz_)
 {
 #if defined(VSTAB_HARNESS) && defined(VSTAB_STAMP)
     const unsigned sid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -93,8 +96,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    unsigned bx_, by_, bz_;
-    xcd_remap(bx_, by_, bz_, p.no_remap != 0);      // each XCD works on a contiguous band of tiles (shared halos stay in its L2)
     const int z = (int)bz_;
     const int phase = z / p.ksplit, split = z - phase * p.ksplit;
     const ConvPhase ph = p.ph[phase];
@@ -562,58 +563,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
     STAMP(3);
 }
 
+template <int BM, int BN, int WM, int WN, bool VEC, bool DMA = false>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
+{
+    unsigned bx_, by_, bz_;
+    xcd_remap(bx_, by_, bz_, p.no_remap != 0);      // each XCD works on a contiguous band of tiles (shared halos stay in its L2)
+    conv_mfma_body<BM, BN, WM, WN, VEC, DMA>(p, bx_, by_, bz_);
+}
+
+// Two independent problems in ONE launch ("horizontal fusion"): the first nA workgroups run problem A with its tile shape, the rest
+// problem B with its own.  Used for a refinement level's transposed convolution and the tap-table GEMM of the flow head that reads
+// the same tensor (model.py:850 and :847-848 both consume conv6_1; :859 / :855-856 concat5; ...): neither fills the chip for one
+// sample, both are a launch's fixed latency, and one launch instead of two lets them share it (and the input's L2 lines).
+template <int BM1, int BN1, int WM1, int WN1, int BM2, int BN2, int WM2, int WN2>
+__global__ __launch_bounds__(256) void conv_dual_kernel(const ConvParams pa, const ConvParams pb, const unsigned nA, const uint3 gA, const uint3 gB)
+{
+    unsigned bx_, by_, bz_;
+    if (blockIdx.x < nA) {                          // workgroup uniform
+        xcd_remap_calc(gA.x, gA.y, gA.z, blockIdx.x, bx_, by_, bz_);
+        conv_mfma_body<BM1, BN1, WM1, WN1, true, true>(pa, bx_, by_, bz_);
+    } else {
+        xcd_remap_calc(gB.x, gB.y, gB.z, blockIdx.x - nA, bx_, by_, bz_);
+        conv_mfma_body<BM2, BN2, WM2, WN2, true, true>(pb, bx_, by_, bz_);
+    }
+}
+
 // Sum the split-K slabs, add bias, activate, scatter to the output tensor.
 __global__ __launch_bounds__(256) void splitk_combine_kernel(const ConvParams p)
 {
-    const int n4 = p.N >> 2;
-    const long long per_phase = (long long)p.Mmax * n4;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= per_phase * p.nphase) return;
-    const int phase = (int)(idx / per_phase);
-    const long long rem = idx - phase * per_phase;
-    const int m = (int)(rem / n4), c4 = (int)(rem - (long long)m * n4);
-    const ConvPhase ph = p.ph[phase];
-    if (m >= ph.M) return;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const float *src = p.partial + (((long long)(phase * p.ksplit) * p.Mmax + m) * p.Npad + c4 * 4);
-    const long long slab = (long long)p.Mmax * p.Npad;
-    int k = 0;
-    for (; k + 8 <= p.ksplit; k += 8) {           // eight slab loads in flight, added in slab order
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (k + u) * slab);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    if (k + 4 <= p.ksplit) {
-        f32x4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (k + u) * slab);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) s += v[u];
-        k += 4;
-    }
-    if (k < p.ksplit) {                           // up to three left: load all, add in order
-        f32x4 v[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) v[u] = k + u < p.ksplit ? *reinterpret_cast<const f32x4 *>(src + (k + u) * slab) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-            if (k + u < p.ksplit) s += v[u];
-    }
-    const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + c4 * 4);
-    s += bv;
-    if (p.act == 1 || p.act == 2) {
-        const float slope = p.act == 1 ? 0.1f : 0.0f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e], slope * s[e]);
-    }
-    const int hw = ph.Hg * ph.Wg;
-    const int n = m / hw, r2 = m - n * hw;
-    const int j = r2 / ph.Wg, i = r2 - j * ph.Wg;
-    const long long oo = ((long long)(n * p.Ho + j * p.s_out + ph.o_y) * p.Wo + i * p.s_out + ph.o_x) * p.Cs_out + p.c_off;
-    if (p.act == 3) s += *reinterpret_cast<const f32x4 *>(p.out + oo + c4 * 4);         // accumulate (gradient sums)
-    *reinterpret_cast<f32x4 *>(p.out + oo + c4 * 4) = s;
+    splitk_combine_item(p, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 
 constexpr int CONV_CUS = 256;                           // MI355X: 8 XCDs x 32 CUs
@@ -654,6 +632,15 @@ hipError_t conv_set_attributes()
     VSTAB_SET((conv_mfma_kernel<64, 64, 2, 2, true, true>), 64, 64)
 #endif
 #undef VSTAB_SET
+    // the two-problem launches: a refinement level's transposed convolution beside the 128x32 tap-table GEMM of its flow head
+#define VSTAB_SET2(BM, BN, WM, WN)                                                                                                 \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_dual_kernel<BM, BN, WM, WN, 128, 32, 4, 1>),                        \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(CONV_LDS_TWO_PER_CU, conv_lds_bytes<BM, BN>())); \
+    if (e != hipSuccess) return e;
+    VSTAB_SET2(128, 128, 2, 2)
+    VSTAB_SET2(128, 64, 2, 2)
+    VSTAB_SET2(64, 128, 1, 4)
+#undef VSTAB_SET2
     return hipSuccess;
 }
 
@@ -756,6 +743,46 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
         e = hipGetLastError();
     }
     return e;
+}
+
+// Problem A (a transposed convolution on a 128x128, 128x64 or 64x128 tile; its split-K slabs, if any, are left for the caller's
+// combine) and problem B (a 128x32 tap-table GEMM, slabs left for predict_up) in one launch.  hipErrorNotSupported: not a pair this
+// kernel is built for -- launch them one after the other.
+hipError_t launch_conv_dual(const ConvParams &pa_in, ConvTile tile_a, const ConvParams &pb_in, ConvTile tile_b, hipStream_t stream,
+                            hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    if (!lds_dma_enabled() || tile_b != TILE_128x32 || (tile_a != TILE_128x128 && tile_a != TILE_128x64 && tile_a != TILE_64x128))
+        return hipErrorNotSupported;
+    ConvParams pa = pa_in, pb = pb_in;
+    for (ConvParams *q : {&pa, &pb}) {
+        q->no_remap = 0;
+        q->out_vec4 = (((uintptr_t)q->out & 15) == 0 && (q->Cs_out & 3) == 0 && (q->c_off & 3) == 0) ? 1 : 0;
+        if (q->in_bytes >= 0x80000000u || q->w_bytes >= 0x80000000u) return hipErrorInvalidValue;
+        if (q->SEGP % 32 != 0 || q->SEGP < q->SEG || q->NSEG < 1 || q->ksplit < 1 || q->nphase < 1 || q->nphase > 16) return hipErrorInvalidValue;
+        if ((q->Cs_in & 3) || (q->SEG & 3) || (q->SEG_STRIDE & 3)) return hipErrorInvalidValue;
+        if (q->ksplit > 1 && ((q->N & 3) || (q->Cs_out & 3) || (q->c_off & 3) || q->partial == nullptr || ((uintptr_t)q->partial & 15)))
+            return hipErrorInvalidValue;
+    }
+    const int BMa = tile_a == TILE_64x128 ? 64 : 128, BNa = tile_a == TILE_128x64 ? 64 : 128;
+    if (pa.Npad % BNa != 0 || pb.Npad % 32 != 0) return hipErrorInvalidValue;
+    const uint3 gA = make_uint3((unsigned)((pa.Mmax + BMa - 1) / BMa), (unsigned)(pa.Npad / BNa), (unsigned)(pa.nphase * pa.ksplit));
+    const uint3 gB = make_uint3((unsigned)((pb.Mmax + 127) / 128), (unsigned)(pb.Npad / 32), (unsigned)(pb.nphase * pb.ksplit));
+    const unsigned long long nA = (unsigned long long)gA.x * gA.y * gA.z, nB = (unsigned long long)gB.x * gB.y * gB.z;
+    if (nA + nB >= 0x7fffffffull) return hipErrorNotSupported;
+    const dim3 grid((unsigned)(nA + nB)), block(256);
+    const bool timed = ev_start != nullptr && ev_stop != nullptr;
+#define VSTAB_LAUNCH2(BM, BN, WM, WN)                                                                                                   \
+    do {                                                                                                                                \
+        const size_t lds = std::max(conv_lds_bytes<BM, BN>(), conv_lds_bytes<128, 32>());                                               \
+        if (timed) hipExtLaunchKernelGGL((conv_dual_kernel<BM, BN, WM, WN, 128, 32, 4, 1>), grid, block, lds, stream, ev_start, ev_stop, 0, \
+                                         pa, pb, (unsigned)nA, gA, gB);                                                                 \
+        else conv_dual_kernel<BM, BN, WM, WN, 128, 32, 4, 1><<<grid, block, lds, stream>>>(pa, pb, (unsigned)nA, gA, gB);               \
+    } while (0)
+    if (tile_a == TILE_128x128) VSTAB_LAUNCH2(128, 128, 2, 2);
+    else if (tile_a == TILE_128x64) VSTAB_LAUNCH2(128, 64, 2, 2);
+    else VSTAB_LAUNCH2(64, 128, 1, 4);
+#undef VSTAB_LAUNCH2
+    return hipGetLastError();
 }
 
 }  // namespace vstab

@@ -124,14 +124,20 @@ __device__ __forceinline__ f32x2 sample_flow_legacy(const float *f, int n, int h
 constexpr int PU_T = 8;                         // flow pixels per workgroup edge
 constexpr int PU_H = PU_T + 2;                  // + halo
 constexpr int PU_S = PU_T + 4;                  // + the source pixels the halo's 3x3 taps reach
-__global__ __launch_bounds__(256) void predict_up_kernel(const float *__restrict__ src, int ks, long long slab_stride, int h, int w,
-                                                         const float *__restrict__ bias2, const float *__restrict__ prev,
-                                                         int ph, int pw, float sy, float sx, float *__restrict__ out,
-                                                         UpflowW W, float *__restrict__ concat, int oh, int ow, int Cs, int c_off)
+struct PredictUpArgs {
+    const float *src; int ks; long long slab_stride; int h, w; const float *bias2; const float *prev; int ph, pw; float sy, sx;
+    float *out; float *concat; int oh, ow, Cs, c_off;
+};
+// the workgroup program of tile (bx, by) of sample bz (predict_up_kernel; the later workgroups of combine_predict_up_kernel)
+__device__ __forceinline__ void predict_up_body(const PredictUpArgs &A, const UpflowW &W, const int bx, const int by, const int bz)
 {
+    const float *__restrict__ src = A.src; const int ks = A.ks; const long long slab_stride = A.slab_stride; const int h = A.h, w = A.w;
+    const float *__restrict__ bias2 = A.bias2; const float *__restrict__ prev = A.prev; const int ph = A.ph, pw = A.pw;
+    const float sy = A.sy, sx = A.sx; float *__restrict__ out = A.out; float *__restrict__ concat = A.concat;
+    const int oh = A.oh, ow = A.ow, Cs = A.Cs, c_off = A.c_off;
     __shared__ float tab[PU_S * PU_S * 18];      // combined tap-table entries of the source pixels (18 used columns)
     __shared__ f32x2 tile[PU_H * PU_H];
-    const int n = blockIdx.z, y0 = blockIdx.y * PU_T, x0 = blockIdx.x * PU_T;
+    const int n = bz, y0 = by * PU_T, x0 = bx * PU_T;
     const float *Tn = src + (long long)n * h * w * 32;
     // stage A: sum the split-K slabs, one (source pixel, column pair) per work item -- PU_S^2 * 9 independent items,
     // four slab loads in flight each, added in slab order (the combine pass's association)
@@ -216,15 +222,43 @@ __global__ __launch_bounds__(256) void predict_up_kernel(const float *__restrict
     }
 }
 
+__global__ __launch_bounds__(256) void predict_up_kernel(const PredictUpArgs A, const UpflowW W)
+{
+    predict_up_body(A, W, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// A refinement level's two small dependent-free passes in ONE launch: the split-K combine of the level's transposed convolution
+// (the first nC workgroups; splitk_combine_kernel's work items) and predict_flowN + upsample_flowN (the rest).  They write different
+// channel slices of the same concat buffer and read nothing of each other; for one sample each is little more than a launch's fixed
+// latency (5.5 us and 8.8 us at 384x512), so sharing the launch hides the shorter one.
+__global__ __launch_bounds__(256) void combine_predict_up_kernel(const ConvParams pc, const unsigned nC, const PredictUpArgs A, const UpflowW W,
+                                                                 const unsigned tiles_x, const unsigned tiles_y)
+{
+    if (blockIdx.x < nC) {                          // workgroup uniform
+        splitk_combine_item(pc, (long long)blockIdx.x * 256 + threadIdx.x);
+        return;
+    }
+    const unsigned t = blockIdx.x - nC, per = tiles_x * tiles_y;
+    const unsigned bz = t / per, r = t - bz * per;
+    predict_up_body(A, W, (int)(r % tiles_x), (int)(r / tiles_x), (int)bz);
+}
+
 hipError_t launch_predict_up(const float *src, int ks, long long slab_stride, int B, int h, int w, const float *bias2,
                              const float *prev, int ph, int pw, float *out, const UpflowW &W, float *concat, int oh, int ow,
-                             int Cs, int c_off, hipStream_t stream)
+                             int Cs, int c_off, hipStream_t stream, const ConvParams *combine)
 {
     if ((Cs & 3) || (c_off & 3) || c_off + 4 > Cs || ks < 1 || oh > 2 * h || ow > 2 * w) return hipErrorInvalidValue;
-    const float sy = prev ? (float)ph / (float)h : 0.f, sx = prev ? (float)pw / (float)w : 0.f;
-    dim3 grid((unsigned)((w + PU_T - 1) / PU_T), (unsigned)((h + PU_T - 1) / PU_T), (unsigned)B);
-    predict_up_kernel<<<grid, dim3(256), 0, stream>>>(src, ks, slab_stride, h, w, bias2, prev, ph, pw, sy, sx, out, W, concat, oh, ow,
-                                                      Cs, c_off);
+    PredictUpArgs A{src, ks, slab_stride, h, w, bias2, prev, ph, pw, prev ? (float)ph / (float)h : 0.f, prev ? (float)pw / (float)w : 0.f,
+                    out, concat, oh, ow, Cs, c_off};
+    const unsigned tx = (unsigned)((w + PU_T - 1) / PU_T), ty = (unsigned)((h + PU_T - 1) / PU_T);
+    if (combine && combine->ksplit > 1) {
+        const long long total = (long long)combine->Mmax * (combine->N >> 2) * combine->nphase;
+        const unsigned long long nC = (unsigned long long)((total + 255) / 256), nP = (unsigned long long)tx * ty * (unsigned)B;
+        if ((combine->N & 3) || nC + nP >= 0x7fffffffull) return hipErrorInvalidValue;
+        combine_predict_up_kernel<<<dim3((unsigned)(nC + nP)), dim3(256), 0, stream>>>(*combine, (unsigned)nC, A, W, tx, ty);
+        return hipGetLastError();
+    }
+    predict_up_kernel<<<dim3(tx, ty, (unsigned)B), dim3(256), 0, stream>>>(A, W);
     return hipGetLastError();
 }
 

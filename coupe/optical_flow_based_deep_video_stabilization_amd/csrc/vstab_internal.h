@@ -96,6 +96,64 @@ struct ConvParams {
     ConvPhase ph[16];       // 4 transposed-conv phases, or the 16 positions of a Winograd-domain GEMM
 };
 
+#ifdef __HIPCC__
+// One work item of the split-K combine (splitk_combine_kernel; also the first workgroups of combine_predict_up_kernel): item idx sums
+// the slabs of four consecutive output columns of one GEMM row in slab order, adds the bias, applies the activation, scatters.
+__device__ __forceinline__ void splitk_combine_item(const ConvParams &p, const long long idx)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+    const int n4 = p.N >> 2;
+    const long long per_phase = (long long)p.Mmax * n4;
+    if (idx >= per_phase * p.nphase) return;
+    const int phase = (int)(idx / per_phase);
+    const long long rem = idx - phase * per_phase;
+    const int m = (int)(rem / n4), c4 = (int)(rem - (long long)m * n4);
+    const ConvPhase ph = p.ph[phase];
+    if (m >= ph.M) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float *src = p.partial + (((long long)(phase * p.ksplit) * p.Mmax + m) * p.Npad + c4 * 4);
+    const long long slab = (long long)p.Mmax * p.Npad;
+    int k = 0;
+    for (; k + 8 <= p.ksplit; k += 8) {           // eight slab loads in flight, added in slab order
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (k + u) * slab);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    if (k + 4 <= p.ksplit) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (k + u) * slab);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u];
+        k += 4;
+    }
+    if (k < p.ksplit) {                           // up to three left: load all, add in order
+        f32x4 v[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) v[u] = k + u < p.ksplit ? *reinterpret_cast<const f32x4 *>(src + (k + u) * slab) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (k + u < p.ksplit) s += v[u];
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + c4 * 4);
+    s += bv;
+    if (p.act == 1 || p.act == 2) {
+        const float slope = p.act == 1 ? 0.1f : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e], slope * s[e]);
+    }
+    const int hw = ph.Hg * ph.Wg;
+    const int n = m / hw, r2 = m - n * hw;
+    const int j = r2 / ph.Wg, i = r2 - j * ph.Wg;
+    const long long oo = ((long long)(n * p.Ho + j * p.s_out + ph.o_y) * p.Wo + i * p.s_out + ph.o_x) * p.Cs_out + p.c_off;
+    if (p.act == 3) s += *reinterpret_cast<const f32x4 *>(p.out + oo + c4 * 4);         // accumulate (gradient sums)
+    *reinterpret_cast<f32x4 *>(p.out + oo + c4 * 4) = s;
+}
+#endif
+
 enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 = 3, TILE_64x64 = 4, TILE_256x32 = 5,
                 TILE_SKINNY = 6 };     // conv_skinny.hip: 32/64 rows x 32 columns per workgroup, weights streamed through registers
 
@@ -104,6 +162,10 @@ enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 
 // combine = false: a split-K launch leaves its slabs in p.partial for the consumer to sum (launch_predict_up)
 hipError_t launch_conv(const ConvParams &p, ConvTile tile, bool vec4, hipStream_t stream,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool combine = true);
+// two problems in one launch (conv_dual_kernel): A on a 128x128 / 128x64 / 64x128 tile, B a 128x32 tap-table GEMM; neither's slabs are
+// combined.  hipErrorNotSupported when the pair is not one the kernel is built for.
+hipError_t launch_conv_dual(const ConvParams &pa, ConvTile tile_a, const ConvParams &pb, ConvTile tile_b, hipStream_t stream,
+                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t conv_set_attributes();   // raises the dynamic-LDS limit once per process
 bool conv_uses_lds_dma(ConvTile tile, bool vec4);   // which instantiation launch_conv picks (for reports)
 
@@ -193,7 +255,9 @@ hipError_t launch_wino_output(const float *M, int B, int Ho, int Wo, int C, cons
 struct UpflowW { float w[64]; float b[2]; };   // w[ky][kx][co][ci]
 hipError_t launch_predict_up(const float *src, int ks, long long slab_stride, int B, int h, int w, const float *bias2,
                              const float *prev, int ph, int pw, float *out, const UpflowW &W, float *concat, int oh, int ow,
-                             int Cs, int c_off, hipStream_t stream);
+                             int Cs, int c_off, hipStream_t stream, const ConvParams *combine = nullptr);
+// combine != null (with ksplit > 1): the same launch also sums that launch's split-K slabs into its output (the level's transposed
+// convolution, launched with combine = false): combine_predict_up_kernel
 
 // predict_flow2 (model.py:882-887) from the per-source-pixel tap table T[B,h2,w2,32]
 // (T[.., tap*2 + o] = sum_c concat2[.., c] * W[tap][c][o]) and pf3.

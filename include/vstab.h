@@ -93,9 +93,11 @@ VSTAB_API size_t vstab_workspace_bytes(int B, int H, int W, int Cin);
  * ragged last micro-batch of a sharded clip: main:553-558's samples are independent).  vstab_set_plan_batch(ctx, P)
  * pins them to what a batch of P samples gets: every call with B <= P then gives each sample bit-identical results, whatever B is
  * (B > P is VSTAB_E_SHAPE).  P = 0 (default) unpins.  The workspace of a pinned context is sized by vstab_workspace_bytes_ctx
- * (a workspace sized for P itself always suffices).  Flags: VSTAB_PLAN_NO_SKINNY keeps few-row layers on the tiled kernel with a
- * split-K combine launch (the round-3 schedule; A/B measurements and tests). */
+ * (a workspace sized for P itself always suffices).  Flags (A/B measurements and tests; 3 = the round-3 schedule):
+ * VSTAB_PLAN_NO_SKINNY keeps few-row layers on the tiled kernel with a split-K combine launch, VSTAB_PLAN_NO_DUAL launches a
+ * refinement level's flow head and transposed convolution one after the other. */
 #define VSTAB_PLAN_NO_SKINNY 1u
+#define VSTAB_PLAN_NO_DUAL 2u      /* a refinement level as four launches (tap table, predict_up, transposed conv, combine) instead of two */
 VSTAB_API int vstab_set_plan_batch(vstab_ctx *ctx, int batch);
 VSTAB_API int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags);
 VSTAB_API size_t vstab_workspace_bytes_ctx(const vstab_ctx *ctx, int B, int H, int W, int Cin);

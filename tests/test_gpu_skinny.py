@@ -106,3 +106,26 @@ def test_pinned_plan_batch_makes_a_sample_independent_of_its_batch(ctx, P, H, W)
     again = vs.flownetS_pyramid(feats, P)                                   # unpinned at the batch itself = the pinned plan's own batch
     for k in KEYS:
         assert torch.equal(again[k], whole[k]), k
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 384, 512), (1, 256, 256), (8, 512, 512), (3, 88, 104), (2, 720, 1280)])
+def test_two_launch_refinement_levels_equal_the_four_launch_sequence_bit_for_bit(ctx, B, H, W):
+    # a level's transposed convolution + tap-table GEMM in one launch (conv_dual_kernel) and its split-K combine + predict_up in one
+    # launch (combine_predict_up_kernel) are the same workgroup programs as the four separate launches: identical bits, every level,
+    # every internal tensor of the decoder.  (Flag 1 keeps the few-row layers on the tiled kernel in both runs: the four-launch
+    # sequence may otherwise put a transposed convolution on the weight-stream kernel, whose sums associate differently.)
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    feats = torch.rand(B, H, W, 27, generator=g).cuda()
+    names = ("concat5", "concat4", "concat3", "concat2")
+    ctx.set_plan_flags(1)
+    a = vs.flownetS_pyramid(feats, B)
+    a = {k: a[k].clone() for k in KEYS}
+    ia = {k: v.clone() for k, v in ctx.internals(B, H, W, 27).items() if k in names}
+    ctx.set_plan_flags(1 | 2)
+    b = vs.flownetS_pyramid(feats, B)
+    ib = {k: v for k, v in ctx.internals(B, H, W, 27).items() if k in names}
+    for k in names:
+        assert torch.equal(ia[k], ib[k]), k
+    for k in KEYS:
+        assert torch.equal(a[k], b[k]), k
+    ctx.set_plan_flags(0)
