@@ -971,17 +971,20 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         pt.in = buf(tab_src[l]); pt.out = buf(tab_dst[l]);
         pt.wpk = dw + ctx->pred_w[l]; pt.bias = dw + ctx->tab_b; pt.partial = buf(B_PARTIAL) + dec_slab;
         const float *tsrc = pt.ksplit > 1 ? pt.partial : pt.out;
-        bool dual = !(pin.flags & VSTAB_PLAN_NO_DUAL) && !pl.skinny[10 + l];
-        if (dual) {
-            TraceRange r2(DEC_RANGE[l]);
-            const hipError_t e = launch_conv_dual(pd, pl.tile[10 + l], pt, pl.tile[15 + l], stream, EV_A(10 + l), EV_B(10 + l));
-            if (e == hipErrorNotSupported) dual = false;
-            else {
-                HIP_TRY(ctx, e);
-                ctx->prof_kernel[10 + l] = "conv_dual_kernel: " + conv_kernel_name(pl.tile[10 + l], true) + " + <128, 32> tap table";
+        const bool fuse = !(pin.flags & VSTAB_PLAN_NO_DUAL) && !pl.skinny[10 + l];
+        if (fuse) {
+            {
+                TraceRange r2(DEC_RANGE[l]);
+                const hipError_t e = launch_conv_dual(pd, pl.tile[10 + l], pt, pl.tile[15 + l], stream, EV_A(10 + l), EV_B(10 + l));
+                if (e == hipErrorNotSupported) {        // not co-resident (large batches): one launch each, the combine still rides with predict_up
+                    HIP_TRY(ctx, launch_conv(pt, pl.tile[15 + l], true, stream, nullptr, nullptr, false));
+                    HIP_TRY(ctx, launch_conv(pd, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l), false));
+                    ctx->prof_kernel[10 + l] = conv_kernel_name(pl.tile[10 + l], true);
+                } else {
+                    HIP_TRY(ctx, e);
+                    ctx->prof_kernel[10 + l] = "conv_dual_kernel: " + conv_kernel_name(pl.tile[10 + l], true) + " + <128, 32> tap table";
+                }
             }
-        }
-        if (dual) {
             TraceRange r3(HEAD_RANGE[l]);
             HIP_TRY(ctx, launch_predict_up(tsrc, pt.ksplit, (long long)pt.Mmax * pt.Npad, B, pt.Hi, pt.Wi, dw + ctx->pred_b[l], prev, ph_, pw_,
                                            pfs[l], ctx->up[l], buf(cat_buf[l]), oh, ow, CONCAT_CS[l], CONCAT_C[l] - 2, stream, &pd));

@@ -32,12 +32,54 @@ def timeit(fn, iters):
     return ms / iters * 1e3
 
 
+def insitu_study(B, H, W, iters):
+    """Why the fused glue + warp launch takes 22.7 us inside a step and 16.6 us here (B=8 512x512): the same launch timed (library
+    dispatch timestamps) with its operands in the cache states a step leaves them in.  Between timed launches:
+      warm        nothing (this script's default: frame and predict_flow2 were read by the previous iteration)
+      cold        1 GiB written to another buffer (L2 and the 256 MB Infinity Cache hold neither operand)
+      frame cold  the same flush, then predict_flow2 re-written by a copy kernel (as pf2_tile_kernel leaves it: fresh, dirty in L2) --
+                  what a step looks like: the frame was last touched a whole step (~700 MB of workspace traffic) ago
+      pf2 cold    the flush, then the FRAME re-read by a copy (frame resident, predict_flow2 from HBM)"""
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(B, H, W, 3, generator=g).cuda()
+    lo = torch.randn(B, 2, max(H // 16, 2), max(W // 16, 2), generator=g) * 6
+    pf2 = torch.nn.functional.interpolate(lo, size=(H - 2, W - 2), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous().cuda()
+    pf2_src, sink = pf2.clone(), torch.empty_like(img)
+    junk = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    modes = {"warm": lambda: None,
+             "cold": lambda: junk.fill_(1.0),
+             "frame cold, predict_flow2 fresh": lambda: (junk.fill_(1.0), pf2.copy_(pf2_src)),
+             "predict_flow2 cold, frame resident": lambda: (junk.fill_(1.0), sink.copy_(img))}
+    out = {}
+    for name, prep in modes.items():
+        for _ in range(3):
+            prep(); vs.flow_glue_warp(pf2, img, H, W)
+        torch.cuda.synchronize()
+        runtime.hbm_profile(1)
+        for _ in range(iters):
+            prep()
+            vs.flow_glue_warp(pf2, img, H, W)
+        torch.cuda.synchronize()
+        runtime.hbm_profile(0)
+        hp = runtime.hbm_profile_read()["flow_glue_warp"]
+        us = hp[0] / hp[1] * 1e3
+        gbs = B * H * W * 40 / us * 1e-3
+        out[name] = {"us": round(us, 2), "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK, 4)}
+        print(f"{B}x{H}x{W} glue+warp fused, {name:<36} {us:8.2f} us  {gbs:8.1f} GB/s  {gbs / PEAK:.3f}", file=sys.stderr, flush=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--flows", default="smooth,random")
     ap.add_argument("--shapes", default="8x512x512,16x1080x1920,32x720x1280,1x384x512")
+    ap.add_argument("--insitu-study", action="store_true", help="only the cache-state study of the fused launch at the first shape")
     args = ap.parse_args()
+    if args.insitu_study:
+        B, H, W = (int(v) for v in args.shapes.split(",")[0].split("x"))
+        print(json.dumps({"shape": args.shapes.split(",")[0], "insitu_study": insitu_study(B, H, W, args.iters)}))
+        return
     rows = []
     for sh in args.shapes.split(","):
         B, H, W = (int(v) for v in sh.split("x"))
