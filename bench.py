@@ -410,8 +410,11 @@ def main():
                     "flops_counted": "issued by the MFMA kernel; *_direct = same layers as direct convolutions (Winograd stages x9/4)",
                     "note": "peak = 157.3 TFLOP/s at the nominal 2.4 GHz; in situ the chip holds 2.34-2.39 GHz in these launches (in-kernel stamps, "
                             "profiles/insitu_stamps_r03k_asm.txt); the K loops are assembly blocks (0.98 of the pipe with two workgroups per CU, 0.94 with one), "
-                            "what is left is prologue + epilogue that the workgroups of a launch run in lockstep; the dominant kernel's average includes the "
-                            "short-reduction Winograd-domain GEMMs of conv3_1 / conv4_1 (0.71 / 0.81; conv2 / conv3 0.89 / 0.91)",
+                            "what is left is prologue + epilogue that the workgroups of a launch run in lockstep.  Launches are grouped by kernel instantiation as "
+                            "rocprofv3 names them: since round 4 a refinement level's transposed convolution shares its launch with the level's tap-table GEMM "
+                            "(conv_dual_kernel: its own group; the events bracket both, the flops counted are the transposed convolution's), so this group is the "
+                            "plain conv_mfma_kernel launches (conv2 ... conv6 at B=8 512x512); profiles/rocprof_r04p_steady.md is the steady-state rocprofv3 "
+                            "trace of the same command, whose average for this kernel agrees with avg_launch_us",
                     "achieved_direct": round(d_dfl / (d_ms * 1e-3) / 1e12, 2),
                     "frac_direct": round(d_dfl / (d_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                     "all_mfma_launches": {"launches_per_step": 15, "ms_per_step": round(tot_ms, 4),

@@ -976,7 +976,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
             {
                 TraceRange r2(DEC_RANGE[l]);
                 const hipError_t e = launch_conv_dual(pd, pl.tile[10 + l], pt, pl.tile[15 + l], stream, EV_A(10 + l), EV_B(10 + l));
-                if (e == hipErrorNotSupported) {        // not co-resident (large batches): one launch each, the combine still rides with predict_up
+                if (e == hipErrorNotSupported) {        // a tile shape the two-problem kernel is not built for: one launch each, the combine still rides with predict_up
                     HIP_TRY(ctx, launch_conv(pt, pl.tile[15 + l], true, stream, nullptr, nullptr, false));
                     HIP_TRY(ctx, launch_conv(pd, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l), false));
                     ctx->prof_kernel[10 + l] = conv_kernel_name(pl.tile[10 + l], true);

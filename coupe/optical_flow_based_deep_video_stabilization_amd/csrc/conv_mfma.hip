@@ -576,14 +576,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p)
 // the same tensor (model.py:850 and :847-848 both consume conv6_1; :859 / :855-856 concat5; ...): neither fills the chip for one
 // sample, both are a launch's fixed latency, and one launch instead of two lets them share it (and the input's L2 lines).
 template <int BM1, int BN1, int WM1, int WN1, int BM2, int BN2, int WM2, int WN2>
-__global__ __launch_bounds__(256) void conv_dual_kernel(const ConvParams pa, const ConvParams pb, const unsigned nA, const uint3 gA, const uint3 gB)
+__global__ __launch_bounds__(256) void conv_dual_kernel(const ConvParams pa, const ConvParams pb, const unsigned nA, const unsigned nB, const int b_first,
+                                                        const uint3 gA, const uint3 gB)
 {
+    // Dispatch order.  Both problems co-resident (one sample): A first -- its tiles keep the XCD banding of a launch of their own
+    // (measured: B first costs a 384x512 frame +10 us).  A alone fills whole rounds (B=8 512x512: deconv2's 1024 workgroups are two
+    // rounds exactly): B's short workgroups first -- they delay half the slots by their own short life instead of forming a ragged
+    // last round of their own (headline shape 2.858 -> 2.839 ms).
     unsigned bx_, by_, bz_;
-    if (blockIdx.x < nA) {                          // workgroup uniform
-        xcd_remap_calc(gA.x, gA.y, gA.z, blockIdx.x, bx_, by_, bz_);
+    const unsigned idA = b_first ? blockIdx.x - nB : blockIdx.x;
+    const bool isA = b_first ? blockIdx.x >= nB : blockIdx.x < nA;      // workgroup uniform
+    if (isA) {
+        xcd_remap_calc(gA.x, gA.y, gA.z, idA, bx_, by_, bz_);
         conv_mfma_body<BM1, BN1, WM1, WN1, true, true>(pa, bx_, by_, bz_);
     } else {
-        xcd_remap_calc(gB.x, gB.y, gB.z, blockIdx.x - nA, bx_, by_, bz_);
+        xcd_remap_calc(gB.x, gB.y, gB.z, b_first ? blockIdx.x : blockIdx.x - nA, bx_, by_, bz_);
         conv_mfma_body<BM2, BN2, WM2, WN2, true, true>(pb, bx_, by_, bz_);
     }
 }
@@ -768,19 +775,19 @@ hipError_t launch_conv_dual(const ConvParams &pa_in, ConvTile tile_a, const Conv
     const uint3 gA = make_uint3((unsigned)((pa.Mmax + BMa - 1) / BMa), (unsigned)(pa.Npad / BNa), (unsigned)(pa.nphase * pa.ksplit));
     const uint3 gB = make_uint3((unsigned)((pb.Mmax + 127) / 128), (unsigned)(pb.Npad / 32), (unsigned)(pb.nphase * pb.ksplit));
     const unsigned long long nA = (unsigned long long)gA.x * gA.y * gA.z, nB = (unsigned long long)gB.x * gB.y * gB.z;
-    // Worth it only while both problems are co-resident (two workgroups per CU): then the launch takes as long as its longer member.
-    // A transposed convolution that already fills whole rounds (B=8 512x512: deconv2's 1024 workgroups = two rounds exactly) gets a
-    // ragged third round of tap-table workgroups appended instead -- measured +43 us on deconv2, +7.7 / +5.3 / +5.7 on deconv5 / 4 / 3,
-    // against 53 us for the four tap-table launches it replaced: nothing gained, so those keep their own launches.
-    if (nA + nB > 2ull * CONV_CUS) return hipErrorNotSupported;
+    // Co-resident (two workgroups per CU hold both problems): the launch takes as long as its longer member.  Beyond that B's tiles go
+    // first (see the kernel); appended BEHIND a transposed convolution that fills whole rounds they were a ragged round of their own
+    // (+43 us on deconv2 at B=8 512x512, profiles/README.md r04).
+    const int b_first = nA + nB > 2ull * CONV_CUS ? 1 : 0;
     const dim3 grid((unsigned)(nA + nB)), block(256);
     const bool timed = ev_start != nullptr && ev_stop != nullptr;
 #define VSTAB_LAUNCH2(BM, BN, WM, WN)                                                                                                   \
     do {                                                                                                                                \
-        const size_t lds = std::max(conv_lds_bytes<BM, BN>(), conv_lds_bytes<128, 32>());                                               \
+        size_t lds = std::max(conv_lds_bytes<BM, BN>(), conv_lds_bytes<128, 32>());                                                     \
+        if (BN == 64 && nA > 2 * CONV_CUS && nA <= 4 * CONV_CUS && nA % (2 * CONV_CUS) == 0) lds = CONV_LDS_TWO_PER_CU;  /* as launch_conv */ \
         if (timed) hipExtLaunchKernelGGL((conv_dual_kernel<BM, BN, WM, WN, 128, 32, 4, 1>), grid, block, lds, stream, ev_start, ev_stop, 0, \
-                                         pa, pb, (unsigned)nA, gA, gB);                                                                 \
-        else conv_dual_kernel<BM, BN, WM, WN, 128, 32, 4, 1><<<grid, block, lds, stream>>>(pa, pb, (unsigned)nA, gA, gB);               \
+                                         pa, pb, (unsigned)nA, (unsigned)nB, b_first, gA, gB);                                          \
+        else conv_dual_kernel<BM, BN, WM, WN, 128, 32, 4, 1><<<grid, block, lds, stream>>>(pa, pb, (unsigned)nA, (unsigned)nB, b_first, gA, gB); \
     } while (0)
     if (tile_a == TILE_128x128) VSTAB_LAUNCH2(128, 128, 2, 2);
     else if (tile_a == TILE_128x64) VSTAB_LAUNCH2(128, 64, 2, 2);
