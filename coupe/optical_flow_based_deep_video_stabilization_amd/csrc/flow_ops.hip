@@ -121,16 +121,19 @@ __device__ __forceinline__ f32x2 sample_flow_legacy(const float *f, int n, int h
 // recomputed, not exchanged), stores the tile, then emits the 32x32 upsampled outputs that depend on it: three
 // dependent launches (combine, gather, upsample) become one.
 // ---------------------------------------------------------------------------------
-constexpr int PU_T = 8;                         // flow pixels per workgroup edge
-constexpr int PU_H = PU_T + 2;                  // + halo
-constexpr int PU_S = PU_T + 4;                  // + the source pixels the halo's 3x3 taps reach
+// PU_T = flow pixels per workgroup edge (template parameter: 8, or 4 for the small grids of one sample -- a level of 48 x 64 flow pixels
+// is 48 workgroups of 8 x 8 on 256 CUs and a chain of dependent phases each; 192 workgroups of 4 x 4 run the same phases on four
+// times the CUs with a quarter of the items per phase.  Same sums per output either way: identical bits).
 struct PredictUpArgs {
     const float *src; int ks; long long slab_stride; int h, w; const float *bias2; const float *prev; int ph, pw; float sy, sx;
     float *out; float *concat; int oh, ow, Cs, c_off;
 };
 // the workgroup program of tile (bx, by) of sample bz (predict_up_kernel; the later workgroups of combine_predict_up_kernel)
+template <int PU_T>
 __device__ __forceinline__ void predict_up_body(const PredictUpArgs &A, const UpflowW &W, const int bx, const int by, const int bz)
 {
+    constexpr int PU_H = PU_T + 2;                  // + halo
+    constexpr int PU_S = PU_T + 4;                  // + the source pixels the halo's 3x3 taps reach
     const float *__restrict__ src = A.src; const int ks = A.ks; const long long slab_stride = A.slab_stride; const int h = A.h, w = A.w;
     const float *__restrict__ bias2 = A.bias2; const float *__restrict__ prev = A.prev; const int ph = A.ph, pw = A.pw;
     const float sy = A.sy, sx = A.sx; float *__restrict__ out = A.out; float *__restrict__ concat = A.concat;
@@ -222,15 +225,17 @@ __device__ __forceinline__ void predict_up_body(const PredictUpArgs &A, const Up
     }
 }
 
+template <int PU_T>
 __global__ __launch_bounds__(256) void predict_up_kernel(const PredictUpArgs A, const UpflowW W)
 {
-    predict_up_body(A, W, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+    predict_up_body<PU_T>(A, W, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 // A refinement level's two small dependent-free passes in ONE launch: the split-K combine of the level's transposed convolution
 // (the first nC workgroups; splitk_combine_kernel's work items) and predict_flowN + upsample_flowN (the rest).  They write different
 // channel slices of the same concat buffer and read nothing of each other; for one sample each is little more than a launch's fixed
 // latency (5.5 us and 8.8 us at 384x512), so sharing the launch hides the shorter one.
+template <int PU_T>
 __global__ __launch_bounds__(256) void combine_predict_up_kernel(const ConvParams pc, const unsigned nC, const PredictUpArgs A, const UpflowW W,
                                                                  const unsigned tiles_x, const unsigned tiles_y)
 {
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void combine_predict_up_kernel(const ConvParam
     }
     const unsigned t = blockIdx.x - nC, per = tiles_x * tiles_y;
     const unsigned bz = t / per, r = t - bz * per;
-    predict_up_body(A, W, (int)(r % tiles_x), (int)(r / tiles_x), (int)bz);
+    predict_up_body<PU_T>(A, W, (int)(r % tiles_x), (int)(r / tiles_x), (int)bz);
 }
 
 hipError_t launch_predict_up(const float *src, int ks, long long slab_stride, int B, int h, int w, const float *bias2,
@@ -250,15 +255,18 @@ hipError_t launch_predict_up(const float *src, int ks, long long slab_stride, in
     if ((Cs & 3) || (c_off & 3) || c_off + 4 > Cs || ks < 1 || oh > 2 * h || ow > 2 * w) return hipErrorInvalidValue;
     PredictUpArgs A{src, ks, slab_stride, h, w, bias2, prev, ph, pw, prev ? (float)ph / (float)h : 0.f, prev ? (float)pw / (float)w : 0.f,
                     out, concat, oh, ow, Cs, c_off};
-    const unsigned tx = (unsigned)((w + PU_T - 1) / PU_T), ty = (unsigned)((h + PU_T - 1) / PU_T);
+    const int T = (long long)((w + 7) / 8) * ((h + 7) / 8) * B < 256 ? 4 : 8;       // 4 x 4 tiles while 8 x 8 ones would leave CUs idle
+    const unsigned tx = (unsigned)((w + T - 1) / T), ty = (unsigned)((h + T - 1) / T);
     if (combine && combine->ksplit > 1) {
         const long long total = (long long)combine->Mmax * (combine->N >> 2) * combine->nphase;
         const unsigned long long nC = (unsigned long long)((total + 255) / 256), nP = (unsigned long long)tx * ty * (unsigned)B;
         if ((combine->N & 3) || nC + nP >= 0x7fffffffull) return hipErrorInvalidValue;
-        combine_predict_up_kernel<<<dim3((unsigned)(nC + nP)), dim3(256), 0, stream>>>(*combine, (unsigned)nC, A, W, tx, ty);
+        if (T == 4) combine_predict_up_kernel<4><<<dim3((unsigned)(nC + nP)), dim3(256), 0, stream>>>(*combine, (unsigned)nC, A, W, tx, ty);
+        else combine_predict_up_kernel<8><<<dim3((unsigned)(nC + nP)), dim3(256), 0, stream>>>(*combine, (unsigned)nC, A, W, tx, ty);
         return hipGetLastError();
     }
-    predict_up_kernel<<<dim3(tx, ty, (unsigned)B), dim3(256), 0, stream>>>(A, W);
+    if (T == 4) predict_up_kernel<4><<<dim3(tx, ty, (unsigned)B), dim3(256), 0, stream>>>(A, W);
+    else predict_up_kernel<8><<<dim3(tx, ty, (unsigned)B), dim3(256), 0, stream>>>(A, W);
     return hipGetLastError();
 }
 

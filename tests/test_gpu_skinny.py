@@ -68,7 +68,7 @@ def test_in_launch_split_k_reduction_is_reproducible_under_load(ctx, H, W):
     xs = [torch.rand(1, H, W, 27, generator=g).cuda() for _ in range(2)]
     first = [None, None]
     outs = []
-    for it in range(40):
+    for it in range(300 if H == 256 else 60):
         r = vs.flownetS_pyramid(xs[it & 1], 1)
         outs.append((it & 1, {k: r[k].clone() for k in KEYS}))
     torch.cuda.synchronize()

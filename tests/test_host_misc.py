@@ -54,6 +54,11 @@ def test_errors_without_context():
     assert L.vstab_warp_flow(None, None, None, 1, 4, 4, 3, None) < 0
     assert L.vstab_flow_box_blur(None, 1, 4, 4, 3, None, None, None) < 0
     assert L.vstab_vec2mtrx(None, 1, 8, 4, None, None) < 0
+    # round-4 entry points: no context / NULL buffers are error codes, never a crash
+    assert L.vstab_set_plan_batch(None, 8) == -6 and L.vstab_set_plan_flags(None, 1) == -6
+    assert L.vstab_transform_image(None, 1, 4, 4, 3, None, None, None, 4, 4, None) == -6
+    assert L.vstab_workspace_bytes_ctx(None, 8, 512, 512, 27) == L.vstab_workspace_bytes(8, 512, 512, 27)      # no context = unpinned
+    assert L.vstab_workspace_bytes_ctx(None, 0, 512, 512, 27) == 0
 
 
 @pytest.mark.parametrize("grid", [(256, 1, 1), (256, 2, 1), (64, 4, 8), (1024, 1, 4), (13, 1, 19), (11, 3, 5), (7, 1, 1), (1, 1, 1),
