@@ -28,12 +28,14 @@ def _u8(t, name):
     return t.contiguous()
 
 
-def resize_u8(src: torch.Tensor, size_hw) -> torch.Tensor:
-    """cv2.resize(src, (w, h)) with INTER_LINEAR on uint8 frames [n,H,W,3]."""
+def resize_u8(src: torch.Tensor, size_hw, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """cv2.resize(src, (w, h)) with INTER_LINEAR on uint8 frames [n,H,W,3]; `out` (contiguous, same device) receives the result in place."""
     src = _u8(src, "src")
     n, sh, sw, _ = src.shape
     dh, dw = int(size_hw[0]), int(size_hw[1])
-    dst = torch.empty((n, dh, dw, 3), dtype=torch.uint8, device=src.device)
+    if out is not None and (out.dtype != torch.uint8 or tuple(out.shape) != (n, dh, dw, 3) or not out.is_contiguous() or out.device != src.device):
+        raise ValueError("out must be a contiguous uint8 tensor [n, h, w, 3] on src's device")
+    dst = out if out is not None else torch.empty((n, dh, dw, 3), dtype=torch.uint8, device=src.device)
     with torch.cuda.device(src.device):
         _lib.check(_lib.lib().vstab_resize_u8(src.data_ptr(), n, sh, sw, dst.data_ptr(), dh, dw, runtime.stream_ptr()))
     return dst
@@ -91,7 +93,7 @@ class ClipStabiliser:
         with torch.cuda.device(self.device):
             _lib.check(L.vstab_quantise_output(warped.data_ptr(), self.n * self.out_h * self.out_w, out.data_ptr(),
                                                runtime.stream_ptr()))                                  # main:625,630
-        self.ring[i % RING].copy_(resize_u8(out, (self.net_h, self.net_w)))      # what later frames read back (main:556)
+        resize_u8(out, (self.net_h, self.net_w), out=self.ring[i % RING])        # what later frames read back (main:556), written in place
         self.last_flows, self.last_outflow = flows, outflow
         self.i += 1
         if self.homography:
