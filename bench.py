@@ -413,7 +413,7 @@ def main():
                             "what is left is prologue + epilogue that the workgroups of a launch run in lockstep.  Launches are grouped by kernel instantiation as "
                             "rocprofv3 names them: since round 4 a refinement level's transposed convolution shares its launch with the level's tap-table GEMM "
                             "(conv_dual_kernel: its own group; the events bracket both, the flops counted are the transposed convolution's), so this group is the "
-                            "plain conv_mfma_kernel launches (conv2 ... conv6 at B=8 512x512); profiles/rocprof_r04p_steady.md is the steady-state rocprofv3 "
+                            "plain conv_mfma_kernel launches (conv2 ... conv6 at B=8 512x512); profiles/rocprof_r04z_steady.md is the steady-state rocprofv3 "
                             "trace of the same command, whose average for this kernel agrees with avg_launch_us",
                     "achieved_direct": round(d_dfl / (d_ms * 1e-3) / 1e12, 2),
                     "frac_direct": round(d_dfl / (d_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
