@@ -16,6 +16,7 @@ from typing import Optional
 import torch
 
 from . import _lib, runtime
+from .model import flownetS_pyramid
 from .pipeline import stabilise_originalsize
 
 STAB_LAGS = (31, 23, 15, 7, 4, 3, 2, 1)          # stabidxs, main:553
@@ -43,12 +44,16 @@ def resize_u8(src: torch.Tensor, size_hw, out: Optional[torch.Tensor] = None) ->
 
 class ClipStabiliser:
     def __init__(self, out_h: int, out_w: int, n_clips: int = 1, net_hw=(384, 512), scope: str = 'flownetS',
-                 device: Optional[int] = None, homography: bool = False, ransac: Optional[dict] = None, flow_filter=None):
+                 device: Optional[int] = None, homography: bool = False, ransac: Optional[dict] = None, flow_filter=None,
+                 keep_outflow: bool = False):
         """homography=True is the evaluator of main:728-743: the frame WRITTEN is the unstable frame under one
         homography fitted to the dense flow (cv2.findHomography + cv2.warpPerspective), while the history later frames
         read stays the flow-warped frame (main:739).  `ransac` = keyword arguments of postfilters.find_homography.
         `flow_filter` (e.g. postfilters.MeanFlow3Filter(): the highTV evaluator, ...highTV...:629-631) maps the output-resolution flow
-        to the flow that warps."""
+        to the flow that warps.  Without a `flow_filter` a frame is FOUR library calls: the network input assembled straight from
+        the full-resolution frame (cv2.resize inside the launch), the network, ONE launch for swap(frame)/255 -> flow glue ->
+        tf_warp -> uint8(swap(warped*255)) on the 8-bit frames, the history frame resized into its ring slot.  `keep_outflow` also
+        writes the output-resolution flow (`last_outflow`; always on with `homography`)."""
         runtime._require_gpu()
         self.out_h, self.out_w, self.n = int(out_h), int(out_w), int(n_clips)
         self.net_h, self.net_w = int(net_hw[0]), int(net_hw[1])
@@ -63,10 +68,28 @@ class ClipStabiliser:
         self.homography, self.ransac, self.last_homography = bool(homography), dict(ransac or {}), None
         self.last_outflow = None
         self.flow_filter = flow_filter
+        self.keep_outflow = bool(keep_outflow) or self.homography
 
     def reset(self):
         self.i = 0
         self.last_flows = None
+
+    def _step_u8(self, f, i, L):
+        """main:550-558, 568-569, 497-514, 625/630 without a flow filter: (flows, outflow or None, out u8)."""
+        # the eight history slots (null = the resized current frame: a clip's first frame) + the current frame resized inside the kernel
+        ptrs = (C.c_void_p * 8)(*[None if i == 0 else self.ring[max(i - lag, 0) % RING].data_ptr() for lag in STAB_LAGS])
+        out = torch.empty_like(f)
+        outflow = torch.empty((self.n, self.out_h, self.out_w, 2), dtype=torch.float32, device=self.device) if self.keep_outflow else None
+        with torch.cuda.device(self.device):
+            _lib.check(L.vstab_assemble_input_resized(ptrs, f.data_ptr(), self.n, self.net_h, self.net_w, self.out_h, self.out_w,
+                                                      self.feats.data_ptr(), runtime.stream_ptr()))
+        flows = flownetS_pyramid(self.feats, self.n, is_train=False, scope=self.scope)                 # main:569
+        pf2 = flows['predict_flow2']
+        with torch.cuda.device(self.device):
+            _lib.check(L.vstab_flow_glue_warp_u8(pf2.data_ptr(), self.n, pf2.shape[1], pf2.shape[2], f.data_ptr(),
+                                                 outflow.data_ptr() if outflow is not None else None, out.data_ptr(), self.out_h, self.out_w,
+                                                 self.net_h, self.net_w, runtime.stream_ptr()))
+        return flows, outflow, out
 
     def step(self, frame_bgr_u8: torch.Tensor) -> torch.Tensor:
         """One frame of every clip: uint8 [n,out_h,out_w,3] BGR -> stabilised uint8 [n,out_h,out_w,3] BGR."""
@@ -75,24 +98,27 @@ class ClipStabiliser:
             raise ValueError(f"frame must be {(self.n, self.out_h, self.out_w, 3)}, got {tuple(f.shape)}")
         L = _lib.lib()
         i = self.i
-        cur_small = resize_u8(f, (self.net_h, self.net_w))                       # main:550
-        slots = []
-        for lag in STAB_LAGS:                                                    # main:553-558
-            if i == 0:
-                slots.append(cur_small)      # totaloutputFrame[0] is still the raw first frame (main:548-549)
-            else:
-                slots.append(self.ring[max(i - lag, 0) % RING])
-        slots.append(cur_small)
-        ptrs = (C.c_void_p * 9)(*[s.data_ptr() for s in slots])
-        with torch.cuda.device(self.device):
-            _lib.check(L.vstab_assemble_input(ptrs, self.n, self.net_h, self.net_w, self.feats.data_ptr(), runtime.stream_ptr()))
-            _lib.check(L.vstab_frame_to_float(f.data_ptr(), self.n * self.out_h * self.out_w, self.frame_f.data_ptr(),
-                                              runtime.stream_ptr()))                                   # main:568
-        flows, outflow, warped = stabilise_originalsize(self.feats, self.frame_f, scope=self.scope, flow_filter=self.flow_filter)    # main:569
-        out = torch.empty_like(f)
-        with torch.cuda.device(self.device):
-            _lib.check(L.vstab_quantise_output(warped.data_ptr(), self.n * self.out_h * self.out_w, out.data_ptr(),
-                                               runtime.stream_ptr()))                                  # main:625,630
+        if self.flow_filter is None:
+            flows, outflow, out = self._step_u8(f, i, L)
+        else:
+            cur_small = resize_u8(f, (self.net_h, self.net_w))                       # main:550
+            slots = []
+            for lag in STAB_LAGS:                                                    # main:553-558
+                if i == 0:
+                    slots.append(cur_small)      # totaloutputFrame[0] is still the raw first frame (main:548-549)
+                else:
+                    slots.append(self.ring[max(i - lag, 0) % RING])
+            slots.append(cur_small)
+            ptrs = (C.c_void_p * 9)(*[s.data_ptr() for s in slots])
+            with torch.cuda.device(self.device):
+                _lib.check(L.vstab_assemble_input(ptrs, self.n, self.net_h, self.net_w, self.feats.data_ptr(), runtime.stream_ptr()))
+                _lib.check(L.vstab_frame_to_float(f.data_ptr(), self.n * self.out_h * self.out_w, self.frame_f.data_ptr(),
+                                                  runtime.stream_ptr()))                                   # main:568
+            flows, outflow, warped = stabilise_originalsize(self.feats, self.frame_f, scope=self.scope, flow_filter=self.flow_filter)    # main:569
+            out = torch.empty_like(f)
+            with torch.cuda.device(self.device):
+                _lib.check(L.vstab_quantise_output(warped.data_ptr(), self.n * self.out_h * self.out_w, out.data_ptr(),
+                                                   runtime.stream_ptr()))                                  # main:625,630
         resize_u8(out, (self.net_h, self.net_w), out=self.ring[i % RING])        # what later frames read back (main:556), written in place
         self.last_flows, self.last_outflow = flows, outflow
         self.i += 1

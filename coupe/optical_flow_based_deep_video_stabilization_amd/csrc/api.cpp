@@ -1475,6 +1475,28 @@ extern "C" int vstab_assemble_input(const uint8_t *const *slots9, int B, int h, 
     return VSTAB_OK;
 }
 
+extern "C" int vstab_assemble_input_resized(const uint8_t *const *slots8, const uint8_t *frame, int B, int h, int w, int sh, int sw, float *feats,
+                                            void *stream)
+{
+    if (!slots8 || !frame || !feats) return fail(nullptr, VSTAB_E_STATE, "assemble_input_resized: NULL buffer");
+    if (B < 1 || h < 1 || w < 1 || sh < 1 || sw < 1) return fail(nullptr, VSTAB_E_SHAPE, "assemble_input_resized: bad shape");
+    HIP_TRY(nullptr, launch_assemble_input_resized(slots8, frame, B, h, w, sh, sw, feats, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
+extern "C" int vstab_flow_glue_warp_u8(const float *flow, int B, int h, int w, const uint8_t *frame, float *outflow, uint8_t *out, int oh, int ow,
+                                       int net_h, int net_w, void *stream)
+{
+    if (!flow || !frame || !out) return fail(nullptr, VSTAB_E_STATE, "flow_glue_warp_u8: NULL buffer");
+    if (B < 1 || h < 1 || w < 2 || oh < 1 || ow < 1 || net_h < 1 || net_w < 1) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp_u8: bad shape (w >= 2)");
+    if ((long long)B * oh * ow >= (1ll << 31) / 3) return fail(nullptr, VSTAB_E_SHAPE, "flow_glue_warp_u8: 3*B*oh*ow must be < 2^31");
+    if (((uintptr_t)flow & 7) || ((uintptr_t)outflow & 7) || ((uintptr_t)out & 3))
+        return fail(nullptr, VSTAB_E_ALIGN, "flow_glue_warp_u8: flow / outflow 8-byte, out 4-byte alignment");
+    TraceRange range("frame_to_float+flow_glue+tf_warp+quantise");
+    HIP_TRY(nullptr, launch_flow_glue_warp_u8(flow, B, h, w, frame, outflow, out, oh, ow, net_h, net_w, (hipStream_t)stream));
+    return VSTAB_OK;
+}
+
 extern "C" int vstab_frame_to_float(const uint8_t *frame, long long npix, float *out, void *stream)
 {
     if (!frame || !out || npix < 1) return fail(nullptr, VSTAB_E_STATE, "frame_to_float: bad argument");

@@ -145,6 +145,48 @@ hipError_t launch_resize_u8(const unsigned char *src, int B, int sh, int sw, uns
     return hipGetLastError();
 }
 
+// assemble_input with the current frame's cv2.resize inside (main:550 + 553-558 in one launch): slot 8 (and every history slot whose
+// pointer is null: the first frame of a clip, main:548-549) is resize_u8_kernel's pixel computed here from the full-resolution frame
+__global__ __launch_bounds__(256) void assemble_input_resized_kernel(Slots9 s, const unsigned char *__restrict__ frame, int B, int h, int w, int sh,
+                                                                     int sw, float *__restrict__ feats)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * h * w) return;
+    const int n = (int)(idx / (h * w));
+    const int rem = (int)(idx - (long long)n * h * w);
+    const int dy = rem / w, dx = rem - dy * w;
+    const Tap X = cv_tap(dx, w, sw), Y = cv_tap(dy, h, sh);
+    const unsigned char *b = frame + (long long)n * sh * sw * 3;
+    const unsigned char *r0 = b + (long long)Y.i0 * sw * 3, *r1 = b + (long long)Y.i1 * sw * 3;
+    unsigned char cur[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int R0 = r0[X.i0 * 3 + c] * X.a0 + r0[X.i1 * 3 + c] * X.a1;
+        const int R1 = r1[X.i0 * 3 + c] * X.a0 + r1[X.i1 * 3 + c] * X.a1;
+        const int v = (((Y.a0 * (R0 >> 4)) >> 16) + ((Y.a1 * (R1 >> 4)) >> 16) + 2) >> 2;
+        cur[c] = (unsigned char)min(max(v, 0), 255);
+    }
+    float *o = feats + idx * 27;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const unsigned char *q = (j < 8 && s.p[j] != nullptr) ? s.p[j] + idx * 3 : cur;
+        o[3 * j + 0] = (float)q[2] / 255.0f;
+        o[3 * j + 1] = (float)q[1] / 255.0f;
+        o[3 * j + 2] = (float)q[0] / 255.0f;
+    }
+}
+
+hipError_t launch_assemble_input_resized(const unsigned char *const *slots8, const unsigned char *frame, int B, int h, int w, int sh, int sw,
+                                         float *feats, hipStream_t stream)
+{
+    Slots9 s;
+    for (int j = 0; j < 8; ++j) s.p[j] = slots8[j];
+    s.p[8] = nullptr;
+    const long long total = (long long)B * h * w;
+    assemble_input_resized_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(s, frame, B, h, w, sh, sw, feats);
+    return hipGetLastError();
+}
+
 hipError_t launch_assemble_input(const unsigned char *const *slots9, int B, int h, int w, float *feats, hipStream_t stream)
 {
     Slots9 s;

@@ -758,6 +758,128 @@ hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const f
 }
 
 // ---------------------------------------------------------------------------------
+// The evaluator's frame path in ONE launch, 8-bit in and out (main:568, 497-514, 625/630): frame_f = swap(frame)/255, outflow =
+// glue(flow), warped = tf_warp(frame_f, outflow), out = uint8(swap(warped*255)) -- without frame_f and warped ever existing in HBM
+// (the clip driver ran four launches here: frame_to_float, the fused glue + warp, quantise_output; 2 x 12 B/px of fp32 traffic more).
+// Statement for statement those kernels' arithmetic: u8 -> float through a 256-entry table of the IEEE quotients i / 255.0f (what
+// frame_to_float_kernel divides per pixel), the warp as warp3_tile_kernel, the quantiser as quantise_output_kernel (truncation,
+// saturating where numpy is undefined, channels swapped back): identical bytes (tests/test_gpu_clip.py).
+// ---------------------------------------------------------------------------------
+template <bool WRITE_FLOW>
+__global__ __launch_bounds__(256) void warp3_u8_tile_kernel(const unsigned char *__restrict__ img, const float *__restrict__ flow,
+                                                            unsigned char *__restrict__ out, float *__restrict__ outflow, int B, int H, int W,
+                                                            int tiles_x, int tiles_y, GlueParams G)
+{
+    constexpr int WH = WT_WH, WW = WT_WW, TW = WT_TW, PPT = WT_PPT, PPR = TW / WW, TH = WT_TH;
+    __shared__ float lut[256];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[TH * TW * 3];
+    lut[threadIdx.x] = (float)threadIdx.x / 255.0f;                  // 256 threads
+    unsigned bx, by, bz;
+    xcd_remap_calc(gridDim.x, 1, 1, blockIdx.x, bx, by, bz);
+    const int tpi = tiles_x * tiles_y;
+    const int n = (int)bx / tpi, trem = (int)bx - n * tpi;
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long HW = (long long)H * W;
+    int yy[PPT], xx[PPT];
+    bool ok[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int q = j * 4 + wave;
+        yy[j] = ty0 + (q / PPR) * WH + lane / WW;
+        xx[j] = tx0 + (q % PPR) * WW + lane % WW;
+        ok[j] = yy[j] < H && xx[j] < W;
+        if (!ok[j]) { yy[j] = 0; xx[j] = 0; }
+    }
+    f32x2 f[PPT];
+    {
+        f32x2 tl[PPT], tr[PPT], bl[PPT], br[PPT];
+        Lerp Y[PPT], X[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            Y[j] = legacy_coord(yy[j], G.ry, G.h); X[j] = legacy_coord(xx[j], G.rx, G.w);
+            const f32x2 *b = reinterpret_cast<const f32x2 *>(flow) + (long long)n * G.h * G.w;
+            const int xb = min(X[j].lo, G.w - 2);
+            const flow2 top = *reinterpret_cast<const flow2 *>(b + Y[j].lo * G.w + xb), bot = *reinterpret_cast<const flow2 *>(b + Y[j].hi * G.w + xb);
+            const bool l1 = X[j].lo != xb, h1 = X[j].hi != xb;
+            tl[j] = l1 ? top.b : top.a; tr[j] = h1 ? top.b : top.a;
+            bl[j] = l1 ? bot.b : bot.a; br[j] = h1 ? bot.b : bot.a;
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            f[j].x = glue_post_x(lerp2(glue_pre(tl[j].x, G), glue_pre(tr[j].x, G), glue_pre(bl[j].x, G), glue_pre(br[j].x, G), X[j].t, Y[j].t), G);
+            f[j].y = glue_post_y(lerp2(glue_pre(tl[j].y, G), glue_pre(tr[j].y, G), glue_pre(bl[j].y, G), glue_pre(br[j].y, G), X[j].t, Y[j].t), G);
+            if (WRITE_FLOW && ok[j]) reinterpret_cast<f32x2 *>(outflow)[n * HW + (long long)yy[j] * W + xx[j]] = f[j];
+        }
+    }
+    __syncthreads();                                                  // the table
+    const unsigned char *b8 = img + n * HW * 3;
+    float wa[PPT], wb[PPT], wc[PPT], wd[PPT];
+    rgb3 Ia[PPT], Ib[PPT], Ic[PPT], Id[PPT];
+    auto px = [&](int y, int x) {                                     // swap(frame)/255: channels 2, 1, 0 of the BGR pixel
+        const unsigned char *q = b8 + ((long long)y * W + x) * 3;
+        rgb3 r; r.r = lut[q[2]]; r.g = lut[q[1]]; r.b = lut[q[0]];
+        return r;
+    };
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const float x = (float)xx[j] + f[j].x, y = (float)yy[j] + f[j].y;
+        int x0 = (int)fminf(fmaxf(x, -2.f), (float)W), y0 = (int)fminf(fmaxf(y, -2.f), (float)H);
+        int x1 = x0 + 1, y1 = y0 + 1;
+        x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1);
+        y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
+        const float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
+        wa[j] = (x1f - x) * (y1f - y); wb[j] = (x1f - x) * (y - y0f);
+        wc[j] = (x - x0f) * (y1f - y); wd[j] = (x - x0f) * (y - y0f);
+        Ia[j] = px(y0, x0); Ib[j] = px(y1, x0); Ic[j] = px(y0, x1); Id[j] = px(y1, x1);
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        float r[3];
+        r[0] = ((wa[j] * Ia[j].r + wb[j] * Ib[j].r) + wc[j] * Ic[j].r) + wd[j] * Id[j].r;      // tf.add_n order
+        r[1] = ((wa[j] * Ia[j].g + wb[j] * Ib[j].g) + wc[j] * Ic[j].g) + wd[j] * Id[j].g;
+        r[2] = ((wa[j] * Ia[j].b + wb[j] * Ib[j].b) + wc[j] * Ic[j].b) + wd[j] * Id[j].b;
+        const int q = j * 4 + wave;
+        unsigned char *o = stage + (((q / PPR) * WH + lane / WW) * TW + (q % PPR) * WW + lane % WW) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (unsigned char)fminf(fmaxf(truncf(r[2 - c] * 255.0f), 0.f), 255.f);   // quantise_output_kernel's
+    }
+    __syncthreads();
+    // a tile row is TW*3 = 96 bytes; 4-byte stores where rows start on a 4-byte boundary (W % 4 == 0), bytes otherwise / at a ragged edge
+    const int vw3 = min(TW, W - tx0) * 3;
+    if ((W & 3) == 0) {
+        constexpr int R4 = TW * 3 / 4;
+        for (int e = threadIdx.x; e < TH * R4; e += 256) {
+            const int row = e / R4, c4 = e - row * R4;
+            if (ty0 + row >= H || c4 * 4 >= vw3) continue;
+            unsigned char *o = out + (n * HW + (long long)(ty0 + row) * W + tx0) * 3 + c4 * 4;
+            if (c4 * 4 + 4 <= vw3) *reinterpret_cast<unsigned *>(o) = *reinterpret_cast<const unsigned *>(stage + row * TW * 3 + c4 * 4);
+            else for (int i = 0; c4 * 4 + i < vw3; ++i) o[i] = stage[row * TW * 3 + c4 * 4 + i];
+        }
+    } else {
+        for (int e = threadIdx.x; e < TH * TW * 3; e += 256) {
+            const int row = e / (TW * 3), c = e - row * (TW * 3);
+            if (ty0 + row < H && c < vw3) out[(n * HW + (long long)(ty0 + row) * W + tx0) * 3 + c] = stage[e];
+        }
+    }
+}
+
+hipError_t launch_flow_glue_warp_u8(const float *flow, int B, int h, int w, const unsigned char *frame, float *outflow, unsigned char *out, int oh,
+                                    int ow, int net_h, int net_w, hipStream_t stream)
+{
+    const long long total = (long long)B * oh * ow;
+    if (total == 0) return hipSuccess;
+    const int tx = (ow + WT_TW - 1) / WT_TW, ty = (oh + WT_TH - 1) / WT_TH;
+    if (w < 2 || total >= (1ll << 31) / 3 || (long long)tx * ty * B >= (1ll << 31) || ((uintptr_t)flow & 7) || ((uintptr_t)outflow & 7) || ((uintptr_t)out & 3))
+        return hipErrorInvalidValue;
+    const GlueParams G = glue_params(h, w, oh, ow, net_h, net_w);
+    const dim3 grid((unsigned)((long long)tx * ty * B)), block(256);
+    const double src = 8.0 * B * h * w;                       // 3 B/px frame + 3 B/px out (+ 8 B/px flow written)
+    if (outflow) return launch_timed(HBM_SLOT_GLUE_WARP, src + 14.0 * total, warp3_u8_tile_kernel<true>, grid, block, stream, frame, flow, out, outflow, B, oh, ow, tx, ty, G);
+    return launch_timed(HBM_SLOT_GLUE_WARP, src + 6.0 * total, warp3_u8_tile_kernel<false>, grid, block, stream, frame, flow, out, (float *)nullptr, B, oh, ow, tx, ty, G);
+}
+
+// ---------------------------------------------------------------------------------
 // The stand-alone glue (main:497-498, for callers that filter the flow between glue and warp) and the 3-channel legacy-bilinear
 // resize (main:806: the unstable frame -- channels 24:27 of the 27-channel stack, read in place through `Cs` / `c_off` -- to
 // the flow grid; main:202-203) on the warp's tile mapping: 16 x 32 pixel tiles, 4 x 16 wave patches, the left/right taps of a

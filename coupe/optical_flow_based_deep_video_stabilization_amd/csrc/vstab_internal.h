@@ -312,6 +312,12 @@ hipError_t launch_vec2mtrx(const float *p, int B, int dim, int approx, float *ou
 hipError_t launch_resize_u8(const unsigned char *src, int B, int sh, int sw, unsigned char *dst, int dh, int dw, hipStream_t stream);
 hipError_t launch_resize_f32_to_u8(const float *src, int B, int sh, int sw, unsigned char *dst, int dh, int dw, hipStream_t stream);
 hipError_t launch_assemble_input(const unsigned char *const *slots9, int B, int h, int w, float *feats, hipStream_t stream);
+// the same with the current frame's cv2.resize inside: slots8[j] == null reads the resized current frame (a clip's first frame)
+hipError_t launch_assemble_input_resized(const unsigned char *const *slots8, const unsigned char *frame, int B, int h, int w, int sh, int sw,
+                                         float *feats, hipStream_t stream);
+// frame_to_float + flow glue + tf_warp + quantise_output in one launch on 8-bit frames (flow_ops.hip)
+hipError_t launch_flow_glue_warp_u8(const float *flow, int B, int h, int w, const unsigned char *frame, float *outflow, unsigned char *out, int oh,
+                                    int ow, int net_h, int net_w, hipStream_t stream);
 hipError_t launch_frame_to_float(const unsigned char *f, long long npix, float *out, hipStream_t stream);
 hipError_t launch_quantise_output(const float *warped, long long npix, unsigned char *out, hipStream_t stream);
 

@@ -266,6 +266,15 @@ VSTAB_API int vstab_resize_f32_to_u8(const float *src, int B, int sh, int sw, ui
 /* curinput (main:550-558): feats[B,h,w,27]; slot j < 8 = history frame of lag {31,23,15,7,4,3,2,1}[j], slot 8 = current
  * frame, each u8 [B,h,w,3] at network resolution; channels swapped (COLOR_RGB2BGR) and divided by 255. */
 VSTAB_API int vstab_assemble_input(const uint8_t *const *slots9, int B, int h, int w, float *feats, void *stream);
+/* The same with the current frame's cv2.resize inside (main:550 + 553-558 as one launch): frame u8 [B,sh,sw,3] at its own resolution;
+ * slots8[j] == NULL reads the resized current frame (the first frame of a clip, main:548-549). */
+VSTAB_API int vstab_assemble_input_resized(const uint8_t *const *slots8, const uint8_t *frame, int B, int h, int w, int sh, int sw,
+                                           float *feats, void *stream);
+/* The evaluator's frame path on 8-bit frames in ONE launch (main:568, 497-514, 625/630): out = uint8(swap(tf_warp(swap(frame)/255,
+ * glue(flow)) * 255)); the fp32 frame and the fp32 warped frame never exist.  flow [B,h,w,2] (predict_flow2), frame / out u8
+ * [B,oh,ow,3] BGR, outflow [B,oh,ow,2] or NULL.  Identical bytes to vstab_frame_to_float + vstab_flow_glue_warp + vstab_quantise_output. */
+VSTAB_API int vstab_flow_glue_warp_u8(const float *flow, int B, int h, int w, const uint8_t *frame, float *outflow, uint8_t *out, int oh, int ow,
+                                      int net_h, int net_w, void *stream);
 /* resizedInput (main:568): swap(frame)/255 -> float [npix,3]. */
 VSTAB_API int vstab_frame_to_float(const uint8_t *frame, long long npix, float *out, void *stream);
 /* np.uint8(swap(warped*255)) (main:625,630,556): float [npix,3] -> u8, truncating, saturating outside [0,255]. */

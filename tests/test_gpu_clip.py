@@ -141,3 +141,48 @@ def test_hightv_mean_flow_evaluator():
     assert (diff > 1).mean() < 2e-3 and (diff > 0).mean() < 0.03, ((diff > 1).mean(), (diff > 0).mean())
     plain = clip_driver.ClipStabiliser(H, W, n_clips=1, net_hw=(nh, nw)).run(torch.from_numpy(clip).cuda()).cpu().numpy()
     assert np.abs(plain.astype(np.int32) - out.astype(np.int32)).mean() > 0.05          # the filter changes the result
+
+
+@pytest.mark.parametrize("n,oh,ow,nh,nw", [(1, 720, 1280, 384, 512), (2, 96, 120, 48, 64), (3, 37, 53, 64, 96), (1, 64, 64, 64, 64)])
+def test_eight_bit_frame_path_in_one_launch_is_byte_identical(n, oh, ow, nh, nw):
+    """vstab_flow_glue_warp_u8 (swap(frame)/255 -> flow glue -> tf_warp -> uint8(swap(warped*255)) in one launch, main:568, 497-514,
+    625/630) and vstab_assemble_input_resized (cv2.resize inside the network-input assembly, main:550-558) against the launches they
+    replace: identical bytes / floats, ragged widths and null history slots (a clip's first frame) included."""
+    import ctypes as C
+    from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
+    L = _lib.lib()
+    st = runtime.stream_ptr()
+    g = torch.Generator().manual_seed(oh * 7 + ow)
+    frame = torch.randint(0, 256, (n, oh, ow, 3), dtype=torch.uint8, generator=g).cuda()
+    pf2 = (torch.randn(n, nh - 2, nw - 2, 2, generator=g) * 5).cuda()
+    pf2[0, 0, 0] = torch.tensor([-0.5, -0.25])                       # an extrapolating corner: values outside [0, 1] reach the quantiser
+    # reference: three launches
+    ff = torch.empty((n, oh, ow, 3), dtype=torch.float32, device="cuda")
+    _lib.check(L.vstab_frame_to_float(frame.data_ptr(), n * oh * ow, ff.data_ptr(), st))
+    outflow, warped = vs.flow_glue_warp(pf2, ff, nh, nw) if (ow % 4 == 0) else (vs.flow_to_output_res(pf2, nh, nw, oh, ow), None)
+    if warped is None:
+        warped = vs.tf_warp(ff, outflow, oh, ow)
+    ref = torch.empty_like(frame)
+    _lib.check(L.vstab_quantise_output(warped.data_ptr(), n * oh * ow, ref.data_ptr(), st))
+    for want_flow in (True, False):
+        out = torch.zeros_like(frame)
+        of = torch.zeros((n, oh, ow, 2), dtype=torch.float32, device="cuda") if want_flow else None
+        _lib.check(L.vstab_flow_glue_warp_u8(pf2.data_ptr(), n, nh - 2, nw - 2, frame.data_ptr(), of.data_ptr() if want_flow else None,
+                                             out.data_ptr(), oh, ow, nh, nw, st))
+        assert torch.equal(out, ref)
+        if want_flow:
+            assert torch.equal(of, outflow)
+    # network-input assembly with the resize inside
+    hist = [torch.randint(0, 256, (n, nh, nw, 3), dtype=torch.uint8, generator=g).cuda() for _ in range(8)]
+    small = clip_driver.resize_u8(frame, (nh, nw))
+    for first in (False, True):
+        slots = [small] * 8 if first else hist
+        p9 = (C.c_void_p * 9)(*[t.data_ptr() for t in slots + [small]])
+        a = torch.empty((n, nh, nw, 27), dtype=torch.float32, device="cuda")
+        _lib.check(L.vstab_assemble_input(p9, n, nh, nw, a.data_ptr(), st))
+        p8 = (C.c_void_p * 8)(*[None if first else t.data_ptr() for t in hist])
+        b = torch.empty_like(a)
+        _lib.check(L.vstab_assemble_input_resized(p8, frame.data_ptr(), n, nh, nw, oh, ow, b.data_ptr(), st))
+        assert torch.equal(a, b)
+    assert L.vstab_flow_glue_warp_u8(None, n, nh - 2, nw - 2, frame.data_ptr(), None, ref.data_ptr(), oh, ow, nh, nw, st) == -6
+    assert L.vstab_assemble_input_resized(p8, None, n, nh, nw, oh, ow, b.data_ptr(), st) == -6
