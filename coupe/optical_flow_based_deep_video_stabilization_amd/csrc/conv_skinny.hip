@@ -190,10 +190,10 @@ __global__ __launch_bounds__(256) void conv_skinny_kernel(const ConvParams p, un
     }
 
     const int ks = p.ksplit;
-    const long long slab = (long long)p.Mmax * p.Npad;                // floats per (phase, split) slab
-    const __amdgpu_buffer_rsrc_t rpz = __builtin_amdgcn_make_buffer_rsrc(
-        p.partial + (long long)phase * ks * slab, 0, (unsigned)min((long long)ks * slab * 4, 0xFFFFFFFFLL), 0x00020000);
     if (ks > 1) {
+        const long long slab = (long long)p.Mmax * p.Npad;            // floats per (phase, split) slab
+        const __amdgpu_buffer_rsrc_t rpz = __builtin_amdgcn_make_buffer_rsrc(
+            p.partial + (long long)phase * ks * slab, 0, (unsigned)min((long long)ks * slab * 4, 0xFFFFFFFFLL), 0x00020000);
         // publish this slice's tile write-through, drain, ticket
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
