@@ -239,7 +239,10 @@ def check_internals(feats, w, ref_int):
 # sizes chosen to hit every first-layer path: row-window kernel (W*Cin % 4 == 0, Cin 27 and 6),
 # generic dword-gather kernel (70x90x27: W*Cin % 4 == 2) and the generic 16-byte kernel (Cin 28)
 @pytest.mark.parametrize("B,H,W,cin,seed", [(2, 64, 64, 27, 3), (1, 88, 104, 27, 4), (1, 70, 90, 6, 5), (3, 48, 64, 28, 6),
-                                            (1, 70, 90, 27, 7), (2, 136, 264, 27, 8)])
+                                            (1, 70, 90, 27, 7), (2, 136, 264, 27, 8),
+                                            # one sample at BASELINE configs[0]'s size and at the reference's own (main:540-630): the round-4
+                                            # schedule -- weight-stream layers, two-problem launches, 4x4 predict_up tiles -- layer by layer
+                                            (1, 256, 256, 27, 9), (1, 384, 512, 27, 10)])
 def test_network_every_layer_vs_oracle(B, H, W, cin, seed):
     w = wts.synthetic_weights(seed=seed, cin=cin, random_bn=True, flow_gain=2.0)
     feats = np.random.default_rng(seed).random((B, H, W, cin), dtype=np.float32)
