@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 4, visit h: tap tiles dispatched first in the two-problem launch; A/B at the headline shape of flags 0 (two-problem launch only
 # while co-resident) vs 4 (always) and the one-sample shapes again (dispatch order changed)
+# HISTORICAL: plan flag 4 ('two-problem launch always') existed only in the build this visit measured; the product now dispatches the tap
+# tiles first whenever the pair is not co-resident (csrc/conv_mfma.hip, conv_dual_kernel).  Kept as the record of how ab_r04h_* was taken.
 set -u
 tag=${1:-r04h}
 mkdir -p gpurun_out; export TMPDIR=/tmp

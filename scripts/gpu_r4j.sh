@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 4, visit j: chained combines (conv_chain_kernel).  The new tests first, under a short time limit of their own (a hand-off bug must
 # not sit on the GPU); only then the suite and the A/B.
+# HISTORICAL: needs tools/chain_combine_r04.diff applied (plan flag 4 = no chained combines, 7 = the round-3 schedule in that build); kept as the
+# record of how profiles/ab_r04j_chained_combines_negative.txt was taken.
 set -u
 tag=${1:-r04j}
 mkdir -p gpurun_out; export TMPDIR=/tmp
