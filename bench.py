@@ -65,19 +65,17 @@ def host_cpu_share():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(batch, H, W, Cin, weights, seconds_budget=20.0):
+def cpu_baseline(feats, frame, weights, seconds_budget=20.0):
     """The CPU restatement (oracle, torch fp32 on all host cores) timed on a bounded sample
-    of the same workload.  kind = "port": TensorFlow 1.10 cannot exist on this box."""
+    of the same workload: `feats` / `frame` are the FIRST samples of the batch the GPU was timed on (host copies).
+    kind = "port": TensorFlow 1.10 cannot exist on this box.  Returns (record, outputs of one pass)."""
     from oracle import vstab_oracle as vo
     threads = host_cpu_share()
     torch.set_num_threads(threads)
-    rng = np.random.default_rng(0)
-    nb = min(batch, 2)
-    feats = rng.random((nb, H, W, Cin), dtype=np.float32)
-    frame = rng.random((nb, H, W, 3), dtype=np.float32)
+    nb, H, W, Cin = feats.shape
     with torch.no_grad():
         t0 = time.perf_counter()
-        vo.stabilise_originalsize(feats, frame, weights, torch.float32)       # warm-up
+        ref = vo.stabilise_originalsize(feats, frame, weights, torch.float32)       # warm-up; its outputs feed flow_err
         warm = time.perf_counter() - t0
         times = []
         while len(times) < 5 and (sum(times) + warm) < seconds_budget:
@@ -88,8 +86,57 @@ def cpu_baseline(batch, H, W, Cin, weights, seconds_budget=20.0):
             times = [warm]
     med = float(np.median(times))
     return {"value": nb / med, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{len(times)} timed passes of a batch of {nb} {H}x{W}x{Cin} samples "
-                      f"(network + flow glue + warp), torch-CPU fp32 restatement of the TF graph"}
+            "sample": f"{len(times)} timed passes of the first {nb} samples of the timed GPU batch ({H}x{W}x{Cin}: "
+                      f"network + flow glue + warp), torch-CPU fp32 restatement of the TF graph"}, ref
+
+
+FLOW_ERR_TOL = 1e-3          # BASELINE.json north_star: flows and warped frames within 1e-3 max-abs on fp32
+
+
+def flow_error(gpu_out, feats, frame, weights, ref32=None, want_fp64=True):
+    """The metric's second half ("+ max-abs flow err vs TF CPU", BASELINE.json): the outputs of the LAST timed step on the GPU
+    against the CPU restatement run on the same first `nb` samples of the timed batch.  `vs_fp32` = the torch-CPU fp32
+    restatement (the pass cpu_baseline times; its own rounding is in the figure), `vs_fp64` = the same graph in fp64 (the
+    arbiter the parity tests use).  Warped frames are compared away from tf_warp's discontinuity lines (x = -1, W-1; y = -1, H-1),
+    where a flow that differs by rounding legitimately picks another branch."""
+    from oracle import vstab_oracle as vo
+    torch.set_num_threads(host_cpu_share())
+    flows_g, outflow_g, warped_g = gpu_out
+    nb = feats.shape[0]
+    oh, ow = frame.shape[1], frame.shape[2]
+    g_flows = {k: flows_g[k][:nb].double().cpu() for k in vo.FLOW_KEYS}
+    g_out = outflow_g[:nb].double().cpu() if outflow_g is not None else None
+    g_warp = warped_g[:nb].double().cpu()
+
+    def against(ref):
+        rf, ro, rw = ref
+        lv = {k: float((g_flows[k] - rf[k].double()).abs().max()) for k in vo.FLOW_KEYS}
+        if g_out is not None:
+            lv["outflow"] = float((g_out - ro.double()).abs().max())
+        mask = vo.warp_discontinuity_mask(ro, oh, ow)
+        if g_out is not None:
+            mask &= vo.warp_discontinuity_mask(g_out, oh, ow)
+        dw = (g_warp - rw.double()).abs().amax(dim=3)
+        return {"max_abs": {k: float(f"{v:.3e}") for k, v in lv.items()},
+                "warped_max_abs_masked": float(f"{float(dw[mask].max()):.3e}"),
+                "warped_pixels_masked_out": int((~mask).sum()),
+                "max_abs_flow": {k: round(float(rf[k].abs().max()), 2) for k in vo.FLOW_KEYS}}
+
+    with torch.no_grad():
+        if ref32 is None:
+            ref32 = vo.stabilise_originalsize(feats, frame, weights, torch.float32)
+        r32 = against(ref32)
+        r64 = against(vo.stabilise_originalsize(feats, frame, weights, torch.float64)) if want_fp64 else None
+    worst = max(list(r32["max_abs"].values()) + [r32["warped_max_abs_masked"]])
+    res = {"max_abs": r32["max_abs"], "warped_max_abs_masked": r32["warped_max_abs_masked"],
+           "warped_pixels_masked_out": r32["warped_pixels_masked_out"], "max_abs_flow": r32["max_abs_flow"],
+           "vs": "torch-CPU fp32 restatement of the TF graph on the same inputs (parity unpinned: TensorFlow 1.10 cannot run here)",
+           "samples": nb, "of_step": "last timed step", "tol": FLOW_ERR_TOL, "worst": worst, "within_tol": bool(worst <= FLOW_ERR_TOL)}
+    if r64 is not None:
+        w64 = max(list(r64["max_abs"].values()) + [r64["warped_max_abs_masked"]])
+        res["vs_fp64"] = {"max_abs": r64["max_abs"], "warped_max_abs_masked": r64["warped_max_abs_masked"], "worst": w64,
+                          "within_tol": bool(w64 <= FLOW_ERR_TOL), "vs": "the same restatement in fp64 (the parity tests' arbiter)"}
+    return res
 
 
 def secondary_rows(vs, runtime, log):
@@ -156,6 +203,10 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--cin", type=int, default=27)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-flow-err", action="store_true",
+                    help="skip the flow_err block (the last timed step's flows and warped frame against the CPU restatement on the same inputs)")
+    ap.add_argument("--err-samples", type=int, default=2, help="samples of the timed batch the CPU restatement is run on")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of warped frames (N>1)")
     ap.add_argument("--gather-schedule", choices=("allgather", "direct"), default="allgather",
                     help="reassembly over RCCL: one all-gather per step, or world-1 point-to-point pushes per rank (all xGMI links at once)")
@@ -349,6 +400,14 @@ def main():
                                           drain=flush_and_drain if (gather is not None or grouped is not None) else None, before_timed=profilers_on,
                                           device="cpu" if args.backend == "gloo" else "cuda")
 
+    # the last timed step's outputs (first --err-samples samples), copied now: later legs reuse the workspace and the output buffers
+    err_nb = max(1, min(B, args.err_samples))
+    err_out = None
+    if rank == 0 and not args.no_flow_err and args.st_warp == "none":
+        fl_, of_, wf_ = out
+        err_out = ({k: v[:err_nb].clone() for k, v in fl_.items()}, of_[:err_nb].clone() if of_ is not None else None, wf_[:err_nb].clone())
+        torch.cuda.synchronize()
+
     if dbg:
         for i, r in enumerate(dbg[-args.steps:]):
             log(f"step {i:3d} host ms: path {r[0] * 1e3:7.3f}  quantise {r[1] * 1e3:7.3f}  submit {r[2] * 1e3:7.3f}")
@@ -534,14 +593,27 @@ def main():
     if rank == 0 and world == 1 and dist is None and not args.no_secondary and graph is None:
         res["secondary"] = secondary_rows(vs, runtime, log)
     if rank == 0:
+        nb = err_nb
+        feats_h, frame_h = feats[:nb].cpu().numpy(), frame[:nb].cpu().numpy()
+        ref32 = None
         if not args.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(B, H, W, Cin, weights)
+                res["cpu_baseline"], ref32 = cpu_baseline(feats_h, frame_h, weights, args.cpu_seconds)
             except Exception as e:   # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "frame-pairs/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
         else:
             res["cpu_baseline"] = None
+        # ---- the metric's second half: max-abs flow error of the timed workload (last timed step) vs the CPU restatement, same inputs
+        if err_out is not None:
+            try:
+                res["flow_err"] = flow_error(err_out, feats_h, frame_h, weights, ref32)
+                fe = res["flow_err"]
+                log(f"flow_err vs fp32 restatement: worst {fe['worst']:.3e} (tol {FLOW_ERR_TOL:g}), max |flow| {fe['max_abs_flow']}")
+            except Exception as e:   # noqa: BLE001
+                res["flow_err"] = {"error": repr(e)[:300]}
+        else:
+            res["flow_err"] = None
         print(json.dumps(res), file=real_stdout, flush=True)
     if dist is not None:
         dist.barrier()

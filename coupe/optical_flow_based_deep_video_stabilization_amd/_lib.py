@@ -29,6 +29,7 @@ EXPORTS = {
     "vstab_load_weights": (C.c_int, [C.c_void_p, C.POINTER(VstabTensor), C.c_int]),
     "vstab_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "vstab_workspace_layout": (C.c_int, [C.c_int] * 4 + [C.POINTER(VstabWsEntry), C.c_int]),
+    "vstab_workspace_layout_ctx": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.POINTER(VstabWsEntry), C.c_int]),
     "vstab_set_plan_batch": (C.c_int, [C.c_void_p, C.c_int]),
     "vstab_set_plan_flags": (C.c_int, [C.c_void_p, C.c_uint]),
     "vstab_workspace_bytes_ctx": (C.c_size_t, [C.c_void_p] + [C.c_int] * 4),

@@ -84,9 +84,12 @@ const int PRED_CIN[4] = {1024, 1026, 770, 386};             // predict6,5,4,3
 const int PRED_CS[4] = {1024, 1028, 772, 388};
 
 enum Buf { B_CONV1, B_CONCAT2, B_CONV3, B_CONCAT3, B_CONV4, B_CONCAT4, B_CONV5, B_CONCAT5, B_CONV6, B_CONV6_1, B_T,
-           B_T6, B_T5, B_T4, B_T3, B_PARTIAL, B_WINO_V, B_WINO_M, N_BUF };
+           B_T6, B_T5, B_T4, B_T3, B_TICKETS, B_PARTIAL, B_WINO_V, B_WINO_M, N_BUF };
+// B_PARTIAL, B_WINO_V, B_WINO_M stay LAST: their sizes depend on plan decisions (split-K factors, Winograd or direct) that a pinned
+// plan may change, while every offset before them depends on the shape alone (vstab_workspace_layout relies on it)
+static_assert(B_PARTIAL == N_BUF - 3 && B_WINO_V == N_BUF - 2 && B_WINO_M == N_BUF - 1, "plan-dependent buffers must come last");
 const char *BUF_NAME[N_BUF] = {"conv1", "concat2", "conv3", "concat3", "conv4", "concat4", "conv5", "concat5",
-                               "conv6", "conv6_1", "pf2_taps", "pf6_taps", "pf5_taps", "pf4_taps", "pf3_taps", "splitk", "winograd_in", "winograd_out"};
+                               "conv6", "conv6_1", "pf2_taps", "pf6_taps", "pf5_taps", "pf4_taps", "pf3_taps", "tickets", "splitk", "winograd_in", "winograd_out"};
 
 // where each encoder stage reads and writes: {in buf (-1 = feats), out buf, out stride, used in channels, in stride}
 struct EncIO { int in_buf, out_buf, cs_out, cs_in; };
@@ -318,6 +321,7 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl, const PlanPin *pin = null
     setbuf(B_T5, pl.eh[7], pl.ew[7], 32, 32);
     setbuf(B_T4, pl.eh[5], pl.ew[5], 32, 32);
     setbuf(B_T3, pl.eh[3], pl.ew[3], 32, 32);
+    setbuf(B_TICKETS, 0, 0, 0, 0);
     setbuf(B_PARTIAL, 0, 0, 0, 0);
     setbuf(B_WINO_V, 0, 0, 0, 0);
     setbuf(B_WINO_M, 0, 0, 0, 0);
@@ -326,6 +330,9 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl, const PlanPin *pin = null
         if (n > lim) return false;
         pl.bytes[b] = (size_t)n * 4;
     }
+    // ticket words of the in-launch split-K reductions (conv_skinny.hip): per WORKSPACE, so forwards on one context that use distinct
+    // workspaces never share them; zeroed by a memset node at the start of every forward that has such a layer
+    pl.bytes[B_TICKETS] = SKINNY_MAX_TILES * sizeof(unsigned);
 
     // ---- encoder convs
     size_t partial_floats = 0;
@@ -520,14 +527,6 @@ extern "C" int vstab_create(vstab_ctx **out, int device)
     vstab_ctx *c = new (std::nothrow) vstab_ctx();
     if (!c) return fail(nullptr, VSTAB_E_NOMEM, "vstab_create: out of host memory");
     c->device = device;
-    // ticket words of the in-launch split-K reductions (conv_skinny.hip): zero here, and every launch leaves them zero
-    hipError_t te = hipMalloc(reinterpret_cast<void **>(&c->tickets), SKINNY_MAX_TILES * sizeof(unsigned));
-    if (te == hipSuccess) te = hipMemset(c->tickets, 0, SKINNY_MAX_TILES * sizeof(unsigned));
-    if (te != hipSuccess) {
-        if (c->tickets) (void)hipFree(c->tickets);
-        delete c;
-        return fail(nullptr, VSTAB_E_NOMEM, "vstab_create: ticket words: %s", hipGetErrorString(te));
-    }
     *out = c;
     return VSTAB_OK;
 }
@@ -536,7 +535,6 @@ extern "C" void vstab_destroy(vstab_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->dev_weights) (void)hipFree(ctx->dev_weights);
-    if (ctx->tickets) (void)hipFree(ctx->tickets);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->vgg_weights) (void)hipFree(ctx->vgg_weights);
     vstab_nldf_free(ctx->nldf);
@@ -614,23 +612,33 @@ extern "C" size_t vstab_workspace_bytes_ctx(const vstab_ctx *ctx, int B, int H, 
     return pl.total;
 }
 
-extern "C" int vstab_workspace_layout(int B, int H, int W, int Cin, vstab_ws_entry *entries, int max_entries)
+static int workspace_layout_of(const PlanPin *pin, int chunk, int H, int W, int Cin, vstab_ws_entry *entries, int max_entries)
 {
     Plan pl;
-    const int chunk = B >= 1 ? max_chunk(B, H, W, Cin) : 0;     // the workspace holds one chunk of the batch
-    if (!entries || chunk < 1 || !make_plan(chunk, H, W, Cin, pl))
-        return fail(nullptr, VSTAB_E_SHAPE, "unsupported problem %dx%dx%dx%d", B, H, W, Cin);
-    B = chunk;
+    if (!entries || chunk < 1 || !make_plan(chunk, H, W, Cin, pl, pin))
+        return fail(nullptr, VSTAB_E_SHAPE, "unsupported problem %dx%dx%dx%d", chunk, H, W, Cin);
     int n = 0;
     for (int b = 0; b < N_BUF && n < max_entries; ++b) {
         vstab_ws_entry &e = entries[n++];
         std::memset(&e, 0, sizeof e);
         std::snprintf(e.name, sizeof e.name, "%s", BUF_NAME[b]);
         e.offset_bytes = (int64_t)pl.off[b];
-        e.n = B; e.h = pl.buf_h[b]; e.w = pl.buf_w[b]; e.c = pl.buf_c[b]; e.c_stride = pl.buf_cs[b];
-        if (b == B_PARTIAL || b == B_WINO_V || b == B_WINO_M) { e.n = 1; e.h = 1; e.w = (int32_t)std::min<size_t>(pl.bytes[b] / 4, 0x7fffffff); e.c = 1; e.c_stride = 1; }
+        e.n = chunk; e.h = pl.buf_h[b]; e.w = pl.buf_w[b]; e.c = pl.buf_c[b]; e.c_stride = pl.buf_cs[b];
+        if (b == B_TICKETS || b == B_PARTIAL || b == B_WINO_V || b == B_WINO_M) { e.n = 1; e.h = 1; e.w = (int32_t)std::min<size_t>(pl.bytes[b] / 4, 0x7fffffff); e.c = 1; e.c_stride = 1; }
     }
     return n;
+}
+
+extern "C" int vstab_workspace_layout(int B, int H, int W, int Cin, vstab_ws_entry *entries, int max_entries)
+{
+    return workspace_layout_of(nullptr, B >= 1 ? max_chunk(B, H, W, Cin) : 0, H, W, Cin, entries, max_entries);     // the workspace holds one chunk of the batch
+}
+
+extern "C" int vstab_workspace_layout_ctx(const vstab_ctx *ctx, int B, int H, int W, int Cin, vstab_ws_entry *entries, int max_entries)
+{
+    const PlanPin pin = pin_of(ctx);
+    if (pin.batch > 0 && B > pin.batch) return fail(nullptr, VSTAB_E_SHAPE, "batch %d exceeds the pinned plan batch %d", B, pin.batch);
+    return workspace_layout_of(&pin, B >= 1 ? chunk_size(pin, B, H, W, Cin) : 0, H, W, Cin, entries, max_entries);
 }
 
 // ------------------------------------------------------------------------- host-only helpers
@@ -848,6 +856,13 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
     char *ws = (char *)workspace;
     auto buf = [&](int b) { return (float *)(ws + pl.off[b]); };
     const float *dw = ctx->dev_weights;
+    // the weight-stream layers finish their split-K inside the launch by tickets (conv_skinny.hip).  The words live in THIS workspace and
+    // are zeroed here: a launch leaves them zero, but the workspace is the caller's (first use, reuse of freed memory) and a launch that
+    // failed mid-flight leaves them dirty
+    unsigned *tickets = reinterpret_cast<unsigned *>(buf(B_TICKETS));
+    bool any_tickets = false;
+    for (int i = 0; i < 14; ++i) any_tickets = any_tickets || (pl.skinny[i] && pl.cp[i].ksplit > 1);
+    if (any_tickets) HIP_TRY(ctx, hipMemsetAsync(tickets, 0, pl.bytes[B_TICKETS], stream));
 
     // optional per-launch events
     hipEvent_t *ev = nullptr;
@@ -942,7 +957,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         p.bias = dw + ctx->enc_b[i];
         p.partial = buf(B_PARTIAL);
         if (pl.skinny[i]) {
-            HIP_TRY(ctx, launch_conv_skinny(p, ctx->tickets, stream, EV_A(i), EV_B(i)));
+            HIP_TRY(ctx, launch_conv_skinny(p, tickets, stream, EV_A(i), EV_B(i)));
             ctx->prof_kernel[i] = "conv_skinny_kernel<1, 4>";
             continue;
         }
@@ -998,7 +1013,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         }
         TraceRange layer_range(DEC_RANGE[l]);
         if (pl.skinny[10 + l]) {
-            HIP_TRY(ctx, launch_conv_skinny(pd, ctx->tickets, stream, EV_A(10 + l), EV_B(10 + l)));
+            HIP_TRY(ctx, launch_conv_skinny(pd, tickets, stream, EV_A(10 + l), EV_B(10 + l)));
             ctx->prof_kernel[10 + l] = "conv_skinny_kernel<1, 4>";
         } else {
             HIP_TRY(ctx, launch_conv(pd, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l)));

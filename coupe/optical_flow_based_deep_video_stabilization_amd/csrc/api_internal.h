@@ -29,7 +29,6 @@ struct vstab_ctx {
     vstab::UpflowW up[4];
     int plan_batch = 0;                  // vstab_set_plan_batch: > 0 pins every arithmetic-changing plan decision to that batch's
     unsigned plan_flags = 0;             // vstab_set_plan_flags (VSTAB_PLAN_*)
-    unsigned *tickets = nullptr;         // SKINNY_MAX_TILES ticket words of the in-launch split-K reductions (conv_skinny.hip), zero between launches
     // profiling (vstab_profile_*): event pairs per conv-like launch, one row per forward
     bool prof = false;
     std::vector<hipEvent_t> prof_ev;     // [forward][15][2]

@@ -171,13 +171,13 @@ class Context:
         """Views of the intermediate tensors in the workspace of the last forward (tests)."""
         ws = self.workspace(B, H, W, Cin)
         ent = (_lib.VstabWsEntry * 24)()
-        n = _lib.lib().vstab_workspace_layout(B, H, W, Cin, ent, 24)
+        n = _lib.lib().vstab_workspace_layout_ctx(self._h, B, H, W, Cin, ent, 24)      # the plan THIS context runs (pinned batch, flags)
         if n < 0:
             _lib.check(n)
         out = {}
         for e in ent[:n]:
             name = e.name.decode()
-            if name == "splitk" or e.h == 0:
+            if name in ("splitk", "tickets") or e.h == 0:
                 continue
             nfl = e.n * e.h * e.w * e.c_stride
             flat = ws[e.offset_bytes:e.offset_bytes + 4 * nfl].view(torch.float32)

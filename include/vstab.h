@@ -16,12 +16,19 @@
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
  *     null stream); no hidden host<->device copies, no allocation after vstab_load_weights;
  *   - the caller owns every I/O buffer and the workspace; the context owns only the
- *     packed weights;
+ *     packed weights (everything a forward writes -- activations, split-K slabs, the ticket
+ *     words of the in-launch reductions -- lies in the caller's workspace);
  *   - every function returns 0 or a negative VSTAB_E_* code and never throws;
  *     vstab_last_error() gives the message for the last failure on that context
  *     (or the last context-less failure when ctx == NULL);
- *   - one context per device; calls on one context must not overlap in time unless
- *     they use distinct workspaces and only read the context.
+ *   - one context per device; forwards on one context may overlap in time (different
+ *     streams) when each uses its OWN workspace: they only read the context.  Calls that
+ *     write the context (vstab_load_weights, vstab_set_plan_batch, the DIAGNOSTIC section
+ *     at the end of this header) must not overlap with anything on that context;
+ *   - product surface first; everything under "DIAGNOSTIC AND TEST SURFACE" at the end
+ *     (plan flags, per-launch profilers, roctx ranges, self-tests, host-only views of the
+ *     launch plan) exists for measurements and tests, is process- or context-global state,
+ *     and is not part of the drop-in contract.
  */
 #ifndef VSTAB_H
 #define VSTAB_H
@@ -93,18 +100,16 @@ VSTAB_API size_t vstab_workspace_bytes(int B, int H, int W, int Cin);
  * ragged last micro-batch of a sharded clip: main:553-558's samples are independent).  vstab_set_plan_batch(ctx, P)
  * pins them to what a batch of P samples gets: every call with B <= P then gives each sample bit-identical results, whatever B is
  * (B > P is VSTAB_E_SHAPE).  P = 0 (default) unpins.  The workspace of a pinned context is sized by vstab_workspace_bytes_ctx
- * (a workspace sized for P itself always suffices).  Flags (A/B measurements and tests; 3 = the round-3 schedule):
- * VSTAB_PLAN_NO_SKINNY keeps few-row layers on the tiled kernel with a split-K combine launch, VSTAB_PLAN_NO_DUAL launches a
- * refinement level's flow head and transposed convolution one after the other. */
-#define VSTAB_PLAN_NO_SKINNY 1u
-#define VSTAB_PLAN_NO_DUAL 2u      /* a refinement level as four launches (tap table, predict_up, transposed conv, combine) instead of two */
+ * (a workspace sized for P itself always suffices); vstab_workspace_bytes / vstab_workspace_layout describe the UNPINNED plan. */
 VSTAB_API int vstab_set_plan_batch(vstab_ctx *ctx, int batch);
-VSTAB_API int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags);
 VSTAB_API size_t vstab_workspace_bytes_ctx(const vstab_ctx *ctx, int B, int H, int W, int Cin);
 
 /* Names/offsets of the intermediate tensors inside the workspace.  Returns the number
  * of entries written (<= max_entries) or a negative error. */
 VSTAB_API int vstab_workspace_layout(int B, int H, int W, int Cin, vstab_ws_entry *entries, int max_entries);
+/* The same for the plan THIS context would run (its pinned batch and plan flags): the activation offsets depend on the shape alone,
+ * the sizes of "splitk", "winograd_in", "winograd_out" (always the last three entries) on the plan. */
+VSTAB_API int vstab_workspace_layout_ctx(const vstab_ctx *ctx, int B, int H, int W, int Cin, vstab_ws_entry *entries, int max_entries);
 
 /* ---- the network: flownetS_pyramid(feats, batch_size, is_train=False) model.py:786-893
  * feats [B,H,W,Cin] -> predict_flow6..3 at the pyramid levels and predict_flow2
@@ -115,37 +120,12 @@ VSTAB_API int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B, 
                            float *pf6, float *pf5, float *pf4, float *pf3, float *pf2,
                            void *workspace, size_t workspace_bytes, void *stream);
 
-/* ---- measurement support.  With profiling enabled every conv-like launch of
- * vstab_flownets_forward (15 per forward: encoder stages 1..6_1, deconv5..2, predict2 tap
- * table; the GEMM kernel itself, not the split-K combine that may follow it) is bracketed by
- * hipEvents recorded on the forward's stream.  vstab_profile_read must be called after that stream has been
- * synchronised: it returns, both summed over the forward passes recorded since the last
- * reset (a batch split into chunks records one pass per chunk; *n_forwards counts them), the
- * elapsed milliseconds per launch slot and the ALGORITHMIC flops per slot (2*MAC of the layer
- * as SURVEY.md 8d counts it; deconvs at 4 taps/output). */
-VSTAB_API int vstab_profile_enable(vstab_ctx *ctx, int enable);
-VSTAB_API int vstab_profile_reset(vstab_ctx *ctx);
-VSTAB_API int vstab_profile_read(vstab_ctx *ctx, double *ms_sum15, double *flops15, int *n_forwards);
-/* vstab_profile_read's flops are what the launches ISSUE: the 3x3 stride-1 encoder stages run in Winograd F(2x2,3x3) form and
- * issue 4/9 of the direct convolution's multiply-adds.  This returns the same slots counted as direct convolutions. */
-VSTAB_API int vstab_profile_read_direct(vstab_ctx *ctx, double *flops15);
-/* Name (as rocprofv3 prints it) of the kernel instantiation launch slot `slot` used in the last forward. */
-VSTAB_API int vstab_profile_kernel_name(vstab_ctx *ctx, int slot, char *buf, int cap);
-
 /* ---- glue: main:497-498 with the literals generalised (384 -> net_h, 512 -> net_w, 382 -> h = the flow's height).
  * out[B,oh,ow,2] = resize_images(flow*net_h/h, [oh,ow]), then x = x*ow/net_w, y = y*oh/net_h, every `*` and `/`
  * a separate fp32 operation in the reference's order ((a*b)/c) (legacy TF bilinear, align_corners=False; identity
  * resample when the size already matches). */
 VSTAB_API int vstab_flow_resize_scale(const float *flow, int B, int h, int w, float *out, int oh, int ow,
                             int net_h, int net_w, void *stream);
-
-/* ---- device self-test of the glue's division by a launch constant (five fused operations on a host-side reciprocal instead
- * of a run-time IEEE division; quotients that do not come out normal -- signed zeros, denormals, infinities -- take the division
- * itself): compares it BIT FOR BIT with `x / d` for the `count` fp32 bit patterns x starting at `first_bits` (NaN numerators
- * skipped), and ADDS the number of mismatches to *bad_count_dev (device memory, 8-byte aligned).
- * VSTAB_E_SHAPE for a divisor the glue would divide plainly (outside [1, 2^24], or an all-ones significand). */
-VSTAB_API int vstab_selftest_div_const(float d, unsigned first_bits, unsigned long long count, unsigned long long *bad_count_dev,
-                                       void *stream);
 
 /* ---- glue: main:806 / model.py:857 UpSampling2dLayer defaults.  Legacy TF bilinear
  * resize of an NHWC tensor. */
@@ -178,21 +158,6 @@ VSTAB_API int vstab_flow_glue_warp(const float *flow, int B, int h, int w, const
 VSTAB_API int vstab_stabilise_originalsize(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, const float *frame,
                                            int oh, int ow, float *pf6, float *pf5, float *pf4, float *pf3, float *pf2,
                                            float *outflow, float *warped, void *workspace, size_t workspace_bytes, void *stream);
-
-/* ---- roctx ranges: with on = 1 every layer of vstab_flownets_forward (conv1 .. conv6_1, predict_flowN+upsample, deconvN,
- * predict_flow2) and the glue/warp launches run inside a named roctx range, so a `rocprofv3 --marker-trace --kernel-trace`
- * timeline reads as the network (model.py:807-887).  The roctx library is loaded with dlopen on first use; VSTAB_E_STATE if
- * none is installed.  Process-wide, off by default. */
-VSTAB_API int vstab_trace_ranges(int on);
-
-/* ---- instrumentation of the HBM-side kernels (tf_warp, the flow glue, the fused launch): with profiling on every such launch
- * is bracketed by dispatch-timestamp events on its own stream.  Process-wide; switching it on clears earlier records.
- * Slots: 0 = vstab_warp_flow, 1 = vstab_flow_resize_scale, 2 = vstab_flow_glue_warp, 3 = the predict_flow2 gather inside
- * vstab_flownets_forward / vstab_pf2_from_taps (128 B per tap-table row + 8 B per coarser-flow and output pixel).  Read after synchronising the stream(s):
- * summed kernel milliseconds, number of launches, summed ALGORITHMIC bytes (SURVEY.md 8d: warp 32 B/px; glue 8 B per source +
- * 8 B per output pixel; fused 8 B per source pixel + 32 (flow written) or 24 B per output pixel). */
-VSTAB_API int vstab_hbm_profile_enable(int mode);   /* 0 = off (records kept), 1 = clear + on, 2 = on again (records kept) */
-VSTAB_API int vstab_hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg_bytes_sum);
 
 /* ---- get_pixel_value(img, x, y) main:44-68.  x, y int32 [B,H,W] -> out[b,h,w,:] =
  * img[b, y, x, :].  Indices are clamped into the image instead of faulting. */
@@ -426,6 +391,60 @@ VSTAB_API int vstab_homography_fit(const float *flow, int B, int H, int W, int K
  * coordinates rounded to 1/32 px, 15-bit fixed-point blend, constant-0 border; Hm maps src -> dst (inverted inside). */
 VSTAB_API int vstab_warp_perspective_u8(const uint8_t *src, int B, int sh, int sw, const double *Hm, uint8_t *dst, int oh, int ow,
                                         void *stream);
+
+/* ==================================================================================================================
+ * DIAGNOSTIC AND TEST SURFACE -- not part of the drop-in contract.  Nothing below is needed to run the path; these calls
+ * exist for A/B measurements, profiles and tests, they hold context-global (plan flags, per-launch events) or PROCESS-global
+ * (roctx ranges, the HBM-side profiler) state, and the plan flags change the ORDER of floating-point sums (results stay
+ * within the parity tolerance but are not bit-identical across flag values).  A product caller leaves all of them alone.
+ * ================================================================================================================== */
+
+/* ---- plan flags (A/B measurements and the bit-equality tests; 3 = the round-3 schedule): VSTAB_PLAN_NO_SKINNY keeps few-row
+ * layers on the tiled kernel with a split-K combine launch, VSTAB_PLAN_NO_DUAL launches a refinement level's flow head and
+ * transposed convolution one after the other.  Context state; workspace sizes then come from vstab_workspace_bytes_ctx. */
+#define VSTAB_PLAN_NO_SKINNY 1u
+#define VSTAB_PLAN_NO_DUAL 2u      /* a refinement level as four launches (tap table, predict_up, transposed conv, combine) instead of two */
+VSTAB_API int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags);
+
+/* ---- measurement support.  With profiling enabled every conv-like launch of
+ * vstab_flownets_forward (15 per forward: encoder stages 1..6_1, deconv5..2, predict2 tap
+ * table; the GEMM kernel itself, not the split-K combine that may follow it) is bracketed by
+ * hipEvents recorded on the forward's stream.  vstab_profile_read must be called after that stream has been
+ * synchronised: it returns, both summed over the forward passes recorded since the last
+ * reset (a batch split into chunks records one pass per chunk; *n_forwards counts them), the
+ * elapsed milliseconds per launch slot and the ALGORITHMIC flops per slot (2*MAC of the layer
+ * as SURVEY.md 8d counts it; deconvs at 4 taps/output). */
+VSTAB_API int vstab_profile_enable(vstab_ctx *ctx, int enable);
+VSTAB_API int vstab_profile_reset(vstab_ctx *ctx);
+VSTAB_API int vstab_profile_read(vstab_ctx *ctx, double *ms_sum15, double *flops15, int *n_forwards);
+/* vstab_profile_read's flops are what the launches ISSUE: the 3x3 stride-1 encoder stages run in Winograd F(2x2,3x3) form and
+ * issue 4/9 of the direct convolution's multiply-adds.  This returns the same slots counted as direct convolutions. */
+VSTAB_API int vstab_profile_read_direct(vstab_ctx *ctx, double *flops15);
+/* Name (as rocprofv3 prints it) of the kernel instantiation launch slot `slot` used in the last forward. */
+VSTAB_API int vstab_profile_kernel_name(vstab_ctx *ctx, int slot, char *buf, int cap);
+
+/* ---- device self-test of the glue's division by a launch constant (five fused operations on a host-side reciprocal instead
+ * of a run-time IEEE division; quotients that do not come out normal -- signed zeros, denormals, infinities -- take the division
+ * itself): compares it BIT FOR BIT with `x / d` for the `count` fp32 bit patterns x starting at `first_bits` (NaN numerators
+ * skipped), and ADDS the number of mismatches to *bad_count_dev (device memory, 8-byte aligned).
+ * VSTAB_E_SHAPE for a divisor the glue would divide plainly (outside [1, 2^24], or an all-ones significand). */
+VSTAB_API int vstab_selftest_div_const(float d, unsigned first_bits, unsigned long long count, unsigned long long *bad_count_dev,
+                                       void *stream);
+
+/* ---- roctx ranges: with on = 1 every layer of vstab_flownets_forward (conv1 .. conv6_1, predict_flowN+upsample, deconvN,
+ * predict_flow2) and the glue/warp launches run inside a named roctx range, so a `rocprofv3 --marker-trace --kernel-trace`
+ * timeline reads as the network (model.py:807-887).  The roctx library is loaded with dlopen on first use; VSTAB_E_STATE if
+ * none is installed.  Process-wide, off by default. */
+VSTAB_API int vstab_trace_ranges(int on);
+
+/* ---- instrumentation of the HBM-side kernels (tf_warp, the flow glue, the fused launch): with profiling on every such launch
+ * is bracketed by dispatch-timestamp events on its own stream.  Process-wide; switching it on clears earlier records.
+ * Slots: 0 = vstab_warp_flow, 1 = vstab_flow_resize_scale, 2 = vstab_flow_glue_warp, 3 = the predict_flow2 gather inside
+ * vstab_flownets_forward / vstab_pf2_from_taps (128 B per tap-table row + 8 B per coarser-flow and output pixel).  Read after synchronising the stream(s):
+ * summed kernel milliseconds, number of launches, summed ALGORITHMIC bytes (SURVEY.md 8d: warp 32 B/px; glue 8 B per source +
+ * 8 B per output pixel; fused 8 B per source pixel + 32 (flow written) or 24 B per output pixel). */
+VSTAB_API int vstab_hbm_profile_enable(int mode);   /* 0 = off (records kept), 1 = clear + on, 2 = on again (records kept) */
+VSTAB_API int vstab_hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg_bytes_sum);
 
 /* ---- host-only helpers (no GPU needed; used by the CPU tests) --------------------- */
 /* Level sizes of the encoder for an HxW input: hw[2*i], hw[2*i+1] = (h, w) of stage i

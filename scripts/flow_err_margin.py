@@ -1,19 +1,118 @@
 #!/usr/bin/env python3
-"""Margin of the flow outputs against the 1e-3 gate: max-abs error of the five flows of ONE sample vs the fp64 oracle."""
-import os, sys
-import numpy as np, torch
+"""Parity headroom of the flow outputs against the 1e-3 gate (BASELINE.json north_star), per pyramid level.
+
+For every (shape, weight set, plan flags) cell: max-abs error of the five flows of ONE sample against the fp64 restatement
+(oracle/vstab_oracle.py, the arbiter of the parity tests), max |flow| of that level, and the fraction of the 1e-3 budget used.
+Also, per cell, the error in units of fp32 epsilon x max |flow| of the level (what a bound "k ulp of the flow" means), and the
+largest difference between the default plan and the other plans (two kernel families for the same layers).
+
+    python scripts/flow_err_margin.py [--out profiles/flow_err_margin_r05.md] [--quick]
+
+Shapes: BASELINE configs[0] (1x256x256), the reference's native 1x384x512 (main:491), configs[1] (8x512x512: sample 0 of a batch
+of eight copies), one 720p sample (configs[2]'s shape).  Weight sets: He-normal + identity BatchNorm (what bench.py times),
+random BatchNorm statistics with flow_gain 1 and 2 (what the parity tests use; flows of tens to ~200 px).
+Plan flags: 0 default, 1 = few-row layers on the tiled kernel, 2 = refinement levels as four launches, 3 = both (round-3 schedule).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import coupe.optical_flow_based_deep_video_stabilization_amd as vs
-from coupe.optical_flow_based_deep_video_stabilization_amd import runtime, weights as wts
-from oracle import vstab_oracle as vo
-for (B, H, W, seed, rb) in ((8, 512, 512, 1, False), (8, 512, 512, 2, True), (8, 384, 512, 3, True)):
-    w = wts.synthetic_weights(seed=seed, cin=27, random_bn=rb)
-    runtime.reset(); vs.assign_weights(w)
-    rng = np.random.default_rng(H + W + seed)
-    one = rng.random((1, H, W, 27), dtype=np.float32)
-    feats = torch.from_numpy(one).cuda().expand(B, -1, -1, -1).contiguous()
-    flows = vs.flownetS_pyramid(feats, B)
-    ref = vo.flownetS_pyramid(one, w, torch.float64)
-    errs = {k: float((flows[k][0].double().cpu() - ref[k][0]).abs().max()) for k in vo.FLOW_KEYS}
-    mags = {k: float(ref[k].abs().max()) for k in vo.FLOW_KEYS}
-    print(B, H, W, "seed", seed, "random_bn", rb, "errs", {k: f"{v:.2e}" for k, v in errs.items()}, "max|flow|", {k: f"{v:.1f}" for k, v in mags.items()}, flush=True)
+import coupe.optical_flow_based_deep_video_stabilization_amd as vs                      # noqa: E402
+from coupe.optical_flow_based_deep_video_stabilization_amd import runtime, weights as wts  # noqa: E402
+from oracle import vstab_oracle as vo                                                   # noqa: E402
+
+TOL = 1e-3
+EPS = float(np.finfo(np.float32).eps)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--quick", action="store_true", help="skip the 720p sample and the gain-1 random set")
+    args = ap.parse_args()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    shapes = [("cfg0", 1, 256, 256), ("native", 1, 384, 512), ("cfg1", 8, 512, 512)]
+    if not args.quick:
+        shapes.append(("720p", 1, 720, 1280))
+    wsets = [("he_identity_bn", dict(seed=1, random_bn=False, flow_gain=1.0)),
+             ("random_bn_gain2", dict(seed=1, random_bn=True, flow_gain=2.0))]
+    if not args.quick:
+        wsets.insert(1, ("random_bn_gain1", dict(seed=2, random_bn=True, flow_gain=1.0)))
+    rows, cells = [], []
+    for wname, wkw in wsets:
+        w = wts.synthetic_weights(cin=27, **wkw)
+        for sname, B, H, W in shapes:
+            rng = np.random.default_rng(H + W + wkw["seed"])
+            one = rng.random((1, H, W, 27), dtype=np.float32)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                ref = vo.flownetS_pyramid(one, w, torch.float64)
+            t_or = time.perf_counter() - t0
+            mags = {k: float(ref[k].abs().max()) for k in vo.FLOW_KEYS}
+            feats = torch.from_numpy(one).cuda().expand(B, -1, -1, -1).contiguous()
+            base = None
+            for flags in (0, 1, 2, 3):
+                runtime.reset()
+                vs.assign_weights(w)
+                ctx = runtime.get_context()
+                if flags:
+                    ctx.set_plan_flags(flags)
+                flows = vs.flownetS_pyramid(feats, B)
+                got = {k: flows[k][0].double().cpu() for k in vo.FLOW_KEYS}
+                errs = {k: float((got[k] - ref[k][0]).abs().max()) for k in vo.FLOW_KEYS}
+                if flags == 0:
+                    base = got
+                vs_default = {k: float((got[k] - base[k]).abs().max()) for k in vo.FLOW_KEYS}
+                worst = max(errs, key=lambda k: errs[k])
+                cell = {"weights": wname, "shape": sname, "B": B, "H": H, "W": W, "plan_flags": flags, "err": errs, "max_abs_flow": mags,
+                        "frac_of_tol": {k: errs[k] / TOL for k in errs}, "err_in_eps_of_flow": {k: errs[k] / (EPS * max(1.0, mags[k])) for k in errs},
+                        "vs_default_plan": vs_default, "worst_level": worst}
+                cells.append(cell)
+                print(f"{wname:<16}{sname:<7}flags {flags}  worst {worst} {errs[worst]:.2e} = {errs[worst] / TOL:.2f} of tol  "
+                      f"max|pf2| {mags['predict_flow2']:.1f}  (oracle {t_or:.1f} s)", flush=True)
+    runtime.reset()
+
+    def fmt(cell):
+        e, m = cell["err"], cell["max_abs_flow"]
+        lv = " | ".join(f"{e[k]:.2e}" for k in vo.FLOW_KEYS)
+        worst = cell["worst_level"]
+        vd = max(cell["vs_default_plan"].values())
+        return (f"| {cell['weights']} | {cell['shape']} {cell['B']}x{cell['H']}x{cell['W']} | {cell['plan_flags']} | {lv} | "
+                f"{m['predict_flow3']:.1f} / {m['predict_flow2']:.1f} | **{e[worst] / TOL:.2f}** ({worst[-1]}) | "
+                f"{cell['err_in_eps_of_flow']['predict_flow2']:.1f} | {vd:.2e} |")
+
+    lines = ["# Parity headroom of the flow outputs (round 5 schedule)", "",
+             "Generated by `scripts/flow_err_margin.py` on the GPU box; every figure is sample 0 of the batch against the **fp64** CPU restatement",
+             "(`oracle/vstab_oracle.py`; parity unpinned: TensorFlow 1.10 cannot run here).  Tolerance 1e-3 max-abs (BASELINE.json north_star).",
+             "`frac` = worst level's error / 1e-3 (the level in brackets).  `pf2 err / (eps·max|pf2|)` = predict_flow2's error in units of one fp32",
+             "epsilon of the largest flow.  `vs default` = largest difference of any level to the default plan's result (two kernel families / launch",
+             "schedules for the same layers: plan flags 1 = few-row layers on the tiled kernel, 2 = refinement levels as four launches, 3 = both).", "",
+             "| weights | shape | flags | pf6 | pf5 | pf4 | pf3 | pf2 | max\\|pf3\\| / max\\|pf2\\| | frac of 1e-3 | pf2 err / (eps·max\\|pf2\\|) | vs default |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    lines += [fmt(c) for c in cells]
+    over = [c for c in cells if max(c["frac_of_tol"].values()) > 0.7]
+    lines += ["", f"Cells above 0.7 of the budget: **{len(over)}**" + (":" if over else "."), ""]
+    for c in over:
+        lines.append(f"* {c['weights']} {c['shape']} flags {c['plan_flags']}: {c['worst_level']} at {max(c['frac_of_tol'].values()):.2f}; "
+                     f"pf3 {c['err']['predict_flow3']:.2e} (x8 upsampled into pf2: eight adds of the bilinear upsample) vs pf2 {c['err']['predict_flow2']:.2e}")
+    worst_eps = max(c["err_in_eps_of_flow"]["predict_flow2"] for c in cells)
+    worst_vd = max(max(c["vs_default_plan"][k] / (EPS * max(1.0, c["max_abs_flow"][k])) for k in vo.FLOW_KEYS) for c in cells)
+    lines += ["", f"Largest predict_flow2 error in fp32 epsilons of its own magnitude: **{worst_eps:.1f} eps**; largest plan-to-plan difference of any level: "
+              f"**{worst_vd:.1f} eps** of that level's largest flow (what `tests/test_gpu_skinny.py` bounds)."]
+    text = "\n".join(lines) + "\n"
+    print(text)
+    if args.out:
+        open(args.out, "w").write(text)
+    if args.json:
+        json.dump(cells, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

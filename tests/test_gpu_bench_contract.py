@@ -12,14 +12,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_contract_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                        "--cpu-seconds", "3", "--no-secondary"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "flow_err"):
         assert k in d, k
+    # the metric's second half (BASELINE.json: "+ max-abs flow err vs TF CPU"): the last timed step's five flows, the output-resolution
+    # flow and the warped frame against the CPU restatement run on the SAME first samples of the timed batch, within 1e-3
+    fe, cb = d["flow_err"], d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and "timed GPU batch" in cb["sample"]
+    assert fe["tol"] == 1e-3 and fe["samples"] == 2 and "parity unpinned" in fe["vs"]
+    assert set(fe["max_abs"]) == {"predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3", "predict_flow2", "outflow"}
+    assert all(0 <= v <= 1e-3 for v in fe["max_abs"].values()), fe
+    assert 0 <= fe["warped_max_abs_masked"] <= 1e-3 and fe["within_tol"] is True and fe["worst"] <= 1e-3
+    assert fe["vs_fp64"]["within_tol"] is True and all(v <= 1e-3 for v in fe["vs_fp64"]["max_abs"].values())
+    assert fe["max_abs_flow"]["predict_flow2"] > 0.5         # a real flow field, not zeros
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
     assert abs(d["value"] - 8 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-3

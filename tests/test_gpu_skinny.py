@@ -129,3 +129,81 @@ def test_two_launch_refinement_levels_equal_the_four_launch_sequence_bit_for_bit
     for k in KEYS:
         assert torch.equal(a[k], b[k]), k
     ctx.set_plan_flags(0)
+
+
+def _raw_forward(ctx, feats, ws, stream):
+    """vstab_flownets_forward through ctypes with a caller-chosen workspace and stream."""
+    B, H, W, Cin = feats.shape
+    lv = vs.netspec.sizes_for(H, W).level
+    flows = [torch.empty((B, lv[k][0], lv[k][1], 2), dtype=torch.float32, device="cuda") for k in (6, 5, 4, 3)]
+    flows.append(torch.empty((B, H - 2, W - 2, 2), dtype=torch.float32, device="cuda"))
+    _lib.check(_lib.lib().vstab_flownets_forward(ctx._h, feats.data_ptr(), B, H, W, Cin, *[f.data_ptr() for f in flows], ws.data_ptr(), ws.numel(),
+                                                 stream.cuda_stream), ctx._h)
+    return flows
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (384, 512)])
+def test_forwards_on_one_context_with_distinct_workspaces_may_overlap(ctx, H, W):
+    # vstab.h: the context owns only the packed weights; everything a forward writes -- the ticket words of the in-launch split-K
+    # reductions included -- lies in the caller's workspace, so two streams may run forwards on ONE context side by side when each
+    # has its own workspace.  The workspaces start as garbage (0xFF bytes: non-zero ticket words, NaN slabs): the forward zeroes
+    # what it needs.  Every overlapped result is bit-identical to the serial one.
+    n = _lib.lib().vstab_workspace_bytes_ctx(ctx._h, 1, H, W, 27)
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.rand(1, H, W, 27, generator=g).cuda() for _ in range(2)]
+    serial = []
+    for x in xs:
+        r = vs.flownetS_pyramid(x, 1)
+        serial.append([r[k].clone() for k in KEYS])
+    wss = [torch.full((n,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for it in range(40):
+        for s in range(2):
+            outs[s].append(_raw_forward(ctx, xs[s], wss[s], streams[s]))
+    torch.cuda.synchronize()
+    for s in range(2):
+        for fl in outs[s]:
+            for a, b, k in zip(fl, serial[s], KEYS):
+                assert torch.equal(a, b), (s, k)
+    # a workspace whose ticket words were left dirty (what a launch that failed mid-flight leaves) is healed by the next forward
+    ent = (_lib.VstabWsEntry * 24)()
+    m = _lib.lib().vstab_workspace_layout_ctx(ctx._h, 1, H, W, 27, ent, 24)
+    tk = [e for e in ent[:m] if e.name == b"tickets"][0]
+    wss[0][tk.offset_bytes:tk.offset_bytes + 4 * tk.w] = 7
+    fl = _raw_forward(ctx, xs[0], wss[0], streams[0])
+    torch.cuda.synchronize()
+    for a, b, k in zip(fl, serial[0], KEYS):
+        assert torch.equal(a, b), k
+    assert int(wss[0][tk.offset_bytes:tk.offset_bytes + 4 * tk.w].view(torch.int32).abs().max()) == 0       # and every launch left them zero
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (1, 384, 512)])
+def test_four_phase_transposed_convolutions_on_the_weight_stream_kernel(ctx, B, H, W):
+    # plan flag 2 alone (no dual launch) sends few-row transposed convolutions through conv_skinny_kernel: per-phase weight offsets,
+    # slab base phase*ks*slab, ticket index (phase*gridDim.x+bx)*gridDim.y+by.  Against the tiled form (flags 1|2) to fp32 rounding
+    # and against the fp64 restatement, every decoder tensor and every flow.
+    tiles = layer_tiles(B, H, W, 2)
+    assert any(t[0] == 6 for t in tiles[10:14]), "flag 2 should put a transposed convolution on the weight-stream kernel at this shape"
+    g = torch.Generator().manual_seed(H + 13 * W)
+    feats = torch.rand(B, H, W, 27, generator=g)
+    names = ("concat5", "concat4", "concat3", "concat2")
+    ctx.set_plan_flags(2)
+    a = vs.flownetS_pyramid(feats.cuda(), B)
+    a = {k: a[k].clone() for k in KEYS}
+    ia = {k: v.clone() for k, v in ctx.internals(B, H, W, 27).items() if k in names}
+    ctx.set_plan_flags(1 | 2)
+    b = vs.flownetS_pyramid(feats.cuda(), B)
+    ib = {k: v.clone() for k, v in ctx.internals(B, H, W, 27).items() if k in names}
+    ctx.set_plan_flags(0)
+    w = wts.synthetic_weights(seed=1, cin=27, random_bn=True, flow_gain=2.0)
+    ref, internals = vo.flownetS_pyramid(feats.numpy(), w, torch.float64, return_internals=True)
+    for k in names:
+        scale = max(1.0, float(ib[k].abs().max()))
+        assert float((ia[k] - ib[k]).abs().max()) <= 2e-5 * scale, k
+        assert float((ia[k].double().cpu() - internals[k]).abs().max()) <= 1e-3 * scale, k
+    for k in KEYS:
+        mag = max(1.0, float(ref[k].abs().max()))
+        assert float((a[k] - b[k]).abs().max()) <= 64 * 1.2e-7 * mag, k
+        assert float((a[k].double().cpu() - ref[k]).abs().max()) <= 1e-3, k

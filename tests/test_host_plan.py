@@ -163,7 +163,10 @@ def test_workspace_layout_is_disjoint_and_aligned():
     L = _lib.lib()
     ent = (_lib.VstabWsEntry * 24)()
     n = L.vstab_workspace_layout(8, 512, 512, 27, ent, 24)
-    assert n == 18          # 10 activation buffers, 5 tap tables, split-K slabs, the two Winograd-domain buffers
+    assert n == 19          # 10 activation buffers, 5 tap tables, the ticket words, split-K slabs, the two Winograd-domain buffers
+    names = [e.name.decode() for e in ent[:n]]
+    assert names[-4:] == ["tickets", "splitk", "winograd_in", "winograd_out"]      # the plan-dependent sizes come last (vstab.h)
+    assert ent[n - 4].w == 4096                                                   # one ticket word per (phase, row tile, column block)
     total = L.vstab_workspace_bytes(8, 512, 512, 27)
     spans = []
     for e in ent[:n]:
