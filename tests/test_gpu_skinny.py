@@ -12,6 +12,11 @@ from oracle import vstab_oracle as vo
 pytestmark = pytest.mark.gpu
 KEYS = ("predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3", "predict_flow2")
 NO_SKINNY = 1
+EPS32 = 1.1920929e-07
+# Two kernel families (or launch schedules) for the same layers associate the same sums differently.  Their flows differ by a few fp32
+# epsilons of the flow itself: profiles/flow_err_margin_r05.md measures at most 9.5 eps of a level's largest flow over every shape,
+# weight set and plan there (the pyramid doubles a level's rounding into the next one and predict_flow2 takes 8 x up(predict_flow3)).
+PLAN_TO_PLAN_EPS = 16
 
 
 @pytest.fixture
@@ -54,7 +59,8 @@ def test_weight_stream_layers_match_the_tiled_form_and_the_oracle(ctx, B, H, W):
         assert float((ia[k] - ib[k]).abs().max()) <= 2e-5 * scale, k
     ref = vo.flownetS_pyramid(feats.numpy(), wts.synthetic_weights(seed=1, cin=27, random_bn=True, flow_gain=2.0), torch.float64)
     for k in KEYS:
-        assert float((a[k] - b[k]).abs().max()) <= 5e-4, k       # flows of up to ~200 px: a few ulp of the 8x upsampled predict_flow3
+        mag = max(1.0, float(ref[k].abs().max()))
+        assert float((a[k] - b[k]).abs().max()) <= PLAN_TO_PLAN_EPS * EPS32 * mag, (k, mag)
         assert float((a[k].double().cpu() - ref[k]).abs().max()) <= 1e-3, k
 
 
@@ -205,5 +211,5 @@ def test_four_phase_transposed_convolutions_on_the_weight_stream_kernel(ctx, B, 
         assert float((ia[k].double().cpu() - internals[k]).abs().max()) <= 1e-3 * scale, k
     for k in KEYS:
         mag = max(1.0, float(ref[k].abs().max()))
-        assert float((a[k] - b[k]).abs().max()) <= 64 * 1.2e-7 * mag, k
+        assert float((a[k] - b[k]).abs().max()) <= PLAN_TO_PLAN_EPS * EPS32 * mag, (k, mag)
         assert float((a[k].double().cpu() - ref[k]).abs().max()) <= 1e-3, k
