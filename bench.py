@@ -341,6 +341,7 @@ def main():
               "homography": lambda im: vwarp.transformImage(st_cfg, im, st_M)}
 
     nstep = [0]
+    gather_on = [True]          # the second timed region of an N > 1 run (the same steps without the reassembly) clears it
 
     dbg = [] if os.environ.get("VSTAB_BENCH_DEBUG") else None
 
@@ -356,7 +357,7 @@ def main():
             warped = st_fns[args.st_warp](warped)
         if vgg is not None:
             vgg.build(vvgg.preprocess(warped))
-        if gather is not None or grouped is not None:
+        if gather_on[0] and (gather is not None or grouped is not None):
             t2 = time.perf_counter()
             submit_frames(warped)
             if dbg is not None:
@@ -399,6 +400,25 @@ def main():
     elapsed, out = benchloop.timed_region(timed_step, args.steps, args.warmup, torch.cuda.synchronize, dist=dist,
                                           drain=flush_and_drain if (gather is not None or grouped is not None) else None, before_timed=profilers_on,
                                           device="cpu" if args.backend == "gloo" else "cuda")
+
+    # ---- N > 1: what the reassembly costs.  The SAME ranks run the same K steps again with the collective (and the uint8 staging
+    # launch that feeds it) switched off; exposed = with - without.  After the timed region, never part of `value`.
+    gather_cost = None
+    if (gather is not None or grouped is not None):
+        gather_on[0] = False
+        if use_events:
+            ctx.profile_set(False)
+            runtime.hbm_profile(0)
+        e2, _ = benchloop.timed_region(lambda k: step(), args.steps, min(args.warmup, 3), torch.cuda.synchronize, dist=dist,
+                                       device="cpu" if args.backend == "gloo" else "cuda")
+        gather_on[0] = True
+        per_rank = B * H * W * 3 * (4 if args.gather_fp32 else 1)
+        gather_cost = {"schedule": args.gather_schedule, "transport": "gloo through host memory (rehearsal: the figures mean nothing)" if host else "RCCL",
+                       "dtype": "fp32" if args.gather_fp32 else "uint8", "steps_per_collective": G,
+                       "bytes_per_rank_per_step": per_rank, "bytes_gathered_per_step": per_rank * world,
+                       "ms_per_step_with": round(elapsed / args.steps * 1e3, 4), "ms_per_step_without": round(e2 / args.steps * 1e3, 4),
+                       "exposed_ms": round((elapsed - e2) / args.steps * 1e3, 4),
+                       "how": f"{args.steps} more steps on the same ranks and buffers after the timed region, reassembly (staging launch + collective) off"}
 
     # the last timed step's outputs (first --err-samples samples), copied now: later legs reuse the workspace and the output buffers
     err_nb = max(1, min(B, args.err_samples))
@@ -582,11 +602,12 @@ def main():
                                f"(5 flows) + flow resize/scale + tf_warp at {H}x{W}",
                    "batch_per_gpu": B, "height": H, "width": W, "cin": Cin,
                    "gflop_per_sample": round(netspec.gflop_per_sample(H, W, Cin), 2),
-                   "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over RCCL, schedule " + args.gather_schedule + f", one collective per {G} step(s)") if (gather is not None or grouped is not None) else False,
+                   "all_gather": (("fp32" if args.gather_fp32 else "uint8") + " warped frames, async over " + ("gloo (host memory; rehearsal)" if host else "RCCL") + ", schedule " + args.gather_schedule + f", one collective per {G} step(s)") if (gather is not None or grouped is not None) else False,
                    "vgg16_trunk": bool(args.vgg16), "st_warp": args.st_warp, "plan_flags": args.plan_flags, "plan_batch": args.plan_batch,
                    "host_calls_per_step": "1 (vstab_stabilise_originalsize, outputs pre-allocated)" if stab is not None else "2 + 7 allocations"},
         "roofline": roofline,
         "roofline_hbm": roofline_hbm,
+        "all_gather": gather_cost,
     }
     # ---- secondary rows, AFTER the timed region and never part of `value`: what bench_clip.py (BASELINE configs[3]) and
     # bench_train.py measure at length, in short form, so that a driver that only runs bench.py sees them

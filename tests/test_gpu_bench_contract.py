@@ -59,7 +59,13 @@ def test_bench_self_launched_rccl_rank_prints_exactly_one_line():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[:500]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and "uint8 warped frames" in d["config"]["all_gather"]
+    assert d["n_gpus"] == 1 and "uint8 warped frames" in d["config"]["all_gather"] and "over RCCL" in d["config"]["all_gather"]
+    # SURVEY.md 8e "fps + gather time separately": the same steps again without the reassembly, after the timed region
+    ag = d["all_gather"]
+    for k in ("schedule", "transport", "bytes_per_rank_per_step", "bytes_gathered_per_step", "ms_per_step_with", "ms_per_step_without", "exposed_ms"):
+        assert k in ag, k
+    assert ag["transport"] == "RCCL" and ag["bytes_per_rank_per_step"] == 8 * 512 * 512 * 3 and ag["ms_per_step_with"] == d["ms_per_step"]
+    assert abs(ag["exposed_ms"] - (ag["ms_per_step_with"] - ag["ms_per_step_without"])) < 1e-3 and ag["ms_per_step_without"] > 0
 
 
 def test_bench_self_launches_two_ranks_rehearsal():
@@ -75,7 +81,9 @@ def test_bench_self_launches_two_ranks_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3          # both ranks' samples / max-over-ranks time
-    assert "schedule allgather" in d["config"]["all_gather"]
+    assert "schedule allgather" in d["config"]["all_gather"] and "gloo" in d["config"]["all_gather"] and "RCCL" not in d["config"]["all_gather"]
+    ag = d["all_gather"]
+    assert ag["transport"].startswith("gloo") and ag["bytes_gathered_per_step"] == 2 * 2 * 128 * 128 * 3 and ag["ms_per_step_without"] > 0
 
 
 def test_bench_clip_two_ranks_ragged_rehearsal():
