@@ -65,6 +65,7 @@ EXPORTS = {
     "vstab_resize_u8": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vstab_assemble_input": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
     "vstab_assemble_input_resized": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
+    "vstab_clip_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "vstab_flow_glue_warp_u8": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "vstab_frame_to_float": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "vstab_quantise_output": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),

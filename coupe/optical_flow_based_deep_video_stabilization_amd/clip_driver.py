@@ -50,10 +50,11 @@ class ClipStabiliser:
         homography fitted to the dense flow (cv2.findHomography + cv2.warpPerspective), while the history later frames
         read stays the flow-warped frame (main:739).  `ransac` = keyword arguments of postfilters.find_homography.
         `flow_filter` (e.g. postfilters.MeanFlow3Filter(): the highTV evaluator, ...highTV...:629-631) maps the output-resolution flow
-        to the flow that warps.  Without a `flow_filter` a frame is FOUR library calls: the network input assembled straight from
-        the full-resolution frame (cv2.resize inside the launch), the network, ONE launch for swap(frame)/255 -> flow glue ->
-        tf_warp -> uint8(swap(warped*255)) on the 8-bit frames, the history frame resized into its ring slot.  `keep_outflow` also
-        writes the output-resolution flow (`last_outflow`; always on with `homography`)."""
+        to the flow that warps.  Without a `flow_filter` a frame is ONE library call (`vstab_clip_step`) into buffers allocated here,
+        once: the network input assembled straight from the full-resolution frame (cv2.resize inside the launch), the network, ONE
+        launch for swap(frame)/255 -> flow glue -> tf_warp -> uint8(swap(warped*255)) on the 8-bit frames, the history frame resized
+        into its ring slot.  `last_flows` (and `last_outflow`) are then the SAME tensors every frame, overwritten by the next step.
+        `keep_outflow` also writes the output-resolution flow (`last_outflow`; always on with `homography`)."""
         runtime._require_gpu()
         self.out_h, self.out_w, self.n = int(out_h), int(out_w), int(n_clips)
         self.net_h, self.net_w = int(net_hw[0]), int(net_hw[1])
@@ -69,37 +70,64 @@ class ClipStabiliser:
         self.last_outflow = None
         self.flow_filter = flow_filter
         self.keep_outflow = bool(keep_outflow) or self.homography
+        self._one_call = None
+
+    def _prepare_one_call(self):
+        """Everything the one-call step needs, once: flow buffers, the workspace, the ring slots' addresses, the argument tail."""
+        from . import netspec
+        ctx = runtime.get_context(self.scope, self.device.index)
+        if ctx.cin is None:
+            raise RuntimeError("vstab: weights have not been loaded (initialize_global_variables / load_and_assign_npz_dict)")
+        if ctx.cin != 27:
+            raise ValueError("the clip driver's network input is 27 channels (8 history frames + the current one)")
+        lv = netspec.sizes_for(self.net_h, self.net_w).level
+        fl = [torch.empty((self.n, lv[k][0], lv[k][1], 2), dtype=torch.float32, device=self.device) for k in (6, 5, 4, 3)]
+        fl.append(torch.empty((self.n, self.net_h - 2, self.net_w - 2, 2), dtype=torch.float32, device=self.device))
+        outflow = torch.empty((self.n, self.out_h, self.out_w, 2), dtype=torch.float32, device=self.device) if self.keep_outflow else None
+        ws = ctx.workspace(self.n, self.net_h, self.net_w, 27)
+        base, slot_bytes = self.ring.data_ptr(), self.ring[0].numel()
+        flows = {'predict_flow6': fl[0], 'predict_flow5': fl[1], 'predict_flow4': fl[2], 'predict_flow3': fl[3], 'predict_flow2': fl[4], 'flow': fl[4]}
+        self._one_call = dict(ctx=ctx, flows=flows, outflow=outflow, ws=ws, ring_ptrs=[base + k * slot_bytes for k in range(RING)],
+                              ptrs=(C.c_void_p * 8)(), fn=_lib.lib().vstab_clip_step, plan=(ctx.plan_batch, ctx.plan_flags),
+                              mid=[self.n, self.net_h, self.net_w, self.out_h, self.out_w, self.feats.data_ptr()] + [f.data_ptr() for f in fl] +
+                                  [outflow.data_ptr() if outflow is not None else None])
 
     def reset(self):
         self.i = 0
         self.last_flows = None
 
-    def _step_u8(self, f, i, L):
-        """main:550-558, 568-569, 497-514, 625/630 without a flow filter: (flows, outflow or None, out u8)."""
-        # the eight history slots (null = the resized current frame: a clip's first frame) + the current frame resized inside the kernel
-        ptrs = (C.c_void_p * 8)(*[None if i == 0 else self.ring[max(i - lag, 0) % RING].data_ptr() for lag in STAB_LAGS])
-        out = torch.empty_like(f)
-        outflow = torch.empty((self.n, self.out_h, self.out_w, 2), dtype=torch.float32, device=self.device) if self.keep_outflow else None
+    def _step_u8(self, f, i, out):
+        """main:550-558, 568-569, 497-514, 625/630, 556 without a flow filter, ONE library call: (flows, outflow or None, out u8).  The
+        stabilised frame's history copy lands in ring slot i % RING inside the same call."""
+        oc = self._one_call
+        if oc is None or oc["ctx"]._h.value is None or oc["plan"] != (oc["ctx"].plan_batch, oc["ctx"].plan_flags) or \
+                runtime._contexts.get((self.scope, self.device.index)) is not oc["ctx"]:
+            self._prepare_one_call()
+            oc = self._one_call
+        ptrs, rp = oc["ptrs"], oc["ring_ptrs"]
+        for j, lag in enumerate(STAB_LAGS):      # the eight history slots (null = the resized current frame: a clip's first frame)
+            ptrs[j] = None if i == 0 else rp[max(i - lag, 0) % RING]
+        if out is None:
+            out = torch.empty_like(f)
+        ws = oc["ws"]
         with torch.cuda.device(self.device):
-            _lib.check(L.vstab_assemble_input_resized(ptrs, f.data_ptr(), self.n, self.net_h, self.net_w, self.out_h, self.out_w,
-                                                      self.feats.data_ptr(), runtime.stream_ptr()))
-        flows = flownetS_pyramid(self.feats, self.n, is_train=False, scope=self.scope)                 # main:569
-        pf2 = flows['predict_flow2']
-        with torch.cuda.device(self.device):
-            _lib.check(L.vstab_flow_glue_warp_u8(pf2.data_ptr(), self.n, pf2.shape[1], pf2.shape[2], f.data_ptr(),
-                                                 outflow.data_ptr() if outflow is not None else None, out.data_ptr(), self.out_h, self.out_w,
-                                                 self.net_h, self.net_w, runtime.stream_ptr()))
-        return flows, outflow, out
+            _lib.check(oc["fn"](oc["ctx"]._h, ptrs, f.data_ptr(), *oc["mid"], out.data_ptr(), rp[i % RING], ws.data_ptr(), ws.numel(),
+                                runtime.stream_ptr()), oc["ctx"]._h)
+        return oc["flows"], oc["outflow"], out
 
-    def step(self, frame_bgr_u8: torch.Tensor) -> torch.Tensor:
-        """One frame of every clip: uint8 [n,out_h,out_w,3] BGR -> stabilised uint8 [n,out_h,out_w,3] BGR."""
+    def step(self, frame_bgr_u8: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One frame of every clip: uint8 [n,out_h,out_w,3] BGR -> stabilised uint8 [n,out_h,out_w,3] BGR.  `out` (same shape,
+        contiguous, same device; without a flow filter) receives the result instead of a freshly allocated tensor."""
         f = _u8(frame_bgr_u8, "frame")
         if tuple(f.shape) != (self.n, self.out_h, self.out_w, 3):
             raise ValueError(f"frame must be {(self.n, self.out_h, self.out_w, 3)}, got {tuple(f.shape)}")
+        if out is not None and (self.flow_filter is not None or out.dtype != torch.uint8 or tuple(out.shape) != tuple(f.shape)
+                                or not out.is_contiguous() or out.device != f.device):
+            raise ValueError("out must be a contiguous uint8 tensor of the frame's shape on its device (and no flow_filter)")
         L = _lib.lib()
         i = self.i
         if self.flow_filter is None:
-            flows, outflow, out = self._step_u8(f, i, L)
+            flows, outflow, out = self._step_u8(f, i, out)
         else:
             cur_small = resize_u8(f, (self.net_h, self.net_w))                       # main:550
             slots = []
@@ -119,7 +147,7 @@ class ClipStabiliser:
             with torch.cuda.device(self.device):
                 _lib.check(L.vstab_quantise_output(warped.data_ptr(), self.n * self.out_h * self.out_w, out.data_ptr(),
                                                    runtime.stream_ptr()))                                  # main:625,630
-        resize_u8(out, (self.net_h, self.net_w), out=self.ring[i % RING])        # what later frames read back (main:556), written in place
+            resize_u8(out, (self.net_h, self.net_w), out=self.ring[i % RING])    # what later frames read back (main:556), written in place
         self.last_flows, self.last_outflow = flows, outflow
         self.i += 1
         if self.homography:

@@ -1526,6 +1526,25 @@ extern "C" int vstab_quantise_output(const float *warped, long long npix, uint8_
     return VSTAB_OK;
 }
 
+// One frame of the evaluator's loop (main:550-558, 568-569, 497-514, 625/630, 556) as ONE call: network input from the history slots + the
+// frame (cv2.resize inside the launch), the network, the 8-bit glue + warp launch, the stabilised frame resized into its history slot.
+extern "C" int vstab_clip_step(vstab_ctx *ctx, const uint8_t *const *slots8, const uint8_t *frame, int n, int net_h, int net_w, int oh, int ow,
+                               float *feats, float *pf6, float *pf5, float *pf4, float *pf3, float *pf2, float *outflow, uint8_t *out,
+                               uint8_t *ring_slot, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!ctx) return fail(nullptr, VSTAB_E_STATE, "clip_step: ctx is NULL");
+    if (!slots8 || !frame || !feats || !out || !ring_slot) return fail(ctx, VSTAB_E_STATE, "clip_step: NULL buffer");
+    if (n < 1 || net_h < 3 || net_w < 4 || oh < 1 || ow < 1) return fail(ctx, VSTAB_E_SHAPE, "clip_step: bad shape");
+    int rc = vstab_assemble_input_resized(slots8, frame, n, net_h, net_w, oh, ow, feats, stream);
+    if (rc == VSTAB_OK) rc = vstab_flownets_forward(ctx, feats, n, net_h, net_w, 27, pf6, pf5, pf4, pf3, pf2, workspace, workspace_bytes, stream);
+    else ctx->err = g_last_error;
+    if (rc != VSTAB_OK) return rc;
+    rc = vstab_flow_glue_warp_u8(pf2, n, net_h - 2, net_w - 2, frame, outflow, out, oh, ow, net_h, net_w, stream);
+    if (rc == VSTAB_OK) rc = vstab_resize_u8(out, n, oh, ow, ring_slot, net_h, net_w, stream);
+    if (rc != VSTAB_OK) ctx->err = g_last_error;
+    return rc;
+}
+
 // ------------------------------------------------------------------------- flow post-filters
 extern "C" int vstab_flow_box_blur(const float *flow, int B, int h, int w, int k, float *tmp, float *out, void *stream)
 {

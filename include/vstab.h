@@ -240,6 +240,15 @@ VSTAB_API int vstab_assemble_input_resized(const uint8_t *const *slots8, const u
  * [B,oh,ow,3] BGR, outflow [B,oh,ow,2] or NULL.  Identical bytes to vstab_frame_to_float + vstab_flow_glue_warp + vstab_quantise_output. */
 VSTAB_API int vstab_flow_glue_warp_u8(const float *flow, int B, int h, int w, const uint8_t *frame, float *outflow, uint8_t *out, int oh, int ow,
                                       int net_h, int net_w, void *stream);
+/* One frame of the evaluator's loop as ONE call (main:550-558 input, 568-569 network, 497-514 + 625/630 the 8-bit glue + warp, 556 the
+ * history frame): vstab_assemble_input_resized(slots8, frame) -> feats [n,net_h,net_w,27]; vstab_flownets_forward(feats) -> pf6..pf2;
+ * vstab_flow_glue_warp_u8(pf2, frame) -> out u8 [n,oh,ow,3] (and outflow [n,oh,ow,2] unless NULL); vstab_resize_u8(out) -> ring_slot
+ * u8 [n,net_h,net_w,3], the slot later frames read this one back from.  slots8: HOST array of 8 device pointers (lags 31,23,15,7,4,3,2,1;
+ * NULL = the resized current frame).  Every buffer is the caller's, allocated once; identical bytes to the four calls.  The network
+ * takes 27 input channels (8 history frames + the current one). */
+VSTAB_API int vstab_clip_step(vstab_ctx *ctx, const uint8_t *const *slots8, const uint8_t *frame, int n, int net_h, int net_w, int oh, int ow,
+                              float *feats, float *pf6, float *pf5, float *pf4, float *pf3, float *pf2, float *outflow, uint8_t *out,
+                              uint8_t *ring_slot, void *workspace, size_t workspace_bytes, void *stream);
 /* resizedInput (main:568): swap(frame)/255 -> float [npix,3]. */
 VSTAB_API int vstab_frame_to_float(const uint8_t *frame, long long npix, float *out, void *stream);
 /* np.uint8(swap(warped*255)) (main:625,630,556): float [npix,3] -> u8, truncating, saturating outside [0,255]. */

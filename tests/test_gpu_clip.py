@@ -186,3 +186,46 @@ def test_eight_bit_frame_path_in_one_launch_is_byte_identical(n, oh, ow, nh, nw)
         assert torch.equal(a, b)
     assert L.vstab_flow_glue_warp_u8(None, n, nh - 2, nw - 2, frame.data_ptr(), None, ref.data_ptr(), oh, ow, nh, nw, st) == -6
     assert L.vstab_assemble_input_resized(p8, None, n, nh, nw, oh, ow, b.data_ptr(), st) == -6
+
+
+def test_one_call_frame_equals_the_four_call_sequence():
+    """vstab_clip_step (one library call per frame, every buffer allocated once) against the four calls it replaces -- network input
+    from the history slots + the frame, the network, the 8-bit glue + warp launch, the history resize -- over a clip long enough to
+    wrap several history lags: identical bytes, frame by frame, and identical flows; `out=` writes in place."""
+    import ctypes as C
+    from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
+    T, H, W, nh, nw = 9, 72, 100, 64, 96
+    clip = torch.from_numpy(smooth_clip(T, H, W, 11)).cuda().unsqueeze(1).contiguous()
+    runtime.reset()
+    vs.assign_weights(wts.synthetic_weights(seed=4, cin=27, random_bn=True, flow_gain=0.5))
+    drv = clip_driver.ClipStabiliser(H, W, n_clips=1, net_hw=(nh, nw), keep_outflow=True)
+    ring = torch.zeros((clip_driver.RING, 1, nh, nw, 3), dtype=torch.uint8, device="cuda")
+    feats = torch.empty((1, nh, nw, 27), dtype=torch.float32, device="cuda")
+    L = _lib.lib()
+    mine = torch.empty((1, H, W, 3), dtype=torch.uint8, device="cuda")
+    for i in range(T):
+        f = clip[i]
+        got = drv.step(f, out=mine) if i % 2 else drv.step(f)
+        assert (got is mine) == bool(i % 2)
+        ptrs = (C.c_void_p * 8)(*[None if i == 0 else ring[max(i - lag, 0) % clip_driver.RING].data_ptr() for lag in clip_driver.STAB_LAGS])
+        _lib.check(L.vstab_assemble_input_resized(ptrs, f.data_ptr(), 1, nh, nw, H, W, feats.data_ptr(), runtime.stream_ptr()))
+        assert torch.equal(feats, drv.feats)
+        flows = vs.flownetS_pyramid(feats, 1)
+        pf2 = flows["predict_flow2"]
+        ref, outflow = torch.empty_like(f), torch.empty((1, H, W, 2), dtype=torch.float32, device="cuda")
+        _lib.check(L.vstab_flow_glue_warp_u8(pf2.data_ptr(), 1, nh - 2, nw - 2, f.data_ptr(), outflow.data_ptr(), ref.data_ptr(), H, W, nh, nw,
+                                             runtime.stream_ptr()))
+        clip_driver.resize_u8(ref, (nh, nw), out=ring[i % clip_driver.RING])
+        assert torch.equal(got, ref), i
+        assert torch.equal(drv.last_outflow, outflow), i
+        for k in ("predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3", "predict_flow2"):
+            assert torch.equal(drv.last_flows[k], flows[k]), (i, k)
+        assert torch.equal(drv.ring[i % clip_driver.RING], ring[i % clip_driver.RING]), i
+    # a second driver on the same context shares nothing that a frame writes (its own flows, ring and feats; the context's workspace is
+    # used in stream order)
+    other = clip_driver.ClipStabiliser(H, W, n_clips=1, net_hw=(nh, nw))
+    a = drv.step(clip[0]).clone()
+    other.step(clip[3])
+    assert torch.equal(drv.last_flows["predict_flow2"], vs.flownetS_pyramid(drv.feats, 1)["predict_flow2"])
+    assert a.shape == (1, H, W, 3)
+    runtime.reset()
