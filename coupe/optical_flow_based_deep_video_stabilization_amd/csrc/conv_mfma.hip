@@ -336,7 +336,12 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams &p, const unsign
 #ifdef VSTAB_NO_ASM_KLOOP
     constexpr bool ASM_KLOOP = false;                                 // A/B builds only (scripts/build_variant_lib.sh)
 #else
-    constexpr bool ASM_KLOOP = DMA && VEC && BM == 128 && WM == 2 && WN == 2 && (BN == 128 || BN == 64) && VSTAB_ABL == 0;
+#ifdef VSTAB_NO_ASM_KLOOP_64
+    constexpr bool ASM_64 = false;                                    // A/B builds only: the 64 x 128 tile on hipcc's loop (rounds 1-4)
+#else
+    constexpr bool ASM_64 = BM == 64 && BN == 128 && WM == 1 && WN == 4;
+#endif
+    constexpr bool ASM_KLOOP = DMA && VEC && VSTAB_ABL == 0 && ((BM == 128 && WM == 2 && WN == 2 && (BN == 128 || BN == 64)) || ASM_64);
 #endif
 
     if constexpr (ASM_KLOOP) {
@@ -356,9 +361,13 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams &p, const unsign
                 la[q] = ldsA + (unsigned)(a_row0 + chunk) * 4u;
                 lb[q] = ldsA + (unsigned)(2 * BM * 32 + b_row0 + chunk) * 4u;
             }
-            int span[4];
+            // per gathered row of this thread (four for the 128-row tiles, two for the 64-row one: the rest are unused operands)
+            int span[4] = {0, 0, 0, 0}, ax[4] = {0, 0, 0, 0}, alo[4] = {0, 0, 0, 0}, aw[4] = {0, 0, 0, 0}, ay[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) span[j] = max(RA[j].z - RA[j].y, 0);
+            for (int j = 0; j < A_ROWS_V; ++j) {
+                span[j] = max(RA[j].z - RA[j].y, 0);
+                ax[j] = RA[j].x; alo[j] = RA[j].y; aw[j] = RA[j].w; ay[j] = R[j].y;
+            }
             const unsigned long long ain = (unsigned long long)(size_t)(p.in - bias_el);
             const unsigned long long awt = (unsigned long long)(size_t)(p.wpk + ph.w_off);
             i32x4 din, dwt;                        // the two buffer descriptors (stride 0, raw, the ranges of rin_b / rwt)
@@ -382,15 +391,18 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams &p, const unsign
               [vt] "=&v"(v_t), [vo0] "=&v"(v_o0), [vo1] "=&v"(v_o1)                                                                        \
             : [la0] "v"(la[0]), [la1] "v"(la[1]), [la2] "v"(la[2]), [la3] "v"(la[3]),                                                     \
               [lb0] "v"(lb[0]), [lb1] "v"(lb[1]), [lb2] "v"(lb[2]), [lb3] "v"(lb[3]),                                                     \
-              [x0] "v"(RA[0].x), [x1] "v"(RA[1].x), [x2] "v"(RA[2].x), [x3] "v"(RA[3].x),                                                 \
-              [lo0] "v"(RA[0].y), [lo1] "v"(RA[1].y), [lo2] "v"(RA[2].y), [lo3] "v"(RA[3].y),                                             \
+              [x0] "v"(ax[0]), [x1] "v"(ax[1]), [x2] "v"(ax[2]), [x3] "v"(ax[3]),                                                         \
+              [lo0] "v"(alo[0]), [lo1] "v"(alo[1]), [lo2] "v"(alo[2]), [lo3] "v"(alo[3]),                                                 \
               [span0] "v"(span[0]), [span1] "v"(span[1]), [span2] "v"(span[2]), [span3] "v"(span[3]),                                     \
-              [w0] "v"(RA[0].w), [w1] "v"(RA[1].w), [w2] "v"(RA[2].w), [w3] "v"(RA[3].w),                                                 \
-              [y0] "v"(R[0].y), [y1] "v"(R[1].y), [y2] "v"(R[2].y), [y3] "v"(R[3].y),                                                     \
+              [w0] "v"(aw[0]), [w1] "v"(aw[1]), [w2] "v"(aw[2]), [w3] "v"(aw[3]),                                                         \
+              [y0] "v"(ay[0]), [y1] "v"(ay[1]), [y2] "v"(ay[2]), [y3] "v"(ay[3]),                                                         \
               [wv] "v"(wvoff0), [rin] "s"(din), [rwt] "s"(dwt), [ma] "s"(m_a), [mb] "s"(m_b),                                            \
               [kps] "s"(kps), [nseg] "s"(L_NSEG), [lstride] "s"(L_STRIDE), [pitch] "s"(row_pitch), [hi] "s"(p.Hi), [wstep] "s"(wstep)     \
             : "memory", "vcc", "scc", VSTAB_KLOOP_CLOBBERS
-            if constexpr (BN == 128) {
+            if constexpr (BM == 64) {
+                asm volatile(VSTAB_KLOOP_ASM_64x128
+                             VSTAB_KLOOP_IO([c00] "+a"(acc[0][0]) VSTAB_COMMA [c10] "+a"(acc[1][0])));
+            } else if constexpr (BN == 128) {
                 asm volatile(VSTAB_KLOOP_ASM_128x128
                              VSTAB_KLOOP_IO([c00] "+a"(acc[0][0]) VSTAB_COMMA [c01] "+a"(acc[0][1]) VSTAB_COMMA [c10] "+a"(acc[1][0]) VSTAB_COMMA [c11] "+a"(acc[1][1])));
             } else {

@@ -20,20 +20,27 @@ def test_committed_include_is_the_generators_output():
 
 
 def _blocks():
+    """tile shape (BM, BN) -> the K loop's lines: 128 x 128, 128 x 64 (2 x 2 waves) and 64 x 128 (1 x 4 waves, the one-sample launches)"""
     g = _gen()
-    return {bn: g.Gen(bn).generate() for bn in (128, 64)}
+    out = {(128, bn): g.Gen(bn).generate() for bn in (128, 64)}
+    out[(64, 128)] = g.Gen(128, BM=64, WM=1, WN=4).generate()
+    return out
 
 
 def test_every_tile_body_has_the_full_mfma_count_and_one_barrier():
-    for bn, lines in _blocks().items():
-        per_tile = 4 * 4 * 2 * (bn // 64)                                   # 4 k-groups x 4 j x MB x NB
+    for (bm, bn), lines in _blocks().items():
+        nb = bn // 64 if bm == 128 else 1
+        per_tile = 4 * 4 * 2 * nb                                           # 4 k-groups x 4 j x MB x NB
         text = "\n".join(lines)
         bodies = re.split(r"\.Lvk\d+_(?:body0|body1|tail0|tail1|end)_%=:", text)[1:5]
         assert len(bodies) == 4
         for i, b in enumerate(bodies):
             assert b.count("v_mfma_f32_32x32x2_f32") == per_tile
             assert b.count("s_barrier") == (1 if i < 2 else 0)                  # steady-state bodies only; the last tile fetches nothing
-            assert b.count("buffer_load_dwordx4") == ((4 + bn // 32) if i < 2 else 0)
+            assert b.count("buffer_load_dwordx4") == ((bm // 32 + bn // 32) if i < 2 else 0)
+    # the three shapes' labels are distinct (one translation unit instantiates all of them)
+    tags = {re.search(r"\.Lvk(\d+)_body0", "\n".join(l)).group(1) for l in _blocks().values()}
+    assert tags == {"128", "64", "64128"}
 
 
 def test_exec_is_whole_again_before_every_lds_dma_load_and_no_mfma_runs_under_a_narrowed_exec():
@@ -59,13 +66,13 @@ def test_m0_is_written_at_least_one_instruction_before_the_load_that_uses_it():
 def test_accumulator_chain_order_is_k_group_then_j():
     """per accumulator the A/B fragment registers come in the order the C++ loop multiplies them (bit-identical results)"""
     g = _gen()
-    for bn in (128, 64):
-        gen = g.Gen(bn)
+    for gen in (g.Gen(128), g.Gen(64), g.Gen(128, BM=64, WM=1, WN=4)):
         for s in (0, 1):
             seq = {}
             for l in gen.mfmas(s):
                 m = re.match(r"v_mfma_f32_32x32x2_f32 %\[(c\d\d)\], v(\d+), v(\d+),", l)
                 seq.setdefault(m.group(1), []).append((int(m.group(2)), int(m.group(3))))
+            assert len(seq) == gen.MB * gen.NB
             for acc, ops in seq.items():
                 mb, nb = int(acc[1]), int(acc[2])
                 a0, b0 = g.frag(s, f"A{mb}", 0), g.frag(s, f"B{nb}", 0)

@@ -38,14 +38,19 @@ def tup(r):
 
 
 class Gen:
-    def __init__(self, BN):
-        self.BM, self.BN = 128, BN
-        self.MB, self.NB = 2, BN // 64
+    def __init__(self, BN, BM=128, WM=2, WN=2):
+        """conv_mfma_kernel<BM, BN, WM, WN, true, true>: 128 x 128 and 128 x 64 (2 x 2 waves), and since round 5 the 64 x 128 tile of the
+        one-sample launches (1 x 4 waves: every wave multiplies all 64 rows by its own 32 columns -- the 128 x 64 tile's wave shape
+        with A and B swapped in size: two row passes of the gather, four passes of weight rows)."""
+        self.BM, self.BN = BM, BN
+        self.MB, self.NB = BM // (32 * WM), BN // (32 * WN)
+        assert self.MB == 2 and self.NB in (1, 2)
         self.G = 4 * self.MB * self.NB
-        self.A_ROWS = 4
+        self.A_ROWS = BM // 32
         self.B_PASS = BN // 32
         self.A_BUF = self.BM * 128           # bytes per A buffer
         self.B_BUF = self.BN * 128
+        self.tag = str(BN) if BM == 128 else f"{BM}{BN}"
         self.out = []
 
     def e(self, s):
@@ -146,7 +151,7 @@ class Gen:
         self.group(["s_waitcnt lgkmcnt(0)"], self.mfmas(1), {}, [f"s_branch {end_label}"] if end_label else [])
 
     def generate(self):
-        L = lambda n: f".Lvk{self.BN}_{n}_%="
+        L = lambda n: f".Lvk{self.tag}_{n}_%="
         self.e("s_nop 4")
         for l in self.reads(0, 0, 0):
             self.e(l)
@@ -681,6 +686,11 @@ def render():
         o.append("    \"\"")
         if BN == 128:
             o.append("#define VSTAB_KLOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in g.clobbers()))
+    g = Gen(128, BM=64, WM=1, WN=4)
+    o.append("#define VSTAB_KLOOP_ASM_64x128 \\")
+    for l in g.generate():
+        o.append(f'    "{l}\\n" \\')
+    o.append("    \"\"")
     r1 = RowWinGen(6, MB=1)
     o.append("#define VSTAB_ROWWIN1_ASM_KPR6 \\")
     for l in r1.generate():
