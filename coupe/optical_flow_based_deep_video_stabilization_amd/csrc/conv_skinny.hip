@@ -17,8 +17,8 @@
 //     acquire, sums the tile's slabs in slab order (`sc1` loads; the same association as splitk_combine_kernel), adds the bias,
 //     applies the activation and stores the output rows -- no combine launch, no dependence on placement or dispatch order
 //     (cdna_hip_programming.md section 5 "In-launch split-K reduction", section 6 Guideline 16).  With 32x32 tiles and the 4-wave
-//     pre-sum a tile's slabs are 4 KB x ks (ks <= 16).  The ticket words live in the context (zeroed at vstab_create) and every last
-//     arriver puts its word back to zero.
+//     pre-sum a tile's slabs are 4 KB x ks (ks <= 16).  The ticket words live in the caller's workspace (round 5; zeroed by a memset node
+//     at the head of every forward) and every last arriver puts its word back to zero.
 //
 // What it buys (profiles/README.md "r04 one-sample path", interleaved A/B on one box): the launch itself is a chain of latencies --
 // first operands, a handful of MFMAs, LDS pre-sum, store drain, ticket, acquire, slab loads, output -- that takes 12 ... 17 us where the
@@ -49,7 +49,19 @@ __global__ __launch_bounds__(256) void conv_skinny_kernel(const ConvParams p, un
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int li = lane & 31, lh = lane >> 5, sw = (li >> 1) & 7;
     unsigned bx_, by_, bz_;
-    xcd_remap(bx_, by_, bz_);           // the column blocks of one (row tile, K slice) sit on one XCD: they share the A operand in its L2
+    {
+        // XCD-aware numbering (the hardware deals workgroups to the 8 XCDs round-robin; xcd_remap_calc gives XCD c a contiguous band of the
+        // new linear id), decomposed column block fastest, then ROW TILE, then (phase, K slice): one XCD's band is whole K slices with ALL
+        // their row tiles and column blocks, so a slice's weights -- the big operand -- are fetched into one L2 once and the second row
+        // tile of a 33 ... 64-row layer reads them there (rounds 1-4 put the row tile slowest: two XCDs streamed the same weights,
+        // 61 MB from HBM for conv6_1's 37.7 MB at one 384x512 sample).  The A rows of a slice are shared by its column blocks as before.
+        unsigned nl, t0_, t1_;
+        xcd_remap_calc(gridDim.x * gridDim.y * gridDim.z, 1, 1, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nl, t0_, t1_);
+        by_ = nl % gridDim.y;
+        const unsigned t2 = nl / gridDim.y;
+        bx_ = t2 % gridDim.x;
+        bz_ = t2 / gridDim.x;
+    }
     const int z = (int)bz_;
     const int phase = z / p.ksplit, split = z - phase * p.ksplit;
     const ConvPhase ph = p.ph[phase];
