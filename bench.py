@@ -235,7 +235,8 @@ def main():
                          "ProjectiveTransformer (spatial_transformer.py:400-452, 539-608) or warp.transformImage (warp.py:46-86) inside the step")
     ap.add_argument("--plan-flags", type=int, default=0,
                     help="vstab_set_plan_flags bits for A/B runs: 1 = few-row layers on the tiled kernel + combine launch (no weight-stream "
-                         "kernel: the round-3 schedule)")
+                         "kernel: the round-3 schedule), 2 = refinement levels as four launches, 4 = predict_flow2's gather and the glue + warp "
+                         "as two launches (the round-4 tail)")
     ap.add_argument("--plan-batch", type=int, default=0,
                     help="vstab_set_plan_batch: pin the arithmetic-changing plan decisions to this batch (0 = plan for --batch itself)")
     ap.add_argument("--vgg16", action="store_true",
@@ -513,7 +514,8 @@ def main():
         name = max(hp, key=lambda k: hp[k][0])
         ms_sum, nl, by = hp[name]
         if nl > 0 and ms_sum > 0:
-            kernels = {"flow_glue_warp": "warp3_tile_kernel<true, true, 4, 16, 32, 2, true, false, " + ("true" if W % 4 == 0 else "false") + ">",
+            kernels = {"pf2_glue_warp": "pf2_glue_warp_kernel<true, " + ("true" if W % 4 == 0 else "false") + ">",
+                       "flow_glue_warp": "warp3_tile_kernel<true, true, 4, 16, 32, 2, true, false, " + ("true" if W % 4 == 0 else "false") + ">",
                        "warp_flow": "warp3_tile_kernel<false, false, ...>", "flow_resize_scale": "flow_resize_scale_kernel"}
             gbs = by / (ms_sum * 1e-3) / 1e9
             h_traffic, h_src = None, "not measured by this run"
@@ -529,7 +531,9 @@ def main():
                 h_traffic, h_src = None, "not measured by this run"
             roofline_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": h_traffic, "traffic_source": h_src,
-                            "kernel": kernels[name], "entry_point": "vstab_" + name, "launches": nl,
+                            "kernel": kernels[name],
+                            "entry_point": "vstab_stabilise_originalsize (its last launch: predict_flow2 gather + flow glue + tf_warp)" if name == "pf2_glue_warp" else "vstab_" + name,
+                            "launches": nl,
                             "avg_launch_us": round(ms_sum / nl * 1e3, 2), "alg_bytes_per_launch": by / nl,
                             "alg_bytes_per_output_pixel": round(by / nl / (B * H * W), 2),
                             "note": "limit is the L1 tag pipe (12-byte gathers), not HBM: profiles/README.md, r02 warp study; "

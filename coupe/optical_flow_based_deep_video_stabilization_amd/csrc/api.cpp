@@ -597,7 +597,7 @@ extern "C" int vstab_set_plan_batch(vstab_ctx *ctx, int batch)
 extern "C" int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags)
 {
     if (!ctx) return fail(nullptr, VSTAB_E_STATE, "set_plan_flags: ctx is NULL");
-    if (flags & ~(unsigned)(VSTAB_PLAN_NO_SKINNY | VSTAB_PLAN_NO_DUAL)) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(unsigned)(VSTAB_PLAN_NO_SKINNY | VSTAB_PLAN_NO_DUAL | VSTAB_PLAN_NO_TAIL)) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
     ctx->plan_flags = flags;
     return VSTAB_OK;
 }
@@ -810,13 +810,24 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
 }
 
 // ------------------------------------------------------------------------- forward
+// evaluate_originalSize's tail riding in the forward: when given, the last launch of a chunk computes predict_flow2, the flow glue and
+// tf_warp of the chunk's frames together (launch_pf2_glue_warp); `fused` reports whether every chunk could (else the caller warps)
+struct FusedTail { const float *frame; float *outflow; float *warped; int oh, ow; bool fused; };
 static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5,
-                         float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_);
+                         float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_, FusedTail *tail);
 static std::string conv_kernel_name(ConvTile t, bool vec4);
+static int forward_impl(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5, float *pf4, float *pf3,
+                        float *pf2, void *workspace, size_t workspace_bytes, void *stream_, FusedTail *tail);
 
 extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6,
                                       float *pf5, float *pf4, float *pf3, float *pf2, void *workspace,
                                       size_t workspace_bytes, void *stream_)
+{
+    return forward_impl(ctx, feats, B, H, W, Cin, pf6, pf5, pf4, pf3, pf2, workspace, workspace_bytes, stream_, nullptr);
+}
+
+static int forward_impl(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5, float *pf4, float *pf3,
+                        float *pf2, void *workspace, size_t workspace_bytes, void *stream_, FusedTail *tail)
 {
     if (!ctx) return fail(nullptr, VSTAB_E_STATE, "forward: ctx is NULL");
     if (!ctx->loaded) return fail(ctx, VSTAB_E_STATE, "forward: vstab_load_weights has not been called");
@@ -830,19 +841,32 @@ extern "C" int vstab_flownets_forward(vstab_ctx *ctx, const float *feats, int B,
     // 2 GiB; equal chunks share one launch plan, so their results are bit-identical -- and so are ragged ones under a pinned plan batch
     const int chunk = chunk_size(pin, B, H, W, Cin);
     if (chunk < 1) return fail(ctx, VSTAB_E_SHAPE, "forward: one %dx%dx%d sample exceeds the 2 GiB tensor limit", H, W, Cin);
+    bool all_fused = tail != nullptr;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int bc = std::min(chunk, B - b0);
+        FusedTail t{};
+        if (tail && all_fused) {
+            const size_t px = (size_t)b0 * tail->oh * tail->ow;
+            t = FusedTail{tail->frame + px * 3, tail->outflow ? tail->outflow + px * 2 : nullptr, tail->warped + px * 3, tail->oh, tail->ow, false};
+        }
         const int rc = forward_chunk(ctx, feats + (size_t)b0 * H * W * Cin, bc, H, W, Cin,
                                      pf6 + (size_t)b0 * eh[9] * ew[9] * 2, pf5 + (size_t)b0 * eh[7] * ew[7] * 2,
                                      pf4 + (size_t)b0 * eh[5] * ew[5] * 2, pf3 + (size_t)b0 * eh[3] * ew[3] * 2,
-                                     pf2 + (size_t)b0 * (H - 2) * (W - 2) * 2, workspace, workspace_bytes, stream_);
+                                     pf2 + (size_t)b0 * (H - 2) * (W - 2) * 2, workspace, workspace_bytes, stream_, (tail && all_fused) ? &t : nullptr);
         if (rc != VSTAB_OK) return rc;
+        // the first chunk decides (the geometry is the same for every chunk; a later chunk's frame slice could only differ in alignment,
+        // and a whole number of frames keeps a 16-byte aligned base 16-byte aligned when oh*ow*12 is a multiple of 16 -- checked per chunk)
+        if (tail && all_fused && !t.fused) {
+            if (b0 != 0) return fail(ctx, VSTAB_E_ALIGN, "stabilise: chunk %d of the batch misses the fused tail's alignment", b0 / chunk);
+            all_fused = false;
+        }
     }
+    if (tail) tail->fused = all_fused;
     return VSTAB_OK;
 }
 
 static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5,
-                         float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_)
+                         float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_, FusedTail *tail)
 {
     Plan pl;
     const PlanPin pin = pin_of(ctx);
@@ -1029,7 +1053,15 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         if (!tap_panel_applicable(M2, p.Cs_in, p.in, p.out)) return fail(ctx, VSTAB_E_SHAPE, "predict_flow2 tap table: unsupported geometry");
         HIP_TRY(ctx, launch_tap_panel(p.in, M2, dw + ctx->tab_wp, p.out, stream, EV_A(14), EV_B(14)));
         ctx->prof_kernel[14] = "tap_panel_kernel";
-        HIP_TRY(ctx, launch_pf2(buf(B_T), B, pl.eh[1], pl.ew[1], dw + ctx->pred2_b, pf3, pl.eh[3], pl.ew[3], pf2, H, W, stream));
+        hipError_t te = hipErrorNotSupported;
+        if (tail && !(pin.flags & VSTAB_PLAN_NO_TAIL)) {       // gather + glue + warp of this chunk's frames in one launch, when the geometry allows
+            TraceRange tail_range("predict_flow2 gather+flow_glue+tf_warp");
+            te = launch_pf2_glue_warp(buf(B_T), B, pl.eh[1], pl.ew[1], dw + ctx->pred2_b, pf3, pl.eh[3], pl.ew[3], pf2, H, W, tail->frame,
+                                      tail->outflow, tail->warped, tail->oh, tail->ow, stream);
+            if (te != hipSuccess && te != hipErrorNotSupported) HIP_TRY(ctx, te);
+            tail->fused = te == hipSuccess;
+        }
+        if (te != hipSuccess) HIP_TRY(ctx, launch_pf2(buf(B_T), B, pl.eh[1], pl.ew[1], dw + ctx->pred2_b, pf3, pl.eh[3], pl.ew[3], pf2, H, W, stream));
     }
 #undef EV_A
 #undef EV_B
@@ -1161,8 +1193,12 @@ extern "C" int vstab_stabilise_originalsize(vstab_ctx *ctx, const float *feats, 
 {
     if (!frame || !warped) return fail(ctx, VSTAB_E_STATE, "stabilise_originalsize: NULL buffer");
     if (oh < 1 || ow < 1) return fail(ctx, VSTAB_E_SHAPE, "stabilise_originalsize: bad output size");
-    const int rc = vstab_flownets_forward(ctx, feats, B, H, W, Cin, pf6, pf5, pf4, pf3, pf2, workspace, workspace_bytes, stream);
+    // the tail (predict_flow2's gather, the glue, tf_warp) rides in the forward's last launch when its geometry allows (flow_ops.hip)
+    FusedTail tail{frame, outflow, warped, oh, ow, false};
+    const bool try_fused = (((uintptr_t)frame | (uintptr_t)warped | (uintptr_t)outflow) & 15) == 0 && ((size_t)oh * ow * 4) % 16 == 0;
+    const int rc = forward_impl(ctx, feats, B, H, W, Cin, pf6, pf5, pf4, pf3, pf2, workspace, workspace_bytes, stream, try_fused ? &tail : nullptr);
     if (rc != VSTAB_OK) return rc;
+    if (tail.fused) return VSTAB_OK;
     const int rc2 = vstab_flow_glue_warp(pf2, B, H - 2, W - 2, frame, outflow, warped, oh, ow, 3, H, W, stream);
     if (rc2 != VSTAB_OK && ctx) ctx->err = g_last_error;
     return rc2;

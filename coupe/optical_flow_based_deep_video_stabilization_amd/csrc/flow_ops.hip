@@ -758,6 +758,213 @@ hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const f
 }
 
 // ---------------------------------------------------------------------------------
+// The tail of evaluate_originalSize's graph in ONE launch (round 5): predict_flow2's gather (model.py:882-887: nine taps of the tap
+// table + eight adds of the upsampled predict_flow3, pf2_tile_kernel above), the glue of main:497-498 and tf_warp (main:514,
+// warp3_tile_kernel<FUSED>).  A workgroup owns the same 16 x 32 tile of OUTPUT pixels the warp kernel does.  The glue's bilinear taps
+// of that tile reach a small rectangle of predict_flow2 (<= 18 x 34 pixels when the output is no smaller than the flow grid); the
+// workgroup computes exactly that rectangle -- statement for statement pf2_tile_kernel's sums, out of a tap-table window in LDS -- keeps
+// it in LDS, writes the part it OWNS to the returned predict_flow2 tensor (rows [lo(ty0), lo(ty0 + TH)), the last tile to the end:
+// neighbouring tiles' rectangles overlap by a pixel or two, every pixel is written once), and glue + warp read their four flow taps
+// from LDS.  predict_flow2 is written (it is a returned tensor) but never re-read: 33 MB less traffic at B=8 512x512, one launch
+// boundary less, and the warp's L1 tag pipe -- its limit -- loses the two flow lookups per pixel.  Same fp32 operations in the same
+// order as the two launches: bit-identical (tests/test_gpu_parity.py::test_fused_tail_bit_identical).
+// ---------------------------------------------------------------------------------
+constexpr int FT_PF_CAP = 704, FT_T_CAP = 160;      // predict_flow2 window pixels (18 x 34 = 612) and tap-table window pixels held in LDS
+struct TailParams {
+    int h2, w2, h3, w3, H, W;                       // tap table grid, predict_flow3 grid, network input size (predict_flow2 is (H-2) x (W-2))
+    float nsy, nsx, usy, usx;
+};
+template <bool WRITE_FLOW, bool STAGE>
+__global__ __launch_bounds__(256) void pf2_glue_warp_kernel(const float *__restrict__ T, const float *__restrict__ bias2, const float *__restrict__ pf3,
+                                                            float *__restrict__ pf2, const float *__restrict__ img, float *__restrict__ out,
+                                                            float *__restrict__ outflow, int B, int OH, int OW, int tiles_x, int tiles_y,
+                                                            TailParams P, GlueParams G)
+{
+    constexpr int TH = WT_TH, TW = WT_TW, WH = WT_WH, WW = WT_WW, PPT = WT_PPT, PPR = TW / WW;
+    __shared__ __attribute__((aligned(8))) float tab[FT_T_CAP * 18];
+    __shared__ __attribute__((aligned(8))) f32x2 pfw[FT_PF_CAP];
+    __shared__ __attribute__((aligned(16))) float stage[STAGE ? TH * TW * 3 : 4];
+    unsigned bx, by, bz;
+    xcd_remap_calc(gridDim.x, 1, 1, blockIdx.x, bx, by, bz);
+    const int tpi = tiles_x * tiles_y;
+    const int n = (int)bx / tpi, trem = (int)bx - n * tpi;
+    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const int h = G.h, w = G.w;                       // predict_flow2's grid
+    // ---- the predict_flow2 rectangle: what the tile's glue taps reach, extended to what the tile owns
+    const int yl = min(ty0 + TH - 1, OH - 1), xl = min(tx0 + TW - 1, OW - 1);
+    const int wy0 = legacy_coord(ty0, G.ry, h).lo, wx0 = legacy_coord(tx0, G.rx, w).lo;
+    const int own_y1 = tyi == tiles_y - 1 ? h : legacy_coord(ty0 + TH, G.ry, h).lo;
+    const int own_x1 = txi == tiles_x - 1 ? w : legacy_coord(tx0 + TW, G.rx, w).lo;
+    const int wy1 = max(legacy_coord(yl, G.ry, h).hi, own_y1 - 1), wx1 = max(legacy_coord(xl, G.rx, w).hi, own_x1 - 1);
+    const int WC = wx1 - wx0 + 1, npf = (wy1 - wy0 + 1) * WC;          // <= FT_PF_CAP: checked on the host
+    // ---- its tap-table window (indices into the UNPADDED concat2 grid: -1 and h2 / w2 are the zero ring), pf2_tile_kernel's way
+    const int r_lo = nearest_ac(wy0, P.nsy, P.h2 + 2) - 1, r_hi = nearest_ac(wy1 + 2, P.nsy, P.h2 + 2) - 1;
+    const int c_lo = nearest_ac(wx0, P.nsx, P.w2 + 2) - 1, c_hi = nearest_ac(wx1 + 2, P.nsx, P.w2 + 2) - 1;
+    const int wcols = c_hi - c_lo + 1, npx = (r_hi - r_lo + 1) * wcols;  // <= FT_T_CAP: checked on the host
+    const float *Tn = T + (size_t)n * P.h2 * P.w2 * 32;
+    {
+        const float inv = 1.0f / (float)wcols;
+        for (int u = threadIdx.x; u < npx * 9; u += 256) {
+            const int px = u / 9, t = u - px * 9;
+            const int wr = (int)(((float)px + 0.5f) * inv), wc = px - wr * wcols;
+            const int sy = r_lo + wr, sx = c_lo + wc;
+            f32x2 v = {0.f, 0.f};
+            if ((unsigned)sy < (unsigned)P.h2 && (unsigned)sx < (unsigned)P.w2) v = *reinterpret_cast<const f32x2 *>(Tn + ((size_t)sy * P.w2 + sx) * 32 + t * 2);
+            *reinterpret_cast<f32x2 *>(tab + px * 18 + t * 2) = v;
+        }
+    }
+    __syncthreads();
+    // ---- predict_flow2 over the rectangle (pf2_tile_kernel's statements), kept in LDS; the owned part leaves for HBM
+    {
+        const float b0 = bias2[0], b1 = bias2[1];
+        const float invc = 1.0f / (float)WC;
+        for (int u = threadIdx.x; u < npf; u += 256) {
+            const int wr = (int)(((float)u + 0.5f) * invc), wc = u - wr * WC;
+            const int y = wy0 + wr, x = wx0 + wc;
+            int ry[3], rx[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                ry[d] = (nearest_ac(y + d, P.nsy, P.h2 + 2) - 1 - r_lo) * wcols;
+                rx[d] = nearest_ac(x + d, P.nsx, P.w2 + 2) - 1 - c_lo;
+            }
+            float a0 = b0, a1 = b1;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const f32x2 t = *reinterpret_cast<const f32x2 *>(tab + (ry[dy] + rx[dx]) * 18 + (dy * 3 + dx) * 2);
+                    a0 += t.x;
+                    a1 += t.y;
+                }
+            const f32x2 uu = sample_flow_legacy(pf3, n, P.h3, P.w3, y, x, P.usy, P.usx);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { a0 += uu.x; a1 += uu.y; }
+            f32x2 o; o.x = a0; o.y = a1;
+            pfw[u] = o;
+            if (y < own_y1 && x < own_x1) reinterpret_cast<f32x2 *>(pf2)[((size_t)n * h + y) * w + x] = o;
+        }
+    }
+    __syncthreads();
+    // ---- glue + warp of the tile's output pixels (warp3_tile_kernel<FUSED>'s statements; the four flow taps come from LDS)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long HW = (long long)OH * OW;
+    int yy[PPT], xx[PPT];
+    bool ok[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int q = j * 4 + wave;
+        yy[j] = ty0 + (q / PPR) * WH + lane / WW;
+        xx[j] = tx0 + (q % PPR) * WW + lane % WW;
+        ok[j] = yy[j] < OH && xx[j] < OW;
+        if (!ok[j]) { yy[j] = ty0; xx[j] = tx0; }              // a pixel of this tile (its taps are inside the LDS rectangle); never stored
+    }
+    f32x2 f[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const Lerp Y = legacy_coord(yy[j], G.ry, h), X = legacy_coord(xx[j], G.rx, w);
+        const f32x2 tl = pfw[(Y.lo - wy0) * WC + (X.lo - wx0)], tr = pfw[(Y.lo - wy0) * WC + (X.hi - wx0)];
+        const f32x2 bl = pfw[(Y.hi - wy0) * WC + (X.lo - wx0)], br = pfw[(Y.hi - wy0) * WC + (X.hi - wx0)];
+        f[j].x = glue_post_x(lerp2(glue_pre(tl.x, G), glue_pre(tr.x, G), glue_pre(bl.x, G), glue_pre(br.x, G), X.t, Y.t), G);
+        f[j].y = glue_post_y(lerp2(glue_pre(tl.y, G), glue_pre(tr.y, G), glue_pre(bl.y, G), glue_pre(br.y, G), X.t, Y.t), G);
+        if (WRITE_FLOW && ok[j]) reinterpret_cast<f32x2 *>(outflow)[n * HW + (long long)yy[j] * OW + xx[j]] = f[j];
+    }
+    float wa[PPT], wb[PPT], wc_[PPT], wd[PPT];
+    rgb3 Ia[PPT], Ib[PPT], Ic[PPT], Id[PPT];
+    const rgb3 *b = reinterpret_cast<const rgb3 *>(img) + n * HW;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const float x = (float)xx[j] + f[j].x, y = (float)yy[j] + f[j].y;
+        int x0 = (int)fminf(fmaxf(x, -2.f), (float)OW), y0 = (int)fminf(fmaxf(y, -2.f), (float)OH);
+        int x1 = x0 + 1, y1 = y0 + 1;
+        x0 = min(max(x0, 0), OW - 1); x1 = min(max(x1, 0), OW - 1);
+        y0 = min(max(y0, 0), OH - 1); y1 = min(max(y1, 0), OH - 1);
+        const float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
+        wa[j] = (x1f - x) * (y1f - y); wb[j] = (x1f - x) * (y - y0f);
+        wc_[j] = (x - x0f) * (y1f - y); wd[j] = (x - x0f) * (y - y0f);
+        Ia[j] = b[y0 * OW + x0]; Ib[j] = b[y1 * OW + x0]; Ic[j] = b[y0 * OW + x1]; Id[j] = b[y1 * OW + x1];
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        rgb3 r;
+        r.r = ((wa[j] * Ia[j].r + wb[j] * Ib[j].r) + wc_[j] * Ic[j].r) + wd[j] * Id[j].r;      // tf.add_n order
+        r.g = ((wa[j] * Ia[j].g + wb[j] * Ib[j].g) + wc_[j] * Ic[j].g) + wd[j] * Id[j].g;
+        r.b = ((wa[j] * Ia[j].b + wb[j] * Ib[j].b) + wc_[j] * Ic[j].b) + wd[j] * Id[j].b;
+        if (STAGE) {
+            const int q = j * 4 + wave;
+            *reinterpret_cast<rgb3 *>(stage + (((q / PPR) * WH + lane / WW) * TW + (q % PPR) * WW + lane % WW) * 3) = r;
+        } else if (ok[j]) {
+            *reinterpret_cast<rgb3 *>(out + (n * HW + (long long)yy[j] * OW + xx[j]) * 3) = r;
+        }
+    }
+    if (STAGE) {       // OW % 4 == 0 (host): a tile row is TW*12 bytes from a 16-byte aligned address
+        __syncthreads();
+        constexpr int R4 = TW * 3 / 4;
+        const int vw3 = min(TW, OW - tx0) * 3;
+        for (int e = threadIdx.x; e < TH * R4; e += 256) {
+            const int row = e / R4, c4 = e - row * R4;
+            if (ty0 + row >= OH || c4 * 4 >= vw3) continue;
+            float *o = out + (n * HW + (long long)(ty0 + row) * OW + tx0) * 3 + c4 * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * TW * 3 + c4 * 4);
+            if (c4 * 4 + 4 <= vw3) *reinterpret_cast<f32x4 *>(o) = v;
+            else for (int i = 0; c4 * 4 + i < vw3; ++i) o[i] = v[i];
+        }
+    }
+}
+
+static Lerp legacy_coord_host(int o, float scale, int n_in)
+{
+    const float f = (float)o * scale;
+    const float fl = floorf(f);
+    Lerp L;
+    L.lo = std::min((int)fl, n_in - 1);
+    L.hi = std::min(L.lo + 1, n_in - 1);
+    L.t = f - fl;
+    return L;
+}
+
+// predict_flow2 gather + glue + warp as one launch; hipErrorNotSupported when a tile's rectangles would not fit the LDS windows (an output
+// much smaller than the flow grid) or the buffers miss the warp kernel's alignment: the caller then runs the two launches
+hipError_t launch_pf2_glue_warp(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2, int H, int W,
+                                const float *img, float *outflow, float *out, int oh, int ow, hipStream_t stream)
+{
+    const int h = H - 2, w = W - 2;
+    if (B < 1 || h < 1 || w < 2 || oh < 1 || ow < 1) return hipErrorNotSupported;
+    if (!warp3_ok(img, out, outflow, B, oh, ow, 3) || ((uintptr_t)pf2 & 7)) return hipErrorNotSupported;
+    const GlueParams G = glue_params(h, w, oh, ow, H, W);
+    TailParams P{h2, w2, h3, w3, H, W, H > 1 ? (float)(h2 + 2 - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w2 + 2 - 1) / (float)(W - 1) : 0.f,
+                 (float)h3 / (float)h, (float)w3 / (float)w};
+    const int tx = (ow + WT_TW - 1) / WT_TW, ty = (oh + WT_TH - 1) / WT_TH;
+    if ((long long)tx * ty * B >= (1ll << 31)) return hipErrorNotSupported;
+    // the largest rectangles of any tile, rows and columns separately (the device evaluates the same fp32 maps); the tiles' owned ranges
+    // must tile [0, h) x [0, w) without gaps: lo(0) = 0 and the ranges are consecutive by construction
+    auto span = [&](int tiles, int T_, int OUT, float r, int nflow, float ns, int ntab, int &pf_max, int &t_max) {
+        for (int t = 0; t < tiles; ++t) {
+            const int o0 = t * T_, ol = std::min(o0 + T_ - 1, OUT - 1);
+            const int w0 = legacy_coord_host(o0, r, nflow).lo;
+            const int own1 = t == tiles - 1 ? nflow : legacy_coord_host(o0 + T_, r, nflow).lo;
+            const int w1 = std::max(legacy_coord_host(ol, r, nflow).hi, own1 - 1);
+            pf_max = std::max(pf_max, w1 - w0 + 1);
+            t_max = std::max(t_max, nearest_ac_host(w1 + 2, ns, ntab + 2) - nearest_ac_host(w0, ns, ntab + 2) + 1);
+        }
+    };
+    if (legacy_coord_host(0, G.ry, h).lo != 0 || legacy_coord_host(0, G.rx, w).lo != 0) return hipErrorNotSupported;
+    int pr = 0, pc = 0, tr = 0, tc = 0;
+    span(ty, WT_TH, oh, G.ry, h, P.nsy, h2, pr, tr);
+    span(tx, WT_TW, ow, G.rx, w, P.nsx, w2, pc, tc);
+    if (pr * pc > FT_PF_CAP || tr * tc > FT_T_CAP) return hipErrorNotSupported;
+    const long long total = (long long)B * oh * ow;
+    // compulsory traffic: tap-table rows, the coarser flow, predict_flow2 WRITTEN once (never re-read), frame read, warped (and the
+    // output-resolution flow) written
+    const double alg_bytes = 128.0 * B * h2 * w2 + 8.0 * B * h3 * w3 + 8.0 * B * h * w + (outflow ? 32.0 : 24.0) * total;
+    const dim3 grid((unsigned)((long long)tx * ty * B)), block(256);
+#define VSTAB_TAIL(WF, ST) launch_timed(HBM_SLOT_TAIL, alg_bytes, pf2_glue_warp_kernel<WF, ST>, grid, block, stream, T, bias2, pf3, pf2, img, out, outflow, B, oh, ow, tx, ty, P, G)
+    if (outflow) return (ow & 3) == 0 ? VSTAB_TAIL(true, true) : VSTAB_TAIL(true, false);
+    return (ow & 3) == 0 ? VSTAB_TAIL(false, true) : VSTAB_TAIL(false, false);
+#undef VSTAB_TAIL
+}
+
+// ---------------------------------------------------------------------------------
 // The evaluator's frame path in ONE launch, 8-bit in and out (main:568, 497-514, 625/630): frame_f = swap(frame)/255, outflow =
 // glue(flow), warped = tf_warp(frame_f, outflow), out = uint8(swap(warped*255)) -- without frame_f and warped ever existing in HBM
 // (the clip driver ran four launches here: frame_to_float, the fused glue + warp, quantise_output; 2 x 12 B/px of fp32 traffic more).

@@ -278,10 +278,13 @@ hipError_t launch_resize_bilinear_slice3(const float *x, int B, int h, int w, in
 hipError_t launch_warp_flow(const float *img, const float *flow, float *out, int B, int H, int W,
                             int C, hipStream_t stream);
 // per-launch timing of the HBM-side kernels (flow_ops.hip): slots of vstab_hbm_profile_read
-enum { HBM_SLOT_WARP = 0, HBM_SLOT_GLUE = 1, HBM_SLOT_GLUE_WARP = 2, HBM_SLOT_PF2 = 3, HBM_SLOT_ST = 4, HBM_SLOT_HOMOG = 5, HBM_SLOTS = 6 };
+enum { HBM_SLOT_WARP = 0, HBM_SLOT_GLUE = 1, HBM_SLOT_GLUE_WARP = 2, HBM_SLOT_PF2 = 3, HBM_SLOT_ST = 4, HBM_SLOT_HOMOG = 5, HBM_SLOT_TAIL = 6, HBM_SLOTS = 7 };
 void hbm_profile_enable(int mode);
 hipError_t hbm_profile_read(int slot, double *ms_sum, int *launches, double *alg_bytes_sum);
 hipError_t launch_div_const_selftest(float d, unsigned first, unsigned long long count, unsigned long long *bad, hipStream_t stream);
+// predict_flow2 gather + flow glue + tf_warp in ONE launch (flow_ops.hip); hipErrorNotSupported = run the two launches instead
+hipError_t launch_pf2_glue_warp(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2, int H, int W,
+                                const float *img, float *outflow, float *out, int oh, int ow, hipStream_t stream);
 hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *out, int oh, int ow,
                                  int C, int net_h, int net_w, hipStream_t stream);
 // 2x2 stride-2 SAME max pool (vgg16.py:51-53), NHWC, C % 4 == 0

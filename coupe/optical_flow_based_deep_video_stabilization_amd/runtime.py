@@ -25,7 +25,7 @@ def trace_ranges(on: bool):
     _lib.check(_lib.lib().vstab_trace_ranges(int(bool(on))))
 
 
-HBM_SLOTS = ("warp_flow", "flow_resize_scale", "flow_glue_warp", "pf2_gather", "st_sampler", "homography_warp")
+HBM_SLOTS = ("warp_flow", "flow_resize_scale", "flow_glue_warp", "pf2_gather", "st_sampler", "homography_warp", "pf2_glue_warp")
 
 
 def hbm_profile(mode: int):
@@ -66,7 +66,8 @@ class Context:
         self._ws.clear()
 
     def set_plan_flags(self, flags: int):
-        """VSTAB_PLAN_* bits (1 = few-row layers stay on the tiled kernel + split-K combine launch: A/B runs and tests)."""
+        """VSTAB_PLAN_* bits (diagnostic; 1 = few-row layers stay on the tiled kernel + split-K combine launch, 2 = refinement levels as four
+        launches, 4 = the one-call stabiliser's last two launches kept apart: A/B runs and tests)."""
         _lib.check(_lib.lib().vstab_set_plan_flags(self._h, int(flags)), self._h)
         self.plan_flags = int(flags)
         self._ws.clear()

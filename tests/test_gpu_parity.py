@@ -92,6 +92,53 @@ def test_fused_glue_warp_bit_identical(B, hn, wn, oh, ow):
     assert torch.equal(wp.cpu(), vo.tf_warp(frame.cpu(), of.cpu(), oh, ow, torch.float32))
 
 
+@pytest.mark.parametrize("B,hn,wn,oh,ow,fused", [
+    (8, 512, 512, 512, 512, True),       # BASELINE configs[1]: the headline step
+    (1, 256, 256, 256, 256, True),       # configs[0]
+    (1, 384, 512, 720, 1280, True),      # the clip driver's shape: the output 1.9x the flow grid
+    (2, 200, 264, 200, 264, True),       # ragged tiles on both axes
+    (3, 136, 200, 250, 333, True),       # output width not a multiple of 4: unstaged stores
+    (2, 128, 160, 120, 150, True),       # output slightly SMALLER than the flow grid (126 x 158): source steps of more than one pixel
+    (1, 384, 512, 96, 128, False),       # output a quarter of the flow grid: the rectangles do not fit LDS -> two launches, same bits
+])
+def test_fused_tail_bit_identical(B, hn, wn, oh, ow, fused):
+    # vstab_stabilise_originalsize ends in ONE launch for predict_flow2's gather (model.py:882-887), the glue (main:497-498) and tf_warp
+    # (main:514) when the geometry allows: every output -- the five flows, the output-resolution flow, the warped frame -- must carry
+    # the bits of the separate launches (plan flag 4), with and without the output-resolution flow; predict_flow2 is written once by
+    # the tiles that own its pixels (sentinel check: no pixel left unwritten).
+    import ctypes as C
+    runtime.reset()
+    vs.assign_weights(wts.synthetic_weights(seed=6, cin=27, random_bn=True, flow_gain=1.0))
+    ctx = runtime.get_context()
+    g = torch.Generator().manual_seed(hn * 7 + ow)
+    feats = torch.rand(B, hn, wn, 27, generator=g).cuda()
+    frame = torch.rand(B, oh, ow, 3, generator=g).cuda()
+    for want in (True, False):
+        ctx.set_plan_flags(4)
+        ref = vs.OriginalSizeStabiliser(B, hn, wn, 27, oh, ow, want_outflow=want)
+        rf, ro, rw = ref(feats, frame)
+        rf = {k: v.clone() for k, v in rf.items()}
+        ro, rw = (ro.clone() if want else None), rw.clone()
+        ctx.set_plan_flags(0)
+        st = vs.OriginalSizeStabiliser(B, hn, wn, 27, oh, ow, want_outflow=want)
+        st.flows[4].fill_(float("nan"))                 # predict_flow2: every pixel must be written by its owner tile
+        st.warped.fill_(float("nan"))
+        runtime.hbm_profile(1)
+        f, o, w_ = st(feats, frame)
+        torch.cuda.synchronize()
+        runtime.hbm_profile(0)
+        prof = runtime.hbm_profile_read()
+        assert (prof["pf2_glue_warp"][1] == 1) == fused and (prof["flow_glue_warp"][1] == 1) == (not fused)
+        for k in rf:
+            assert torch.equal(f[k], rf[k]), (k, want)
+        assert torch.equal(w_, rw), want
+        if want:
+            assert torch.equal(o, ro)
+        else:
+            assert o is None
+    runtime.reset()
+
+
 def test_glue_division_by_launch_constants_is_the_ieee_quotient():
     # The glue divides by three constants of the launch (main:497-498: /382, /512, /384).  The kernels do it with five fused
     # operations on a host-side reciprocal instead of the ~11-instruction run-time division; this compares the two ON THE DEVICE:
