@@ -841,7 +841,9 @@ static int forward_impl(vstab_ctx *ctx, const float *feats, int B, int H, int W,
     // 2 GiB; equal chunks share one launch plan, so their results are bit-identical -- and so are ragged ones under a pinned plan batch
     const int chunk = chunk_size(pin, B, H, W, Cin);
     if (chunk < 1) return fail(ctx, VSTAB_E_SHAPE, "forward: one %dx%dx%d sample exceeds the 2 GiB tensor limit", H, W, Cin);
-    bool all_fused = tail != nullptr;
+    // a batch processed in several chunks hands every chunk its slice of the frames: the slices keep the fused launch's 16-byte alignment
+    // only when a frame is a whole number of 16-byte units (else: the two launches after the last chunk, as before)
+    bool all_fused = tail != nullptr && (chunk >= B || ((size_t)tail->oh * tail->ow * 4) % 16 == 0);
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int bc = std::min(chunk, B - b0);
         FusedTail t{};
@@ -1195,7 +1197,7 @@ extern "C" int vstab_stabilise_originalsize(vstab_ctx *ctx, const float *feats, 
     if (oh < 1 || ow < 1) return fail(ctx, VSTAB_E_SHAPE, "stabilise_originalsize: bad output size");
     // the tail (predict_flow2's gather, the glue, tf_warp) rides in the forward's last launch when its geometry allows (flow_ops.hip)
     FusedTail tail{frame, outflow, warped, oh, ow, false};
-    const bool try_fused = (((uintptr_t)frame | (uintptr_t)warped | (uintptr_t)outflow) & 15) == 0 && ((size_t)oh * ow * 4) % 16 == 0;
+    const bool try_fused = (((uintptr_t)frame | (uintptr_t)warped | (uintptr_t)outflow) & 15) == 0;
     const int rc = forward_impl(ctx, feats, B, H, W, Cin, pf6, pf5, pf4, pf3, pf2, workspace, workspace_bytes, stream, try_fused ? &tail : nullptr);
     if (rc != VSTAB_OK) return rc;
     if (tail.fused) return VSTAB_OK;
