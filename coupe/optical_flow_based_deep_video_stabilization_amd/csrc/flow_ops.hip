@@ -769,7 +769,7 @@ hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const f
 // boundary less, and the warp's L1 tag pipe -- its limit -- loses the two flow lookups per pixel.  Same fp32 operations in the same
 // order as the two launches: bit-identical (tests/test_gpu_parity.py::test_fused_tail_bit_identical).
 // ---------------------------------------------------------------------------------
-constexpr int FT_PF_CAP = 704, FT_T_CAP = 160;      // predict_flow2 window pixels (18 x 34 = 612) and tap-table window pixels held in LDS
+constexpr int FT_PF_CAP = 640, FT_T_CAP = 96;       // predict_flow2 window pixels (18 x 34 = 612) and tap-table window pixels (7 x 11 = 77) held in LDS
 struct TailParams {
     int h2, w2, h3, w3, H, W;                       // tap table grid, predict_flow3 grid, network input size (predict_flow2 is (H-2) x (W-2))
     float nsy, nsx, usy, usx;
@@ -781,9 +781,12 @@ __global__ __launch_bounds__(256) void pf2_glue_warp_kernel(const float *__restr
                                                             TailParams P, GlueParams G)
 {
     constexpr int TH = WT_TH, TW = WT_TW, WH = WT_WH, WW = WT_WW, PPT = WT_PPT, PPR = TW / WW;
-    __shared__ __attribute__((aligned(8))) float tab[FT_T_CAP * 18];
+    // the tap-table window is dead once predict_flow2's rectangle is in `pfw` (second barrier): the output staging tile takes its place
+    // (12 KB of LDS per workgroup instead of 23: the wave limit of the register file, not LDS, bounds the occupancy)
+    constexpr int TAB_FLOATS = FT_T_CAP * 18, STAGE_FLOATS = STAGE ? TH * TW * 3 : 4;
+    __shared__ __attribute__((aligned(16))) float tab[TAB_FLOATS > STAGE_FLOATS ? TAB_FLOATS : STAGE_FLOATS];
     __shared__ __attribute__((aligned(8))) f32x2 pfw[FT_PF_CAP];
-    __shared__ __attribute__((aligned(16))) float stage[STAGE ? TH * TW * 3 : 4];
+    float *stage = tab;
     unsigned bx, by, bz;
     xcd_remap_calc(gridDim.x, 1, 1, blockIdx.x, bx, by, bz);
     const int tpi = tiles_x * tiles_y;
