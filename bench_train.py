@@ -149,6 +149,14 @@ def main():
         for _ in range(3):
             tr.step(feats, gt, un, lr=1e-4)
         fam = tr.profile_read()
+        if rank == 0 and tr.calls:          # per call, in issue order (a step's calls repeat three times): the layer-level view
+            n1 = len(tr.calls) // 3
+            print(f"{'#':>3} {'family':<24}{'GFLOP':>9}{'ms':>9}{'TFLOP/s':>9}{'frac':>7}", file=sys.stderr)
+            for i in range(n1):
+                kind, fl = tr.calls[i][0], tr.calls[i][1]
+                ms = sum(tr.calls[i + r * n1][2].elapsed_time(tr.calls[i + r * n1][3]) for r in range(3)) / 3
+                tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                print(f"{i:>3} {kind:<24}{fl / 1e9:>9.2f}{ms:>9.4f}{tf:>9.1f}{tf / MFMA_F32_PEAK_TFLOPS:>7.3f}", file=sys.stderr)
         tr.profile_calls(False)
         if fam:
             rows = {k: {"ms_per_step": round(ms / 3, 4), "calls_per_step": n // 3, "gflop_per_step": round(fl / 3 / 1e9, 2),
