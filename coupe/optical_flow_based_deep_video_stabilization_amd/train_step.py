@@ -161,6 +161,21 @@ class Trainer:
         self.T = z(h2, w2, 32)                                                              # F7's tap table and its gradient
         self.dT = z(h2, w2, 32)
         self.pf2c = torch.zeros((B, H - 2, W - 2, 2), dtype=torch.float32, device=self.dev)
+        # the pyramid heads predict_flow6..3 run through tap tables too (round 5; see _head_forward): per level the table and its
+        # gradient [B,h,w,32], the gathered conv output in 2-channel pixels, and the head's filter as the [cs_in, 32] matrix of the
+        # table's 1x1 conv, its transpose and its gradient (the zero columns 18..31 / pad rows are written once, here)
+        self.Th, self.dTh, self.pc2, self.WTh, self.WTth, self.dWTh = {}, {}, {}, {}, {}, {}
+        for pname, (pin, _c) in PRED_IN.items():
+            level = "predict_flow" + pname[-1]
+            cs = BUF_C[pin]
+            if pname != "predict2":
+                fh, fw = self.flow_hw[level]
+                self.Th[level], self.dTh[level] = z(fh, fw, 32), z(fh, fw, 32)
+                self.pc2[level] = torch.zeros((B, fh, fw, 2), dtype=torch.float32, device=self.dev)
+            self.WTh[level] = torch.zeros((1, 1, cs, 32), dtype=torch.float32, device=self.dev)
+            self.WTth[level] = torch.zeros((1, 1, 32, cs), dtype=torch.float32, device=self.dev)
+            self.dWTh[level] = torch.zeros((1, 1, cs, 32), dtype=torch.float32, device=self.dev)
+        self.zero_flow = torch.zeros((B, 1, 1, 2), dtype=torch.float32, device=self.dev)
         self.save = {}                                                                       # BatchNorm (mean, rstd) per layer
 
     def _workspace(self, nbytes):
@@ -313,7 +328,7 @@ class Trainer:
             level = "predict_flow" + pname[-1]
             pin, _ = PRED_IN[pname]
             cs_in = a[pin].shape[3]
-            self._conv_fwd(a[pin], 0, cs_in, p[f"{pname}/W_conv2d"], p[f"{pname}/b_conv2d"], 3, 1, 1, self.pconv[level], 0, 4)
+            self._head_forward(pname, level, a[pin], cs_in)
             if prev is None:
                 self.pf[level].copy_(self.pconv[level])
             else:                                                                         # (conv + up) + up, model.py:857
@@ -328,9 +343,7 @@ class Trainer:
         # full-resolution head (model.py:882-887) through its tap table, as in the inference path: the padded, nearest-upsampled
         # concat2 (1.6 GB at B=8 512x512) never exists.  T[s][tap*2+o] = sum_c concat2[s][c] W[tap][c][o] is a 1x1 conv.
         c2 = a["concat2"]
-        w2 = p["predict2/W_conv2d"]                                                       # [3,3,196,4], columns 2,3 zero
-        self.WT = torch.zeros((1, 1, 196, 32), dtype=torch.float32, device=self.dev)
-        self.WT[0, 0, :, :18].copy_(w2[..., :2].permute(2, 0, 1, 3).reshape(196, 18))
+        self.WT = self._head_matrix("predict2", "predict_flow2", 196)                     # [1,1,196,32] from [3,3,196,4] (columns 2,3 zero)
         self._conv_fwd(c2, 0, 196, self.WT, None, 1, 1, 0, self.T, 0, 32)
         pf3c = self.pf["predict_flow3"][..., :2].contiguous()
         h3, w3 = pf3c.shape[1], pf3c.shape[2]
@@ -338,6 +351,40 @@ class Trainer:
                                                pf3c.data_ptr(), h3, w3, self.pf2c.data_ptr(), self.H, self.W, self.st))
         self.pf["predict_flow2"][..., :2].copy_(self.pf2c)
         return {k: v[..., :2] for k, v in self.pf.items()}
+
+    def _head_matrix(self, pname, level, cs):
+        """The 3x3 -> 2 head's filter [3,3,cs,4] as the matrix of its tap table's 1x1 conv: WT[c][tap*2+o] = W[tap][c][o] (o < 2), into the
+        level's persistent [1,1,cs,32] buffer (one strided copy; columns 18..31 stay zero)."""
+        WT = self.WTh[level]
+        WT[0, 0, :, :18].view(cs, 3, 3, 2).copy_(self.p[f"{pname}/W_conv2d"][..., :2].permute(2, 0, 1, 3))
+        return WT
+
+    def _head_forward(self, pname, level, x, cs):
+        """predict_flowN's 3x3 pad-1 conv to 2 channels (model.py:848, 856, 865, 874) through its tap table, as the inference path and the
+        full-resolution head do: T[s][tap*2+o] = sum_c x[s][c] W[tap][c][o] is a 1x1 conv to 18 (of 32) columns -- the input is read ONCE
+        instead of nine times by an im2col GEMM whose N is 4 -- and the conv output gathers its nine in-image taps + bias.  The gather is
+        vstab_pf2_from_taps with H = h + 2, W = w + 2: the nearest-neighbour map of the full-resolution head is then the identity, and
+        its eight adds of the upsampled coarser flow add a zero field.  Result -> pconv[level] channels 0..1 (2..3 stay zero)."""
+        B, h, w, _ = x.shape
+        WT = self._head_matrix(pname, level, cs)
+        self._conv_fwd(x, 0, cs, WT, None, 1, 1, 0, self.Th[level], 0, 32)
+        self._check(self.L.vstab_pf2_from_taps(self.Th[level].data_ptr(), B, h, w, self.p[f"{pname}/b_conv2d"].data_ptr(),
+                                               self.zero_flow.data_ptr(), 1, 1, self.pc2[level].data_ptr(), h + 2, w + 2, self.st))
+        self.pconv[level][..., :2].copy_(self.pc2[level])
+
+    def _head_backward(self, pname, level, x, cs, Gx, acc):
+        """Its backward: dT = the adjoint of the tap gather applied to the flow gradient (vstab_pf2_taps_backward, identity map), the
+        filter gradient = x^T dT (a 1x1 filter gradient: K = the pixels), the input gradient = dT W^T (1x1 conv, accumulated into the
+        concat gradient when something was written there before), the bias gradient = the column sums of the flow gradient."""
+        B, h, w, _ = x.shape
+        d, dT, dWT = self.dpf[level], self.dTh[level], self.dWTh[level]
+        self._check(self.L.vstab_pf2_taps_backward(d.data_ptr(), 4, B, h + 2, w + 2, dT.data_ptr(), h, w, self.st))
+        self._wgrad(x, 0, cs, dT, 0, 32, 1, 1, 0, dWT, None)
+        self.g[f"{pname}/W_conv2d"][..., :2].copy_(dWT[0, 0, :, :18].view(cs, 3, 3, 2).permute(1, 2, 0, 3))
+        self._colsum(d, 0, 4, self.g[f"{pname}/b_conv2d"])
+        WTt = self.WTth[level]
+        WTt[0, 0].copy_(self.WTh[level][0, 0].t())
+        self._conv_fwd(dT, 0, 32, WTt, None, 1, 1, 0, Gx, 0, cs, act=3 if acc else 0)
 
     def lrelu_masks(self) -> Dict[str, torch.Tensor]:
         """{BatchNorm layer: y > 0} of the last forward (host bool tensors): which side of the leaky relu every element is on."""
@@ -388,11 +435,12 @@ class Trainer:
         self._colsum(d2, 0, 4, g["predict2/b_conv2d"])
         self._check(self.L.vstab_pf2_taps_backward(d2.data_ptr(), 4, self.B, self.H, self.W, self.dT.data_ptr(), c2.shape[1], c2.shape[2],
                                                    self.st))
-        dWT = torch.empty((1, 1, 196, 32), dtype=torch.float32, device=self.dev)
+        dWT = self.dWTh["predict_flow2"]
         self._wgrad(c2, 0, 196, self.dT, 0, 32, 1, 1, 0, dWT, None)
         # (the padded output channels of predict2's filter gradient keep the zeros they were created with)
-        g["predict2/W_conv2d"][..., :2].copy_(dWT[0, 0, :, :18].reshape(196, 3, 3, 2).permute(1, 2, 0, 3))
-        WTt = self.WT[0, 0].t().contiguous().view(1, 1, 32, 196)
+        g["predict2/W_conv2d"][..., :2].copy_(dWT[0, 0, :, :18].view(196, 3, 3, 2).permute(1, 2, 0, 3))
+        WTt = self.WTth["predict_flow2"]
+        WTt[0, 0].copy_(self.WT[0, 0].t())
         self._conv_fwd(self.dT, 0, 32, WTt, None, 1, 1, 0, G["concat2"], 0, 196, act=3 if self._acc("concat2") else 0)
         # decoder levels, fine to coarse
         levels = ["predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3"]
@@ -414,8 +462,7 @@ class Trainer:
             if i > 0:
                 self._resize_bwd(self.dpf[level], self.dpf[levels[i - 1]], 2.0)
             pin, _ = PRED_IN[pname]
-            self._wgrad(a[pin], 0, a[pin].shape[3], self.dpf[level], 0, 4, 3, 1, 1, g[f"{pname}/W_conv2d"], g[f"{pname}/b_conv2d"])
-            self._convT(self.dpf[level], 0, 4, p[f"{pname}/W_conv2d"], None, 3, 1, 1, G[pin], 0, a[pin].shape[3], self._acc(pin))
+            self._head_backward(pname, level, a[pin], a[pin].shape[3], G[pin], self._acc(pin))
         self._grads_ready(self.BUCKET_ENDS[0])
         # encoder, last stage first
         for name, k, s, pad, cout in reversed(ENC):

@@ -52,6 +52,37 @@ def test_generic_conv_through_the_assembly_k_loop(B, H, W, cin, k, s, p, cout):
     assert float((y.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("cout", [132, 388, 160, 129])
+@pytest.mark.parametrize("B,H,W,cin,k,s,p", [(2, 16, 20, 64, 4, 2, 1), (1, 12, 12, 36, 3, 1, 1), (3, 8, 8, 32, 1, 1, 0)])
+def test_conv_forward_splits_a_few_column_tail_into_its_own_launch(B, H, W, cin, k, s, p, cout):
+    """128 q + r output channels with r <= 32 and a multiple of 4 (the decoder's concat widths 388 / 772 / 1028 as the N of its input
+    gradients) run as two launches -- columns [0, 128 q) on the wide tile, the tail on the 32-column tile, both reading their column
+    range of the ONE filter tensor; other widths (129: r not a multiple of 4; 160: r = 32 -> split) keep one launch.  Bias slices and
+    act = 3 (accumulate into y) must follow the split."""
+    g = torch.Generator().manual_seed(cout * 7 + cin + k)
+    x = torch.randn(B, H, W, cin, generator=g)
+    Wt = torch.randn(k, k, cin, cout, generator=g) / (k * k * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    if cout % 4:
+        pytest.skip("channel counts are multiples of 4 on this path")
+    y = _conv_forward(x.cuda(), Wt.cuda(), b.cuda(), k, s, p)
+    ref = _ref(x, Wt, b, k, s, p)
+    tol = 2e-5 * float(ref.abs().max()) + 1e-6
+    assert y.shape == ref.shape and float((y.double().cpu() - ref).abs().max()) <= tol
+    # accumulate: y0 + conv (no bias)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    y0 = torch.randn(B, Ho, Wo, cout, generator=g)
+    L = _lib.lib()
+    yd, xd, Wd = y0.cuda(), x.cuda(), Wt.cuda()
+    n = L.vstab_conv_forward_workspace_bytes(B, H, W, cin, cin, k, s, p, cout, cout, 0, 3, Ho, Wo)
+    ws = torch.empty(int(n) + 256, dtype=torch.uint8, device="cuda")
+    _lib.check(L.vstab_conv_forward(xd.data_ptr(), B, H, W, cin, 0, cin, Wd.data_ptr(), None, k, s, p, yd.data_ptr(), Ho, Wo, cout, 0, cout, 3,
+                                    ws.data_ptr(), ws.numel(), None))
+    torch.cuda.synchronize()
+    ref2 = y0.double() + _ref(x, Wt, torch.zeros(cout), k, s, p)
+    assert float((yd.double().cpu() - ref2).abs().max()) <= 2e-5 * float(ref2.abs().max()) + 1e-6
+
+
 # ----------------------------------------------------------------------------- predict_flow2's tap table (csrc/tap_panel.hip)
 def _tap_table(W):
     """[200][32] device table of vstab_predict2_tap_table from the head's filter W [3,3,194,2]"""
