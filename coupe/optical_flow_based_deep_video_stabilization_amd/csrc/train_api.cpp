@@ -416,16 +416,14 @@ extern "C" int vstab_lrelu_backward(const float *y, int cs_y, int cy_off, float 
 
 // ------------------------------------------------------------------------- forward conv with device-resident raw weights
 namespace {
-// columns [n0, n0 + cout) of a filter with w_cout output channels (the whole filter: n0 = 0, w_cout = cout)
 bool fwd_plan(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int pad, int cout, int cs_y, int cy_off, int act, int Ho, int Wo,
-              DgradPlan &out, int n0 = 0, int w_cout = 0)
+              DgradPlan &out)
 {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int>, DgradPlan> cache;
+    static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int, int, int>, DgradPlan> cache;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;             // (a table-packed plan owns device memory)
-    if (w_cout == 0) w_cout = cout;
-    const auto key = std::make_tuple(dev, B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo, n0, w_cout);
+    const auto key = std::make_tuple(dev, B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo);
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) { out = it->second; return true; }
@@ -444,14 +442,11 @@ bool fwd_plan(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int p
     const KLayout L{d.p.KH, d.p.NSEG, d.p.SEG, d.p.SEGP, d.p.SEG_STRIDE};
     d.packed_floats = (size_t)L.ktiles() * d.p.Npad * 32;
     if (d.p.ksplit > 1) d.part_floats = (size_t)d.p.nphase * d.p.ksplit * d.p.Mmax * d.p.Npad;
-    if (L.NSEG == 1 && L.SEG == L.SEGP && cs_x == cin && (cout & 3) == 0 && (d.p.Npad & 63) == 0 && n0 == 0 && w_cout == cout) {
+    if (L.NSEG == 1 && L.SEG == L.SEGP && cs_x == cin && (cout & 3) == 0 && (d.p.Npad & 63) == 0) {
         d.blocked_K = L.KH * L.SEG;              // HWIO with its first three axes flattened IS the [K][N] matrix
     } else {
         std::vector<int32_t> tbl(d.packed_floats);
         pack_index_conv(k, k, cin, cs_x, cout, d.p.Npad, L, tbl.data());
-        if (n0 != 0 || w_cout != cout)           // a column range of a wider filter: element (row, n) sits at row * w_cout + n0 + n
-            for (int32_t &e : tbl)              // (entries are source index + 1; 0 = a zero of the padding)
-                if (e > 0) { const int32_t src = e - 1; e = (src / cout) * w_cout + n0 + src % cout + 1; }
         if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;
         if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d.tbl); return false; }
     }
@@ -461,18 +456,27 @@ bool fwd_plan(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int p
 }
 }  // namespace
 
-namespace {
-// A filter of 128 q + r output channels with 1 <= r <= 32 (the concat widths 388 = 3 x 128 + 4, 772, 1028 of the decoder's input
-// gradients) would pay a whole 128-column tile for its last r columns; it runs as TWO launches instead: columns [0, 128 q) on the wide
-// tile, the tail on the 32-column tile (0.25 of a column tile's work).  Returns the tail's width, 0 = one launch.
-int fwd_tail_cols(int cout) { const int r = cout % 128; return (cout > 128 && r >= 1 && r <= 32) ? r : 0; }
-
-int conv_forward_range(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *W, const float *bias_in, int k, int stride,
-                       int pad, float *y, int Ho, int Wo, int cs_y, int cy_off, int cout, int act, void *workspace, size_t workspace_bytes, void *stream,
-                       int n0, int w_cout)
+extern "C" size_t vstab_conv_forward_workspace_bytes(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int pad, int cout, int cs_y,
+                                                     int cy_off, int act, int Ho, int Wo)
 {
     DgradPlan d;
-    if (!fwd_plan(B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo, d, n0, w_cout))
+    if (!fwd_plan(B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo, d)) return 0;
+    size_t a, b;
+    return dgrad_ws(d, &a, &b);
+}
+
+extern "C" int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *W, const float *bias_in,
+                                  int k, int stride, int pad, float *y, int Ho, int Wo, int cs_y, int cy_off, int cout, int act,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!x || !W || !y || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv_forward: NULL buffer");
+    if (B < 1 || Hi < 1 || Wi < 1 || k < 1 || k > 7 || stride < 1 || pad < 0 || cin < 1 || cout < 1 || cx_off < 0 || cy_off < 0 ||
+        cx_off + cin > cs_x || cy_off + cout > cs_y || act < 0 || act > 3)
+        return fail(nullptr, VSTAB_E_SHAPE, "conv_forward: bad shape");
+    if ((cx_off & 3) || (cy_off & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 255))
+        return fail(nullptr, VSTAB_E_ALIGN, "conv_forward: channel offsets multiples of 4, x 16-byte, workspace 256-byte aligned");
+    DgradPlan d;
+    if (!fwd_plan(B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo, d))
         return fail(nullptr, VSTAB_E_SHAPE, "conv_forward: unsupported geometry");
     size_t bias_off, part_off;
     const size_t need = dgrad_ws(d, &bias_off, &part_off);
@@ -497,45 +501,6 @@ int conv_forward_range(const float *x, int B, int Hi, int Wi, int cs_x, int cx_o
     p.partial = reinterpret_cast<float *>(ws + part_off);
     HIP_TRY(nullptr, launch_conv(p, d.tile, d.vec4, st));
     return VSTAB_OK;
-}
-}  // namespace
-
-extern "C" size_t vstab_conv_forward_workspace_bytes(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int pad, int cout, int cs_y,
-                                                     int cy_off, int act, int Ho, int Wo)
-{
-    DgradPlan d;
-    size_t a, b;
-    const int r = fwd_tail_cols(cout);
-    if (r) {          // two launches, one after the other in the same workspace
-        DgradPlan t;
-        if (!fwd_plan(B, Hi, Wi, cs_x, cin, k, stride, pad, cout - r, cs_y, cy_off, act, Ho, Wo, d, 0, cout) ||
-            !fwd_plan(B, Hi, Wi, cs_x, cin, k, stride, pad, r, cs_y, cy_off + cout - r, act, Ho, Wo, t, cout - r, cout)) return 0;
-        return std::max(dgrad_ws(d, &a, &b), dgrad_ws(t, &a, &b));
-    }
-    if (!fwd_plan(B, Hi, Wi, cs_x, cin, k, stride, pad, cout, cs_y, cy_off, act, Ho, Wo, d)) return 0;
-    return dgrad_ws(d, &a, &b);
-}
-
-extern "C" int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *W, const float *bias_in,
-                                  int k, int stride, int pad, float *y, int Ho, int Wo, int cs_y, int cy_off, int cout, int act,
-                                  void *workspace, size_t workspace_bytes, void *stream)
-{
-    if (!x || !W || !y || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv_forward: NULL buffer");
-    if (B < 1 || Hi < 1 || Wi < 1 || k < 1 || k > 7 || stride < 1 || pad < 0 || cin < 1 || cout < 1 || cx_off < 0 || cy_off < 0 ||
-        cx_off + cin > cs_x || cy_off + cout > cs_y || act < 0 || act > 3)
-        return fail(nullptr, VSTAB_E_SHAPE, "conv_forward: bad shape");
-    if ((cx_off & 3) || (cy_off & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 255))
-        return fail(nullptr, VSTAB_E_ALIGN, "conv_forward: channel offsets multiples of 4, x 16-byte, workspace 256-byte aligned");
-    const int r = fwd_tail_cols(cout);
-    if (r && (r & 3) == 0) {       // (the tail's channel offset must stay a multiple of 4: cout - r is a multiple of 128)
-        const int rc = conv_forward_range(x, B, Hi, Wi, cs_x, cx_off, cin, W, bias_in, k, stride, pad, y, Ho, Wo, cs_y, cy_off, cout - r, act, workspace,
-                                          workspace_bytes, stream, 0, cout);
-        if (rc != VSTAB_OK) return rc;
-        return conv_forward_range(x, B, Hi, Wi, cs_x, cx_off, cin, W, bias_in ? bias_in + (cout - r) : nullptr, k, stride, pad, y, Ho, Wo, cs_y,
-                                  cy_off + cout - r, r, act, workspace, workspace_bytes, stream, cout - r, cout);
-    }
-    return conv_forward_range(x, B, Hi, Wi, cs_x, cx_off, cin, W, bias_in, k, stride, pad, y, Ho, Wo, cs_y, cy_off, cout, act, workspace, workspace_bytes,
-                              stream, 0, cout);
 }
 
 // ------------------------------------------------------------------------- resampler adjoints, full-res upsampler, Adam
