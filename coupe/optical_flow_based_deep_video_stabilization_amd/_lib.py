@@ -81,6 +81,9 @@ EXPORTS = {
     "vstab_conv_forward_workspace_bytes": (C.c_size_t, [C.c_int] * 14),
     "vstab_conv_forward": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] + [C.c_int] * 6 +
                            [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vstab_conv_rowwin_forward_workspace_bytes": (C.c_size_t, [C.c_int] * 12),
+    "vstab_conv_rowwin_forward": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 3 +
+                                  [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "vstab_conv3x3_winograd_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "vstab_conv3x3_winograd": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p] + [C.c_int] * 3 +
                                [C.c_void_p, C.c_size_t, C.c_void_p]),

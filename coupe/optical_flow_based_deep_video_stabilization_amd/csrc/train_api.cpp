@@ -503,6 +503,107 @@ extern "C" int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_
     return VSTAB_OK;
 }
 
+// ------------------------------------------------------------------------- the first layer on the inference path's row-window kernel
+// model.py:807-808 (PadLayer(3) -> Conv2d 7x7 stride 2 VALID, 27 -> 64) with DEVICE-resident raw weights: conv_rowwin_kernel (stream form,
+// assembly K loop: 0.92 of the MFMA peak at B=8 512x512, where the generic implicit GEMM reaches 0.73) fed by an operand gathered on
+// the device every call -- the host packer's layout, recorded once per geometry as an index table by packing a tensor of indices.
+namespace {
+struct RowWinPlan { RowWinParams r; int32_t *tbl; size_t packed_floats; bool two; RowWinParams t; };
+
+bool rowwin_plan(int B, int H, int W, int Cin, int cs_w, int cout, int k, int stride, int pad, int cs_y, int cy_off, int act, RowWinPlan &out)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int>, RowWinPlan> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const auto key = std::make_tuple(dev, B, H, W, Cin, cs_w, cout, k, stride, pad, cs_y, cy_off, act);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) { out = it->second; return true; }
+    if (cout < 1 || cout > 64 || cs_w < Cin || k < 1 || k > 7 || stride < 1 || pad < 0 || (cy_off & 3) || (cs_y & 3)) return false;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (Ho < 1 || Wo < 1 || (long long)B * H * W * Cin * 4 >= 0x80000000LL || (long long)B * Ho * Wo * cs_y * 4 >= 0x80000000LL) return false;
+    RowWinPlan d{};
+    RowWinParams &r = d.r;
+    r.in_bytes = (unsigned)((long long)B * H * W * Cin * 4);
+    r.B = B; r.Hi = H; r.Wi = W; r.Cs_in = Cin; r.KH = k;
+    r.SEGP = rowwin_segp(-pad, k, Cin);
+    r.s_in = stride; r.off_y = -pad;
+    r.e_off = -pad * Cin - rowwin_lead(-pad, Cin);
+    r.w_a = ((r.e_off % 4) + 4) % 4;
+    r.MB = rowwin_mb(B, Ho, Wo);
+    r.WLEN = round_up(r.s_in * Cin * (64 * r.MB - 1) + r.w_a + r.SEGP, 4);
+    r.Ho = Ho; r.Wo = Wo; r.Cs_out = cs_y; r.c_off = cy_off; r.N = cout; r.Npad = 64; r.act = act;
+    r.in = reinterpret_cast<const float *>(16);       // (rowwin_applicable tests the alignment of the real pointer at launch time)
+    if (!rowwin_applicable(r)) return false;
+    const int rem = Wo % 128;
+    if (r.MB == 2 && Wo > 128 && rem >= 1 && rem <= 64) {      // 128 k + (1..64) columns: k full tiles, then ONE 64-pixel tile (api.cpp's rule)
+        RowWinParams t = r;
+        t.MB = 1; t.ox_base = (Wo / 128) * 128; t.ntile_x = 1;
+        t.WLEN = round_up(t.s_in * Cin * 63 + t.w_a + t.SEGP, 4);
+        if (rowwin_applicable(t)) { r.ntile_x = Wo / 128; d.two = true; d.t = t; }
+    }
+    // the packer's layout as a gather table: pack a filter whose value at (ky, kx, ci, n) is 1 + its index in the [k,k,cs_w,cout] tensor
+    const int lead = rowwin_lead(-pad, Cin);
+    d.packed_floats = (size_t)k * (r.SEGP / 32) * 64 * 32;
+    std::vector<float> idx((size_t)k * k * Cin * cout), packed(d.packed_floats);
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int n = 0; n < cout; ++n)
+                    idx[(((size_t)ky * k + kx) * Cin + ci) * cout + n] = (float)(1 + (((size_t)ky * k + kx) * cs_w + ci) * cout + n);
+    if ((size_t)k * k * cs_w * cout >= (1u << 24)) return false;      // indices must be exact in fp32
+    std::vector<double> ones(64, 1.0);
+    pack_conv_rowwin(idx.data(), ones.data(), k, k, Cin, cout, 64, lead, r.SEGP, packed.data());
+    std::vector<int32_t> tbl(d.packed_floats);
+    for (size_t i = 0; i < tbl.size(); ++i) tbl[i] = (int32_t)packed[i];
+    if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;
+    if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d.tbl); return false; }
+    cache[key] = d;
+    out = d;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t vstab_conv_rowwin_forward_workspace_bytes(int B, int H, int W, int Cin, int cs_w, int cout, int k, int stride, int pad, int cs_y,
+                                                            int cy_off, int act)
+{
+    RowWinPlan d;
+    if (!rowwin_plan(B, H, W, Cin, cs_w, cout, k, stride, pad, cs_y, cy_off, act, d)) return 0;
+    return (d.packed_floats * sizeof(float) + 255) / 256 * 256 + 512;
+}
+
+extern "C" int vstab_conv_rowwin_forward(const float *x, int B, int H, int W, int Cin, const float *Wf, int cs_w, int cout, const float *bias, int k,
+                                         int stride, int pad, float *y, int cs_y, int cy_off, int act, void *workspace, size_t workspace_bytes,
+                                         void *stream)
+{
+    if (!x || !Wf || !y || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv_rowwin_forward: NULL buffer");
+    if (act < 0 || act > 2) return fail(nullptr, VSTAB_E_SHAPE, "conv_rowwin_forward: act must be 0, 1 or 2");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 255))
+        return fail(nullptr, VSTAB_E_ALIGN, "conv_rowwin_forward: x and y 16-byte, workspace 256-byte aligned");
+    RowWinPlan d;
+    if (!rowwin_plan(B, H, W, Cin, cs_w, cout, k, stride, pad, cs_y, cy_off, act, d))
+        return fail(nullptr, VSTAB_E_SHAPE, "conv_rowwin_forward: the row-window kernel does not take this geometry");
+    const size_t poff = (d.packed_floats * sizeof(float) + 255) / 256 * 256;
+    if (workspace_bytes < poff + 512) return fail(nullptr, VSTAB_E_NOMEM, "conv_rowwin_forward: workspace %zu < %zu bytes", workspace_bytes, poff + 512);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(nullptr, rowwin_set_attributes());
+    float *wpk = reinterpret_cast<float *>(workspace);
+    float *b64 = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + poff);
+    HIP_TRY(nullptr, launch_pack_apply(Wf, d.tbl, (long long)d.packed_floats, wpk, st));
+    HIP_TRY(nullptr, hipMemsetAsync(b64, 0, 64 * sizeof(float), st));
+    if (bias) HIP_TRY(nullptr, hipMemcpyAsync(b64, bias, (size_t)cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    RowWinParams r = d.r;
+    r.in = x; r.out = y; r.wpk = wpk; r.bias = b64;
+    if (d.two) {
+        RowWinParams t = d.t;
+        t.in = x; t.out = y; t.wpk = wpk; t.bias = b64;
+        HIP_TRY(nullptr, launch_conv_rowwin(r, st));
+        HIP_TRY(nullptr, launch_conv_rowwin(t, st));
+    } else HIP_TRY(nullptr, launch_conv_rowwin(r, st));
+    return VSTAB_OK;
+}
+
 // ------------------------------------------------------------------------- resampler adjoints, full-res upsampler, Adam
 extern "C" int vstab_resize_bilinear_backward(const float *dout, int B, int oh, int ow, int C, float *din, int h, int w, float gain,
                                               int accumulate, void *stream)

@@ -225,6 +225,21 @@ class Trainer:
             x.data_ptr(), B, Hi, Wi, cs_x, cx_off, cin, W.data_ptr(), b.data_ptr() if b is not None else None,
             k, s, p, y.data_ptr(), Ho, Wo, cs_y, cy_off, cout, act, ws.data_ptr(), ws.numel(), self.st)))
 
+    def _conv1_rowwin(self, x, W, b, k, s, p, y, cout):
+        """model.py:807-808 on conv_rowwin_kernel (vstab_conv_rowwin_forward): x [B,H,W,27] as given, W the padded device filter
+        [k,k,28,64] (its 28th input channel is never read); False when the kernel does not take the geometry."""
+        B, H, Wd, cin = x.shape
+        cs_w = int(W.shape[2])
+        n = self.L.vstab_conv_rowwin_forward_workspace_bytes(B, H, Wd, cin, cs_w, cout, k, s, p, y.shape[3], 0, 0)
+        if n == 0:
+            return False
+        ws = self._workspace(n)
+        Ho, Wo = y.shape[1], y.shape[2]
+        self._timed("conv_forward", 2.0 * B * Ho * Wo * k * k * cin * cout, lambda: self._check(self.L.vstab_conv_rowwin_forward(
+            x.data_ptr(), B, H, Wd, cin, W.data_ptr(), cs_w, cout, b.data_ptr(), k, s, p, y.data_ptr(), y.shape[3], 0, 0,
+            ws.data_ptr(), ws.numel(), self.st)))
+        return True
+
     def _convT(self, g, cg_off, cout, W, b, k, s, p, dx, cx_off, cin, accumulate):
         """dx (+)= transposed conv of g with W [k,k,cin,cout] (conv input gradient; also DeConv2dLayer's forward)."""
         B, Ho, Wo, cs_g = g.shape
@@ -316,11 +331,13 @@ class Trainer:
             raise ValueError(f"feats must be a float32 CUDA tensor {(self.B, self.H, self.W, 27)}")
         self.st = runtime.stream_ptr()
         a, p = self.a, self.p
-        a["x0"][..., :27].copy_(feats)
+        a["x0"][..., :27].copy_(feats)              # the 28-channel copy the first layer's filter gradient reads
         for name, k, s, pad, cout in ENC:                                                # model.py:807-844
             ib, ioff, cin = ENC_IN[name]
             ob, ooff = ENC_OUT[name]
-            if not (k == 3 and s == 1 and self._wino(a[ib], ioff, p[f"{name}/W_conv2d"], False, p[f"{name}/b_conv2d"], a[ob], ooff, 0)):
+            if name == "1" and self._conv1_rowwin(feats.contiguous(), p["1/W_conv2d"], p["1/b_conv2d"], k, s, pad, a[ob], cout):
+                pass                                 # the first layer on the inference path's row-window kernel, straight from the 27-channel input
+            elif not (k == 3 and s == 1 and self._wino(a[ib], ioff, p[f"{name}/W_conv2d"], False, p[f"{name}/b_conv2d"], a[ob], ooff, 0)):
                 self._conv_fwd(a[ib], ioff, cin, p[f"{name}/W_conv2d"], p[f"{name}/b_conv2d"], k, s, pad, a[ob], ooff, cout)
             self._bn_fwd(name, a[ob], ooff, cout)
         prev = None

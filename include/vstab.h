@@ -321,6 +321,15 @@ VSTAB_API size_t vstab_conv_forward_workspace_bytes(int B, int Hi, int Wi, int c
 VSTAB_API int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_x, int cx_off, int cin, const float *W, const float *bias,
                                  int k, int stride, int pad, float *y, int Ho, int Wo, int cs_y, int cy_off, int cout, int act,
                                  void *workspace, size_t workspace_bytes, void *stream);
+/* PadLayer(pad) -> Conv2d(k, stride, VALID) + bias for a FEW-channel input (the network's first layer, model.py:807-808: 27 -> 64, 7x7
+ * stride 2) on the inference path's row-window kernel, with DEVICE-resident raw weights Wf [k,k,cs_w,cout] of which input channels
+ * 0..Cin-1 are used (cs_w >= Cin: the training buffers pad 27 to 28).  x [B,H,W,Cin] contiguous; cout <= 64; act 0 none, 1 leaky relu,
+ * 2 relu; VSTAB_E_SHAPE when the kernel does not take the geometry (the caller then uses vstab_conv_forward). */
+VSTAB_API size_t vstab_conv_rowwin_forward_workspace_bytes(int B, int H, int W, int Cin, int cs_w, int cout, int k, int stride, int pad, int cs_y,
+                                                           int cy_off, int act);
+VSTAB_API int vstab_conv_rowwin_forward(const float *x, int B, int H, int W, int Cin, const float *Wf, int cs_w, int cout, const float *bias, int k,
+                                        int stride, int pad, float *y, int cs_y, int cy_off, int act, void *workspace, size_t workspace_bytes,
+                                        void *stream);
 /* The same for a 3x3 stride-1 pad-1 layer in Winograd F(2x2,3x3) form (4/9 of the multiply-adds): transpose = 0 is the forward
  * convolution x [.., cin] -> y [.., cout]; transpose = 1 the input gradient (x = output gradient [.., cout] -> y = dx [.., cin], kernel
  * flipped, channel roles swapped).  W: DEVICE [3,3,cin,cout]; the Winograd-domain operand is rebuilt on the device every call.

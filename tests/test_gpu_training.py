@@ -372,3 +372,36 @@ def test_new_entry_points_reject_bad_arguments():
     out = torch.zeros((), dtype=torch.float64, device="cuda")
     assert L.vstab_loss_main(C.addressof(desc), 1, None, None, 1, 4, 4, out.data_ptr(), ws.data_ptr(), n, runtime.stream_ptr()) < 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,H,W,act", [(2, 64, 96, 0), (4, 256, 336, 1), (8, 128, 512, 0), (1, 70, 90, 2)])
+def test_first_layer_on_the_row_window_kernel_with_device_weights(B, H, W, act):
+    """vstab_conv_rowwin_forward: model.py:807-808 (pad 3, 7x7 stride 2, 27 -> 64) on the inference path's first-layer kernel with the raw
+    filter in device memory, padded to 28 input channels as the training buffers hold it (the 28th is never read: it is poisoned here).
+    64- and 128-pixel tiles, the 128 k + (1..64) column split (W = 336 -> 168 output columns), the stream form; none / leaky / relu."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * 100 + W)
+    x = torch.rand(B, H, W, 27, generator=g)
+    Wf = torch.randn(7, 7, 28, 64, generator=g) / (49 * 27) ** 0.5
+    Wf[:, :, 27, :] = float("nan")
+    b = torch.randn(64, generator=g) * 0.1
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    L = _lib.lib()
+    n = L.vstab_conv_rowwin_forward_workspace_bytes(B, H, W, 27, 28, 64, 7, 2, 3, 64, 0, act)
+    if (H, W) == (70, 90):
+        # 90 * 27 floats per row is not a multiple of 4: the kernel does not take it and says so
+        assert n == 0
+        return
+    assert n > 0
+    ws = torch.empty(int(n) + 256, dtype=torch.uint8, device="cuda")
+    y = torch.full((B, Ho, Wo, 64), float("nan"), dtype=torch.float32, device="cuda")
+    xd, Wd, bd = x.cuda(), Wf.cuda(), b.cuda()
+    _lib.check(L.vstab_conv_rowwin_forward(xd.data_ptr(), B, H, W, 27, Wd.data_ptr(), 28, 64, bd.data_ptr(), 7, 2, 3, y.data_ptr(), 64, 0, act,
+                                           ws.data_ptr(), ws.numel(), None))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), Wf[:, :, :27].double().permute(3, 2, 0, 1), b.double(), stride=2, padding=3).permute(0, 2, 3, 1)
+    if act == 1:
+        ref = torch.maximum(ref, 0.1 * ref)
+    elif act == 2:
+        ref = torch.relu(ref)
+    assert float((y.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
