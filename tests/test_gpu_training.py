@@ -3,7 +3,7 @@ arithmetic of the restated graph, gradient from torch autograd through it."""
 import pytest
 import torch
 
-from coupe.optical_flow_based_deep_video_stabilization_amd import training
+from coupe.optical_flow_based_deep_video_stabilization_amd import _lib, training
 from oracle import vstab_oracle as vo
 
 pytestmark = pytest.mark.gpu
