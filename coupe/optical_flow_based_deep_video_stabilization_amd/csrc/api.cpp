@@ -812,7 +812,7 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
 // ------------------------------------------------------------------------- forward
 // evaluate_originalSize's tail riding in the forward: when given, the last launch of a chunk computes predict_flow2, the flow glue and
 // tf_warp of the chunk's frames together (launch_pf2_glue_warp); `fused` reports whether every chunk could (else the caller warps)
-struct FusedTail { const float *frame; float *outflow; float *warped; int oh, ow; bool fused; };
+struct FusedTail { const float *frame; float *outflow; float *warped; int oh, ow; bool fused; const uint8_t *frame8; uint8_t *out8; };      // fp32 frames, or the clip driver's 8-bit ones (frame8 / out8)
 static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5,
                          float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_, FusedTail *tail);
 static std::string conv_kernel_name(ConvTile t, bool vec4);
@@ -843,13 +843,15 @@ static int forward_impl(vstab_ctx *ctx, const float *feats, int B, int H, int W,
     if (chunk < 1) return fail(ctx, VSTAB_E_SHAPE, "forward: one %dx%dx%d sample exceeds the 2 GiB tensor limit", H, W, Cin);
     // a batch processed in several chunks hands every chunk its slice of the frames: the slices keep the fused launch's 16-byte alignment
     // only when a frame is a whole number of 16-byte units (else: the two launches after the last chunk, as before)
-    bool all_fused = tail != nullptr && (chunk >= B || ((size_t)tail->oh * tail->ow * 4) % 16 == 0);
+    bool all_fused = tail != nullptr && (chunk >= B || ((size_t)tail->oh * tail->ow * 4) % 16 == 0);      // (8-bit frames: 4-byte units; the same test covers them)
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int bc = std::min(chunk, B - b0);
         FusedTail t{};
         if (tail && all_fused) {
             const size_t px = (size_t)b0 * tail->oh * tail->ow;
-            t = FusedTail{tail->frame + px * 3, tail->outflow ? tail->outflow + px * 2 : nullptr, tail->warped + px * 3, tail->oh, tail->ow, false};
+            t = FusedTail{tail->frame ? tail->frame + px * 3 : nullptr, tail->outflow ? tail->outflow + px * 2 : nullptr,
+                          tail->warped ? tail->warped + px * 3 : nullptr, tail->oh, tail->ow, false,
+                          tail->frame8 ? tail->frame8 + px * 3 : nullptr, tail->out8 ? tail->out8 + px * 3 : nullptr};
         }
         const int rc = forward_chunk(ctx, feats + (size_t)b0 * H * W * Cin, bc, H, W, Cin,
                                      pf6 + (size_t)b0 * eh[9] * ew[9] * 2, pf5 + (size_t)b0 * eh[7] * ew[7] * 2,
@@ -1058,8 +1060,12 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         hipError_t te = hipErrorNotSupported;
         if (tail && !(pin.flags & VSTAB_PLAN_NO_TAIL)) {       // gather + glue + warp of this chunk's frames in one launch, when the geometry allows
             TraceRange tail_range("predict_flow2 gather+flow_glue+tf_warp");
-            te = launch_pf2_glue_warp(buf(B_T), B, pl.eh[1], pl.ew[1], dw + ctx->pred2_b, pf3, pl.eh[3], pl.ew[3], pf2, H, W, tail->frame,
-                                      tail->outflow, tail->warped, tail->oh, tail->ow, stream);
+            if (tail->frame8)
+                te = launch_pf2_glue_warp_u8(buf(B_T), B, pl.eh[1], pl.ew[1], dw + ctx->pred2_b, pf3, pl.eh[3], pl.ew[3], pf2, H, W, tail->frame8,
+                                             tail->outflow, tail->out8, tail->oh, tail->ow, stream);
+            else
+                te = launch_pf2_glue_warp(buf(B_T), B, pl.eh[1], pl.ew[1], dw + ctx->pred2_b, pf3, pl.eh[3], pl.ew[3], pf2, H, W, tail->frame,
+                                          tail->outflow, tail->warped, tail->oh, tail->ow, stream);
             if (te != hipSuccess && te != hipErrorNotSupported) HIP_TRY(ctx, te);
             tail->fused = te == hipSuccess;
         }
@@ -1196,7 +1202,7 @@ extern "C" int vstab_stabilise_originalsize(vstab_ctx *ctx, const float *feats, 
     if (!frame || !warped) return fail(ctx, VSTAB_E_STATE, "stabilise_originalsize: NULL buffer");
     if (oh < 1 || ow < 1) return fail(ctx, VSTAB_E_SHAPE, "stabilise_originalsize: bad output size");
     // the tail (predict_flow2's gather, the glue, tf_warp) rides in the forward's last launch when its geometry allows (flow_ops.hip)
-    FusedTail tail{frame, outflow, warped, oh, ow, false};
+    FusedTail tail{frame, outflow, warped, oh, ow, false, nullptr, nullptr};
     const bool try_fused = (((uintptr_t)frame | (uintptr_t)warped | (uintptr_t)outflow) & 15) == 0;
     const int rc = forward_impl(ctx, feats, B, H, W, Cin, pf6, pf5, pf4, pf3, pf2, workspace, workspace_bytes, stream, try_fused ? &tail : nullptr);
     if (rc != VSTAB_OK) return rc;
@@ -1574,10 +1580,13 @@ extern "C" int vstab_clip_step(vstab_ctx *ctx, const uint8_t *const *slots8, con
     if (!slots8 || !frame || !feats || !out || !ring_slot) return fail(ctx, VSTAB_E_STATE, "clip_step: NULL buffer");
     if (n < 1 || net_h < 3 || net_w < 4 || oh < 1 || ow < 1) return fail(ctx, VSTAB_E_SHAPE, "clip_step: bad shape");
     int rc = vstab_assemble_input_resized(slots8, frame, n, net_h, net_w, oh, ow, feats, stream);
-    if (rc == VSTAB_OK) rc = vstab_flownets_forward(ctx, feats, n, net_h, net_w, 27, pf6, pf5, pf4, pf3, pf2, workspace, workspace_bytes, stream);
+    // the network; its last launch also does the 8-bit glue + warp of the frame when the geometry allows (flow_ops.hip, pf2_glue_warp_kernel)
+    FusedTail tail{nullptr, outflow, nullptr, oh, ow, false, frame, out};
+    const bool try_fused = (((uintptr_t)outflow & 7) | ((uintptr_t)out & 3)) == 0 && (long long)n * oh * ow < (1ll << 31) / 3;
+    if (rc == VSTAB_OK) rc = forward_impl(ctx, feats, n, net_h, net_w, 27, pf6, pf5, pf4, pf3, pf2, workspace, workspace_bytes, stream, try_fused ? &tail : nullptr);
     else ctx->err = g_last_error;
     if (rc != VSTAB_OK) return rc;
-    rc = vstab_flow_glue_warp_u8(pf2, n, net_h - 2, net_w - 2, frame, outflow, out, oh, ow, net_h, net_w, stream);
+    if (!tail.fused) rc = vstab_flow_glue_warp_u8(pf2, n, net_h - 2, net_w - 2, frame, outflow, out, oh, ow, net_h, net_w, stream);
     if (rc == VSTAB_OK) rc = vstab_resize_u8(out, n, oh, ow, ring_slot, net_h, net_w, stream);
     if (rc != VSTAB_OK) ctx->err = g_last_error;
     return rc;

@@ -774,12 +774,16 @@ struct TailParams {
     int h2, w2, h3, w3, H, W;                       // tap table grid, predict_flow3 grid, network input size (predict_flow2 is (H-2) x (W-2))
     float nsy, nsx, usy, usx;
 };
-template <bool WRITE_FLOW, bool STAGE>
+// U8 = the clip driver's frame path (warp3_u8_tile_kernel's statements: BGR bytes -> swap / 255 through the 256-entry table, the warp,
+// truncating quantiser, bytes out); otherwise fp32 frames in and out (warp3_tile_kernel's)
+template <bool WRITE_FLOW, bool STAGE, bool U8>
 __global__ __launch_bounds__(256) void pf2_glue_warp_kernel(const float *__restrict__ T, const float *__restrict__ bias2, const float *__restrict__ pf3,
-                                                            float *__restrict__ pf2, const float *__restrict__ img, float *__restrict__ out,
+                                                            float *__restrict__ pf2, const void *__restrict__ img_, void *__restrict__ out_,
                                                             float *__restrict__ outflow, int B, int OH, int OW, int tiles_x, int tiles_y,
                                                             TailParams P, GlueParams G)
 {
+    const float *__restrict__ img = reinterpret_cast<const float *>(img_);
+    float *__restrict__ out = reinterpret_cast<float *>(out_);
     constexpr int TH = WT_TH, TW = WT_TW, WH = WT_WH, WW = WT_WW, PPT = WT_PPT, PPR = TW / WW;
     // the tap-table window is dead once predict_flow2's rectangle is in `pfw` (second barrier): the output staging tile takes its place
     // (12 KB of LDS per workgroup instead of 23: the wave limit of the register file, not LDS, bounds the occupancy)
@@ -787,6 +791,8 @@ __global__ __launch_bounds__(256) void pf2_glue_warp_kernel(const float *__restr
     __shared__ __attribute__((aligned(16))) float tab[TAB_FLOATS > STAGE_FLOATS ? TAB_FLOATS : STAGE_FLOATS];
     __shared__ __attribute__((aligned(8))) f32x2 pfw[FT_PF_CAP];
     float *stage = tab;
+    __shared__ float lut[U8 ? 256 : 1];
+    if (U8) lut[threadIdx.x] = (float)threadIdx.x / 255.0f;          // 256 threads; read after the barriers below
     unsigned bx, by, bz;
     xcd_remap_calc(gridDim.x, 1, 1, blockIdx.x, bx, by, bz);
     const int tpi = tiles_x * tiles_y;
@@ -875,6 +881,16 @@ __global__ __launch_bounds__(256) void pf2_glue_warp_kernel(const float *__restr
     float wa[PPT], wb[PPT], wc_[PPT], wd[PPT];
     rgb3 Ia[PPT], Ib[PPT], Ic[PPT], Id[PPT];
     const rgb3 *b = reinterpret_cast<const rgb3 *>(img) + n * HW;
+    const unsigned char *b8 = reinterpret_cast<const unsigned char *>(img_) + n * HW * 3;
+    auto px = [&](int y, int x) {                                     // fp32 frame, or swap(frame) / 255: channels 2, 1, 0 of the BGR pixel
+        if constexpr (U8) {
+            const unsigned char *q = b8 + ((long long)y * OW + x) * 3;
+            rgb3 r; r.r = lut[q[2]]; r.g = lut[q[1]]; r.b = lut[q[0]];
+            return r;
+        } else {
+            return b[y * OW + x];
+        }
+    };
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const float x = (float)xx[j] + f[j].x, y = (float)yy[j] + f[j].y;
@@ -885,7 +901,7 @@ __global__ __launch_bounds__(256) void pf2_glue_warp_kernel(const float *__restr
         const float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
         wa[j] = (x1f - x) * (y1f - y); wb[j] = (x1f - x) * (y - y0f);
         wc_[j] = (x - x0f) * (y1f - y); wd[j] = (x - x0f) * (y - y0f);
-        Ia[j] = b[y0 * OW + x0]; Ib[j] = b[y1 * OW + x0]; Ic[j] = b[y0 * OW + x1]; Id[j] = b[y1 * OW + x1];
+        Ia[j] = px(y0, x0); Ib[j] = px(y1, x0); Ic[j] = px(y0, x1); Id[j] = px(y1, x1);
     }
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -893,14 +909,41 @@ __global__ __launch_bounds__(256) void pf2_glue_warp_kernel(const float *__restr
         r.r = ((wa[j] * Ia[j].r + wb[j] * Ib[j].r) + wc_[j] * Ic[j].r) + wd[j] * Id[j].r;      // tf.add_n order
         r.g = ((wa[j] * Ia[j].g + wb[j] * Ib[j].g) + wc_[j] * Ic[j].g) + wd[j] * Id[j].g;
         r.b = ((wa[j] * Ia[j].b + wb[j] * Ib[j].b) + wc_[j] * Ic[j].b) + wd[j] * Id[j].b;
-        if (STAGE) {
-            const int q = j * 4 + wave;
-            *reinterpret_cast<rgb3 *>(stage + (((q / PPR) * WH + lane / WW) * TW + (q % PPR) * WW + lane % WW) * 3) = r;
+        const int q = j * 4 + wave;
+        const int spix = ((q / PPR) * WH + lane / WW) * TW + (q % PPR) * WW + lane % WW;
+        if constexpr (U8) {                           // quantise_output_kernel's: truncate, saturate, channels swapped back
+            unsigned char *o = reinterpret_cast<unsigned char *>(stage) + spix * 3;
+            const float rr[3] = {r.r, r.g, r.b};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = (unsigned char)fminf(fmaxf(truncf(rr[2 - c] * 255.0f), 0.f), 255.f);
+        } else if (STAGE) {
+            *reinterpret_cast<rgb3 *>(stage + spix * 3) = r;
         } else if (ok[j]) {
             *reinterpret_cast<rgb3 *>(out + (n * HW + (long long)yy[j] * OW + xx[j]) * 3) = r;
         }
     }
-    if (STAGE) {       // OW % 4 == 0 (host): a tile row is TW*12 bytes from a 16-byte aligned address
+    if constexpr (U8) {
+        __syncthreads();
+        const unsigned char *sb = reinterpret_cast<const unsigned char *>(stage);
+        unsigned char *out8 = reinterpret_cast<unsigned char *>(out_);
+        // a tile row is TW*3 = 96 bytes; 4-byte stores where rows start on a 4-byte boundary (OW % 4 == 0), bytes otherwise / at a ragged edge
+        const int vw3 = min(TW, OW - tx0) * 3;
+        if ((OW & 3) == 0) {
+            constexpr int R4 = TW * 3 / 4;
+            for (int e = threadIdx.x; e < TH * R4; e += 256) {
+                const int row = e / R4, c4 = e - row * R4;
+                if (ty0 + row >= OH || c4 * 4 >= vw3) continue;
+                unsigned char *o = out8 + (n * HW + (long long)(ty0 + row) * OW + tx0) * 3 + c4 * 4;
+                if (c4 * 4 + 4 <= vw3) *reinterpret_cast<unsigned *>(o) = *reinterpret_cast<const unsigned *>(sb + row * TW * 3 + c4 * 4);
+                else for (int i = 0; c4 * 4 + i < vw3; ++i) o[i] = sb[row * TW * 3 + c4 * 4 + i];
+            }
+        } else {
+            for (int e = threadIdx.x; e < TH * TW * 3; e += 256) {
+                const int row = e / (TW * 3), c = e - row * (TW * 3);
+                if (ty0 + row < OH && c < vw3) out8[(n * HW + (long long)(ty0 + row) * OW + tx0) * 3 + c] = sb[e];
+            }
+        }
+    } else if (STAGE) {       // OW % 4 == 0 (host): a tile row is TW*12 bytes from a 16-byte aligned address
         __syncthreads();
         constexpr int R4 = TW * 3 / 4;
         const int vw3 = min(TW, OW - tx0) * 3;
@@ -928,12 +971,15 @@ static Lerp legacy_coord_host(int o, float scale, int n_in)
 
 // predict_flow2 gather + glue + warp as one launch; hipErrorNotSupported when a tile's rectangles would not fit the LDS windows (an output
 // much smaller than the flow grid) or the buffers miss the warp kernel's alignment: the caller then runs the two launches
-hipError_t launch_pf2_glue_warp(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2, int H, int W,
-                                const float *img, float *outflow, float *out, int oh, int ow, hipStream_t stream)
+static hipError_t launch_tail(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2, int H, int W,
+                              const void *img, float *outflow, void *out, int oh, int ow, bool u8, hipStream_t stream)
 {
     const int h = H - 2, w = W - 2;
     if (B < 1 || h < 1 || w < 2 || oh < 1 || ow < 1) return hipErrorNotSupported;
-    if (!warp3_ok(img, out, outflow, B, oh, ow, 3) || ((uintptr_t)pf2 & 7)) return hipErrorNotSupported;
+    if ((uintptr_t)pf2 & 7) return hipErrorNotSupported;
+    if (u8) {
+        if ((long long)B * oh * ow >= (1ll << 31) / 3 || ((uintptr_t)outflow & 7) || ((uintptr_t)out & 3)) return hipErrorNotSupported;
+    } else if (!warp3_ok(img, out, outflow, B, oh, ow, 3)) return hipErrorNotSupported;
     const GlueParams G = glue_params(h, w, oh, ow, H, W);
     TailParams P{h2, w2, h3, w3, H, W, H > 1 ? (float)(h2 + 2 - 1) / (float)(H - 1) : 0.f, W > 1 ? (float)(w2 + 2 - 1) / (float)(W - 1) : 0.f,
                  (float)h3 / (float)h, (float)w3 / (float)w};
@@ -959,12 +1005,27 @@ hipError_t launch_pf2_glue_warp(const float *T, int B, int h2, int w2, const flo
     const long long total = (long long)B * oh * ow;
     // compulsory traffic: tap-table rows, the coarser flow, predict_flow2 WRITTEN once (never re-read), frame read, warped (and the
     // output-resolution flow) written
-    const double alg_bytes = 128.0 * B * h2 * w2 + 8.0 * B * h3 * w3 + 8.0 * B * h * w + (outflow ? 32.0 : 24.0) * total;
+    const double px_bytes = u8 ? (outflow ? 14.0 : 6.0) : (outflow ? 32.0 : 24.0);
+    const double alg_bytes = 128.0 * B * h2 * w2 + 8.0 * B * h3 * w3 + 8.0 * B * h * w + px_bytes * total;
     const dim3 grid((unsigned)((long long)tx * ty * B)), block(256);
-#define VSTAB_TAIL(WF, ST) launch_timed(HBM_SLOT_TAIL, alg_bytes, pf2_glue_warp_kernel<WF, ST>, grid, block, stream, T, bias2, pf3, pf2, img, out, outflow, B, oh, ow, tx, ty, P, G)
-    if (outflow) return (ow & 3) == 0 ? VSTAB_TAIL(true, true) : VSTAB_TAIL(true, false);
-    return (ow & 3) == 0 ? VSTAB_TAIL(false, true) : VSTAB_TAIL(false, false);
+#define VSTAB_TAIL(WF, ST, U) launch_timed(HBM_SLOT_TAIL, alg_bytes, pf2_glue_warp_kernel<WF, ST, U>, grid, block, stream, T, bias2, pf3, pf2, img, out, outflow, B, oh, ow, tx, ty, P, G)
+    if (u8) return outflow ? VSTAB_TAIL(true, true, true) : VSTAB_TAIL(false, true, true);
+    if (outflow) return (ow & 3) == 0 ? VSTAB_TAIL(true, true, false) : VSTAB_TAIL(true, false, false);
+    return (ow & 3) == 0 ? VSTAB_TAIL(false, true, false) : VSTAB_TAIL(false, false, false);
 #undef VSTAB_TAIL
+}
+
+hipError_t launch_pf2_glue_warp(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2, int H, int W,
+                                const float *img, float *outflow, float *out, int oh, int ow, hipStream_t stream)
+{
+    return launch_tail(T, B, h2, w2, bias2, pf3, h3, w3, pf2, H, W, img, outflow, out, oh, ow, false, stream);
+}
+
+// the same on the clip driver's 8-bit frames: identical bytes to launch_pf2 + launch_flow_glue_warp_u8
+hipError_t launch_pf2_glue_warp_u8(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2, int H, int W,
+                                   const unsigned char *frame, float *outflow, unsigned char *out, int oh, int ow, hipStream_t stream)
+{
+    return launch_tail(T, B, h2, w2, bias2, pf3, h3, w3, pf2, H, W, frame, outflow, out, oh, ow, true, stream);
 }
 
 // ---------------------------------------------------------------------------------

@@ -285,6 +285,8 @@ hipError_t launch_div_const_selftest(float d, unsigned first, unsigned long long
 // predict_flow2 gather + flow glue + tf_warp in ONE launch (flow_ops.hip); hipErrorNotSupported = run the two launches instead
 hipError_t launch_pf2_glue_warp(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2, int H, int W,
                                 const float *img, float *outflow, float *out, int oh, int ow, hipStream_t stream);
+hipError_t launch_pf2_glue_warp_u8(const float *T, int B, int h2, int w2, const float *bias2, const float *pf3, int h3, int w3, float *pf2, int H, int W,
+                                   const unsigned char *frame, float *outflow, unsigned char *out, int oh, int ow, hipStream_t stream);
 hipError_t launch_flow_glue_warp(const float *flow, int B, int h, int w, const float *img, float *outflow, float *out, int oh, int ow,
                                  int C, int net_h, int net_w, hipStream_t stream);
 // 2x2 stride-2 SAME max pool (vgg16.py:51-53), NHWC, C % 4 == 0
