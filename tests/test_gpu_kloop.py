@@ -52,7 +52,7 @@ def test_generic_conv_through_the_assembly_k_loop(B, H, W, cin, k, s, p, cout):
     assert float((y.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("cout", [132, 388, 160, 129])
+@pytest.mark.parametrize("cout", [132, 388, 160])
 @pytest.mark.parametrize("B,H,W,cin,k,s,p", [(2, 16, 20, 64, 4, 2, 1), (1, 12, 12, 36, 3, 1, 1), (3, 8, 8, 32, 1, 1, 0)])
 def test_conv_forward_with_a_few_columns_beyond_whole_tiles(B, H, W, cin, k, s, p, cout):
     """128 q + r output channels (the decoder's concat widths 388 / 772 / 1028 as the N of its input gradients: a last column tile with
@@ -63,8 +63,6 @@ def test_conv_forward_with_a_few_columns_beyond_whole_tiles(B, H, W, cin, k, s, 
     x = torch.randn(B, H, W, cin, generator=g)
     Wt = torch.randn(k, k, cin, cout, generator=g) / (k * k * cin) ** 0.5
     b = torch.randn(cout, generator=g)
-    if cout % 4:
-        pytest.skip("channel counts are multiples of 4 on this path")
     y = _conv_forward(x.cuda(), Wt.cuda(), b.cuda(), k, s, p)
     ref = _ref(x, Wt, b, k, s, p)
     tol = 2e-5 * float(ref.abs().max()) + 1e-6
