@@ -298,12 +298,18 @@ long long skinny_tiles(const ConvParams &p)
     return (long long)((p.Mmax + 31) / 32) * (p.Npad / 32) * p.nphase;
 }
 
-// split-K factor over WORKGROUPS (each splits its slice four ways again): about two workgroups per CU, at least two K-tiles per wave
+// split-K factor over WORKGROUPS (each splits its slice four ways again): about ONE workgroup per CU, at least two K-tiles per wave.
+// Round 5 A/B (profiles/ab_r05j_skinny_target.txt): 256 workgroups beat 512 (conv6 / conv6_1 of one 384x512 sample 18.4 / 21.6 -> 16.6 /
+// 19.6 us, conv6_1 of one 256x256 sample 15.0 -> 13.5 us) and 192 / 128 / 1024 all lose: the launch is a chain of latencies whose
+// reduction end grows with the number of slabs, and half as many workgroups publish half as many.
 int conv_skinny_split(const ConvParams &p, int cap)
 {
     const int KT = p.KH * p.NSEG * (p.SEGP / 32);
     const long long base = skinny_tiles(p);
-    long long ks = (512 + base / 2) / base;
+#ifndef VSTAB_SKINNY_TARGET
+#define VSTAB_SKINNY_TARGET 256          // workgroups a launch aims for (A/B builds: scripts/build_variant_lib.sh -DVSTAB_SKINNY_TARGET=...)
+#endif
+    long long ks = (VSTAB_SKINNY_TARGET + base / 2) / base;
     ks = std::min<long long>(ks, KT / 8);
     ks = std::min<long long>(ks, cap);
     if (ks < 1) ks = 1;
