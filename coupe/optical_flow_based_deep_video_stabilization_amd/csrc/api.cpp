@@ -263,7 +263,10 @@ void fill_wino_gemm(ConvParams &p, int B, int H, int W, int cin, int cout)
 }
 
 // does a 3x3 stride-1 pad-1 layer run in Winograd form?  Two extra HBM passes and two more launches: pays once the Winograd-domain
-// GEMM issues a few GFLOP (measured: B=8 512x512 every encoder stage gains, 20..96 us; B=1 384x512 (1.6 GFLOP per stage) loses 2..5 %)
+// GEMM issues a GFLOP or two (measured: B=8 512x512 every encoder stage gains, 20..96 us; one 384x512 sample -- 1.61 GFLOP per stage -- lost
+// 2..5 % in rounds 2-3 and GAINS 2.5 % of the frame since the stream GEMMs and one-workgroup-per-CU plans of rounds 4-5: conv3_1 / conv4_1
+// 38.4 / 37.1 -> 24.2 / 25.2 us and their split-K combines gone (profiles/ab_r05k_winograd_threshold.txt); one 256x256 sample, 0.54 GFLOP per
+// stage, still loses 4 %)
 bool wino_applies(int B, int H, int W, int cin, int cout)
 {
 #ifdef VSTAB_HARNESS
@@ -273,7 +276,10 @@ bool wino_applies(int B, int H, int W, int cin, int cout)
     if ((cin & 31) || (cout & 127)) return false;                  // whole K tiles, 128x64 output tiles
     const long long TH = (H + 1) / 2, TW = (W + 1) / 2;
     if ((long long)B * 16 * TH * TW * std::max(cin, cout) * 4 >= 0x80000000LL) return false;
-    return 32.0 * B * TH * TW * cin * cout >= 3.0e9;
+#ifndef VSTAB_WINO_MIN_FLOPS
+#define VSTAB_WINO_MIN_FLOPS 1.5e9       // (A/B builds: scripts/build_variant_lib.sh -DVSTAB_WINO_MIN_FLOPS=...)
+#endif
+    return 32.0 * B * TH * TW * cin * cout >= VSTAB_WINO_MIN_FLOPS;
 }
 
 namespace {
