@@ -24,11 +24,14 @@ def short(name):
 def main():
     path, title, skip = sys.argv[1], sys.argv[2], int(sys.argv[3])
     bench = json.load(open(sys.argv[4])) if len(sys.argv) > 4 and sys.argv[4] not in ("", "-") else None
-    marker = sys.argv[5] if len(sys.argv) > 5 else "warp3_tile_kernel<true"
+    # the launch a step ends with: since round 5 the fused tail (pf2_glue_warp_kernel); the round-4 glue + warp launch in older traces
+    marker = sys.argv[5] if len(sys.argv) > 5 else None
     rows = [r for r in csv.DictReader(open(path)) if r["Kind"] == "KERNEL_DISPATCH"]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # steps: a step ends with the marker launch
     steps, cur = [], []
+    if marker is None:
+        marker = "pf2_glue_warp_kernel" if any("pf2_glue_warp_kernel" in r["Kernel_Name"] for r in rows) else "warp3_tile_kernel<true"
     for r in rows:
         cur.append(r)
         if marker in r["Kernel_Name"]:
