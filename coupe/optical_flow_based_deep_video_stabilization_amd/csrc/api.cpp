@@ -896,7 +896,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
     unsigned *tickets = reinterpret_cast<unsigned *>(buf(B_TICKETS));
     bool any_tickets = false;
     for (int i = 0; i < 14; ++i) any_tickets = any_tickets || (pl.skinny[i] && pl.cp[i].ksplit > 1);
-    if (any_tickets) HIP_TRY(ctx, hipMemsetAsync(tickets, 0, pl.bytes[B_TICKETS], stream));
+    bool tickets_cleared = !any_tickets;          // the first layer's launch clears them when it is the row-window kernel; else a memset node
 
     // optional per-launch events
     hipEvent_t *ev = nullptr;
@@ -946,12 +946,13 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
             r.WLEN = round_up(r.s_in * Cin * (64 * r.MB - 1) + r.w_a + r.SEGP, 4);
             r.Ho = p.Ho; r.Wo = p.Wo; r.Cs_out = p.Cs_out; r.c_off = 0; r.N = p.N; r.Npad = p.Npad; r.act = 1;
             if (in_bytes < 0x80000000LL && rowwin_applicable(r)) {
+                if (!tickets_cleared) { r.clear_words = tickets; r.clear_n = SKINNY_MAX_TILES; tickets_cleared = true; }
                 const int rem = p.Wo % 128;
                 if (r.MB == 2 && p.Wo > 128 && rem >= 1 && rem <= 64) {
                     // 128 k + (1..64) columns: k full tiles, then the rest as ONE 64-pixel tile (second launch; events span both)
                     RowWinParams t = r;
                     r.ntile_x = p.Wo / 128;
-                    t.MB = 1; t.ox_base = r.ntile_x * 128; t.ntile_x = 1;
+                    t.MB = 1; t.ox_base = r.ntile_x * 128; t.ntile_x = 1; t.clear_n = 0;
                     t.WLEN = round_up(t.s_in * Cin * 63 + t.w_a + t.SEGP, 4);
                     if (rowwin_applicable(t)) {
                         HIP_TRY(ctx, launch_conv_rowwin(r, stream, EV_A(0), nullptr));
@@ -966,6 +967,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
                 continue;
             }
         }
+        if (!tickets_cleared) { HIP_TRY(ctx, hipMemsetAsync(tickets, 0, pl.bytes[B_TICKETS], stream)); tickets_cleared = true; }
         if (pl.wino[i]) {       // transform, 16-position GEMM on the MFMA kernel, inverse transform (+ bias, leaky relu)
             ConvParams q = pl.wcp[i];
             const int cin_i = ENC[i - 1].cout;

@@ -51,6 +51,11 @@ __global__ __launch_bounds__(256) void conv_rowwin_kernel(const RowWinParams p)
     // 7-row input windows overlap by five rows
     unsigned bx_, by_, bz_;
     xcd_remap(bx_, by_, bz_);
+    // a chore for the launches that FOLLOW this one in the forward: the first workgroup zeroes the ticket words of the in-launch split-K
+    // reductions (conv_skinny.hip).  As the forward's first launch this kernel finishes before any of them starts (stream order), and the
+    // words ride here instead of in a memset node of their own (4.7 us per forward: 1 ... 1.6 % of a one-sample frame)
+    if (p.clear_n > 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int i = tid; i < p.clear_n; i += 256) p.clear_words[i] = 0u;
     const int stream_r = (MB == 2 && p.asm_loop) ? p.stream_rows : 0;          // > 0: this workgroup computes stream_r output rows (oy, oy + S, oy + 2 S ...)
     // rows between a stream's tiles.  1: the stream walks down CONSECUTIVE rows.  (Interleaving a column's streams -- stride = their
     // number, so that they work on adjacent rows at any time and share input rows in L2 -- brings the launch's HBM reads from 3.2x to 1.9x

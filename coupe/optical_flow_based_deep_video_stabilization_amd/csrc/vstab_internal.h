@@ -205,6 +205,8 @@ struct RowWinParams {
     int out_vec4;           // set by launch_conv_rowwin: the tile leaves through LDS as 16-byte stores
     int asm_loop;           // set by launch_conv_rowwin: the K loop runs as the assembly block of conv_kloop_gfx950.inc (128-pixel tiles, 6 K-tiles per filter row)
     int stream_rows;        // set by launch_conv_rowwin: > 0 = a workgroup walks down this many consecutive output rows as one seamless stream of tiles (grid.x = Ho / stream_rows)
+    unsigned *clear_words;  // clear_n > 0: the launch's first workgroup zeroes these words (the forward's split-K tickets; the launches that
+    int clear_n;            // use them come later in the stream)
     int ox_base, ntile_x;   // first output column and number of x tiles of this launch (0 tiles = up to the row end): a row whose length
                             // is 128 k + (1..64) runs as k 128-pixel tiles plus ONE 64-pixel tile in a second launch instead of a
                             // half-empty 128-pixel one (Wo = 960 at 1080p: 6 % of the first layer's MFMA work)
