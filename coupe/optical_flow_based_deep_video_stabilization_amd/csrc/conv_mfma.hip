@@ -595,9 +595,13 @@ __global__ __launch_bounds__(256) void conv_dual_kernel(const ConvParams pa, con
     // (measured: B first costs a 384x512 frame +10 us).  A alone fills whole rounds (B=8 512x512: deconv2's 1024 workgroups are two
     // rounds exactly): B's short workgroups first -- they delay half the slots by their own short life instead of forming a ragged
     // last round of their own (headline shape 2.858 -> 2.839 ms).
+    // (B first: B's workgroups are padded to a multiple of 8 -- the pad exits at once -- so that A's ids keep their residue mod 8, i.e. the
+    // XCD the hardware deals them to is the one xcd_remap_calc assumes and A's row-tile bands stay whole per L2)
     unsigned bx_, by_, bz_;
-    const unsigned idA = b_first ? blockIdx.x - nB : blockIdx.x;
-    const bool isA = b_first ? blockIdx.x >= nB : blockIdx.x < nA;      // workgroup uniform
+    const unsigned nBp = (nB + 7u) & ~7u;
+    const unsigned idA = b_first ? blockIdx.x - nBp : blockIdx.x;
+    const bool isA = b_first ? blockIdx.x >= nBp : blockIdx.x < nA;     // workgroup uniform
+    if (b_first && !isA && blockIdx.x >= nB) return;                    // the pad
     if (isA) {
         xcd_remap_calc(gA.x, gA.y, gA.z, idA, bx_, by_, bz_);
         conv_mfma_body<BM1, BN1, WM1, WN1, true, true>(pa, bx_, by_, bz_);
@@ -791,7 +795,7 @@ hipError_t launch_conv_dual(const ConvParams &pa_in, ConvTile tile_a, const Conv
     // first (see the kernel); appended BEHIND a transposed convolution that fills whole rounds they were a ragged round of their own
     // (+43 us on deconv2 at B=8 512x512, profiles/README.md r04).
     const int b_first = nA + nB > 2ull * CONV_CUS ? 1 : 0;
-    const dim3 grid((unsigned)(nA + nB)), block(256);
+    const dim3 grid((unsigned)(nA + (b_first ? ((nB + 7ull) & ~7ull) : nB))), block(256);      // B first: B padded to whole groups of 8 (the kernel's XCD note)
     const bool timed = ev_start != nullptr && ev_stop != nullptr;
 #define VSTAB_LAUNCH2(BM, BN, WM, WN)                                                                                                   \
     do {                                                                                                                                \
