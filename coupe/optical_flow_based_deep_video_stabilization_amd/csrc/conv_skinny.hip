@@ -17,8 +17,8 @@
 //     acquire, sums the tile's slabs in slab order (`sc1` loads; the same association as splitk_combine_kernel), adds the bias,
 //     applies the activation and stores the output rows -- no combine launch, no dependence on placement or dispatch order
 //     (cdna_hip_programming.md section 5 "In-launch split-K reduction", section 6 Guideline 16).  With 32x32 tiles and the 4-wave
-//     pre-sum a tile's slabs are 4 KB x ks (ks <= 16).  The ticket words live in the caller's workspace (round 5; zeroed by a memset node
-//     at the head of every forward) and every last arriver puts its word back to zero.
+//     pre-sum a tile's slabs are 4 KB x ks (ks <= 16).  The ticket words live in the caller's workspace (round 5; zeroed by the first
+//     workgroup of the forward's first launch, conv_rowwin.hip, or by a memset node when that kernel does not run) and every last arriver puts its word back to zero.
 //
 // What it buys (profiles/README.md "r04 one-sample path", interleaved A/B on one box): the launch itself is a chain of latencies --
 // first operands, a handful of MFMAs, LDS pre-sum, store drain, ticket, acquire, slab loads, output -- that takes 12 ... 17 us where the
