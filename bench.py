@@ -400,7 +400,7 @@ def main():
     # W warm-up steps, then exactly K steps between barrier + synchronize pairs; elapsed = max over ranks (benchloop.py)
     elapsed, out = benchloop.timed_region(timed_step, args.steps, args.warmup, torch.cuda.synchronize, dist=dist,
                                           drain=flush_and_drain if (gather is not None or grouped is not None) else None, before_timed=profilers_on,
-                                          device="cpu" if args.backend == "gloo" else "cuda")
+                                          device="cpu" if args.backend == "gloo" else "cuda", prime=profilers_on if use_events else None)
 
     # ---- N > 1: what the reassembly costs.  The SAME ranks run the same K steps again with the collective (and the uint8 staging
     # launch that feeds it) switched off; exposed = with - without.  After the timed region, never part of `value`.

@@ -9,13 +9,17 @@ from typing import Callable, Optional
 
 def timed_region(step: Callable[[int], object], steps: int, warmup: int, sync: Callable[[], None], dist=None,
                  drain: Optional[Callable[[], None]] = None, before_timed: Optional[Callable[[], None]] = None,
-                 device: str = "cuda"):
+                 device: str = "cuda", prime: Optional[Callable[[], None]] = None):
     """Returns (elapsed seconds, max over ranks; the last step's return value).  `step(k)` gets the index of the timed step
     (-1 during warm-up); `drain` waits for asynchronous work the steps started (the overlapped all-gather); `before_timed`
-    runs after the warm-up has drained and before the opening barrier (profilers are switched on there)."""
+    runs after the warm-up has drained and before the opening barrier (profilers are switched on there); `prime` runs in front of the
+    LAST warm-up step (bench.py switches its per-launch event recording on there, so that the first use of that launch path -- a
+    one-off cost of about a millisecond -- falls into the warm-up and not into the first timed step: a 20-step run read 1 % slow)."""
     import torch
     out = None
-    for _ in range(warmup):
+    for i in range(warmup):
+        if prime is not None and i == warmup - 1:
+            prime()
         out = step(-1)
     if drain is not None:
         drain()
