@@ -219,8 +219,9 @@ def main():
     ap.add_argument("--gather-fp32", action="store_true",
                     help="all-gather the fp32 warped frames instead of the uint8 video frames the reference writes (main:630)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
-    ap.add_argument("--event-every", type=int, default=4,
-                    help="record the per-launch HIP events on every n-th step of the timed region (they cost ~2 %% of a step)")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="record the per-launch HIP events on every n-th step of the timed region (an event-carrying step costs ~2 %% more at the "
+                         "headline shape, ~15 %% more for one sample; at least two steps carry them)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph (torch.cuda.CUDAGraph) and replay it; single GPU, no kernel events")
     ap.add_argument("--roctx", action="store_true", help="run every layer inside a named roctx range (rocprofv3 --marker-trace)")
@@ -381,7 +382,7 @@ def main():
 
     from coupe.optical_flow_based_deep_video_stabilization_amd import benchloop
     use_events = not args.no_kernel_events
-    ev_every = max(1, args.event_every)
+    ev_every = max(1, min(args.event_every, max(1, args.steps // 2)))
     n_event_steps = 0
 
     def profilers_on():
