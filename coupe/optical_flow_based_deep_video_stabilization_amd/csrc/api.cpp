@@ -206,24 +206,6 @@ ConvTile choose_tile_split(ConvParams &p, ConvTile tile, bool vec4)
     return tile;
 }
 
-// 64-column layers run 128 x 64 tiles: half the MFMA work per K-tile of a 128 x 128 tile for the same barrier, 1.5x the LDS fragment reads
-// and DMA rows per MFMA (deconv2 at B=8 512x512: 0.77 of peak where the 128-column layers reach 0.83-0.91).  A 256 x 64 tile gives each
-// wave the 128 x 128 tile's 64 x 64 block; its 87 KB of LDS allow one workgroup per CU, so it only pays when the launch is a whole
-// number of 256-workgroup rounds (or many of them).  Measured: profiles/README.md r05 "256x64".
-#ifndef VSTAB_TILE_256x64
-#define VSTAB_TILE_256x64 1
-#endif
-bool tile_256x64_pays(const ConvParams &p)
-{
-    if (!VSTAB_TILE_256x64) return false;
-    long long wgs = 0;
-    for (int k = 0; k < p.nphase; ++k) wgs += (p.ph[k].M + 255) / 256;
-    wgs *= p.Npad / 64;
-    if (p.Npad % 64 != 0 || wgs < 256) return false;
-    const long long rounds = (wgs + 255) / 256;
-    return wgs % 256 == 0 || rounds >= 8;          // whole rounds, or so many that a ragged last one is under an eighth of the launch
-}
-
 // Few rows per phase (one sample's 1/32 and 1/64 levels, the first decoder steps): the layer is a weight stream (conv_skinny.hip).
 // Returns true and sets p.ksplit to that kernel's own factor.
 bool choose_skinny(ConvParams &p, bool vec4, unsigned flags)
@@ -449,9 +431,6 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl, const PlanPin *pin = null
             // predict_up: the weight-stream kernel's one advantage -- no combine launch -- is gone, so it serves the encoder only)
             pl.skinny[10 + l] = (flags & VSTAB_PLAN_NO_DUAL) ? choose_skinny(p, true, flags) : false;
             if (pl.skinny[10 + l]) pl.tile[10 + l] = TILE_SKINNY;
-            // a 64-column transposed convolution with many rows (deconv2): 256 x 64 tiles -- the 128 x 128 tile's wave shape, one workgroup
-            // per CU -- when they fill whole rounds of the chip (see tile_256x64_pays)
-            if (pl.tile[10 + l] == TILE_128x64 && p.ksplit == 1 && tile_256x64_pays(p)) pl.tile[10 + l] = TILE_256x64;
         }
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad);
     }
@@ -1108,7 +1087,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
 
 static std::string conv_kernel_name(ConvTile t, bool vec4)
 {
-    const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : (t == TILE_64x128 ? "64, 128, 1, 4" : (t == TILE_64x64 ? "64, 64, 2, 2" : (t == TILE_256x32 ? "256, 32, 4, 1" : (t == TILE_256x64 ? "256, 64, 4, 1" : "128, 32, 4, 1")))));
+    const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : (t == TILE_64x128 ? "64, 128, 1, 4" : (t == TILE_64x64 ? "64, 64, 2, 2" : (t == TILE_256x32 ? "256, 32, 4, 1" : "128, 32, 4, 1"))));
     const bool dma = conv_uses_lds_dma(t, vec4);
     return std::string("conv_mfma_kernel<") + shape + (vec4 ? ", true" : ", false") + (dma ? ", true>" : ", false>");
 }

@@ -341,8 +341,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams &p, const unsign
 #else
     constexpr bool ASM_64 = BM == 64 && BN == 128 && WM == 1 && WN == 4;
 #endif
-    constexpr bool ASM_256 = BM == 256 && BN == 64 && WM == 4 && WN == 1;
-    constexpr bool ASM_KLOOP = DMA && VEC && VSTAB_ABL == 0 && ((BM == 128 && WM == 2 && WN == 2 && (BN == 128 || BN == 64)) || ASM_64 || ASM_256);
+    constexpr bool ASM_KLOOP = DMA && VEC && VSTAB_ABL == 0 && ((BM == 128 && WM == 2 && WN == 2 && (BN == 128 || BN == 64)) || ASM_64);
 #endif
 
     if constexpr (ASM_KLOOP) {
@@ -362,10 +361,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams &p, const unsign
                 la[q] = ldsA + (unsigned)(a_row0 + chunk) * 4u;
                 lb[q] = ldsA + (unsigned)(2 * BM * 32 + b_row0 + chunk) * 4u;
             }
-            // per gathered row of this thread (four for the 128-row tiles, two for the 64-row one, eight for the 256-row one: the rest
-            // are unused operands)
-            constexpr int NR = A_ROWS_V > 4 ? 8 : 4;
-            int span[NR] = {}, ax[NR] = {}, alo[NR] = {}, aw[NR] = {}, ay[NR] = {};
+            // per gathered row of this thread (four for the 128-row tiles, two for the 64-row one: the rest are unused operands)
+            int span[4] = {0, 0, 0, 0}, ax[4] = {0, 0, 0, 0}, alo[4] = {0, 0, 0, 0}, aw[4] = {0, 0, 0, 0}, ay[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < A_ROWS_V; ++j) {
                 span[j] = max(RA[j].z - RA[j].y, 0);
@@ -388,7 +385,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams &p, const unsign
             int s_ky = c_ky, s_sg = c_sg, s_kc = c_kc, s_soffw = (kt0 + 1) * wstep, s_n = kt1 - kt0 - 1;
             int t_qseg, t_qabs, t_soff, t_t, t_kyc;
             unsigned v_t, v_o0, v_o1;
-#define VSTAB_KLOOP_IO(ACCS, ...)                                                                                                           \
+#define VSTAB_KLOOP_IO(ACCS)                                                                                                                \
             : ACCS, [ky] "+s"(s_ky), [sg] "+s"(s_sg), [kc] "+s"(s_kc), [soffw] "+s"(s_soffw), [n] "+s"(s_n),                              \
               [qseg] "=&s"(t_qseg), [qabs] "=&s"(t_qabs), [soff] "=&s"(t_soff), [t] "=&s"(t_t), [kyc] "=&s"(t_kyc),                        \
               [vt] "=&v"(v_t), [vo0] "=&v"(v_o0), [vo1] "=&v"(v_o1)                                                                        \
@@ -401,18 +398,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams &p, const unsign
               [y0] "v"(ay[0]), [y1] "v"(ay[1]), [y2] "v"(ay[2]), [y3] "v"(ay[3]),                                                         \
               [wv] "v"(wvoff0), [rin] "s"(din), [rwt] "s"(dwt), [ma] "s"(m_a), [mb] "s"(m_b),                                            \
               [kps] "s"(kps), [nseg] "s"(L_NSEG), [lstride] "s"(L_STRIDE), [pitch] "s"(row_pitch), [hi] "s"(p.Hi), [wstep] "s"(wstep)     \
-              __VA_ARGS__                                                                                                                  \
             : "memory", "vcc", "scc", VSTAB_KLOOP_CLOBBERS
-            if constexpr (BM == 256) {
-                // (eight gathered rows per thread: the four-row operand list plus rows 4 ... 7)
-                asm volatile(VSTAB_KLOOP_ASM_256x64
-                             VSTAB_KLOOP_IO([c00] "+a"(acc[0][0]) VSTAB_COMMA [c01] "+a"(acc[0][1]) VSTAB_COMMA [c10] "+a"(acc[1][0]) VSTAB_COMMA [c11] "+a"(acc[1][1]),
-                                            VSTAB_COMMA [x4] "v"(ax[NR - 4]) VSTAB_COMMA [x5] "v"(ax[NR - 3]) VSTAB_COMMA [x6] "v"(ax[NR - 2]) VSTAB_COMMA [x7] "v"(ax[NR - 1])
-                                            VSTAB_COMMA [lo4] "v"(alo[NR - 4]) VSTAB_COMMA [lo5] "v"(alo[NR - 3]) VSTAB_COMMA [lo6] "v"(alo[NR - 2]) VSTAB_COMMA [lo7] "v"(alo[NR - 1])
-                                            VSTAB_COMMA [span4] "v"(span[NR - 4]) VSTAB_COMMA [span5] "v"(span[NR - 3]) VSTAB_COMMA [span6] "v"(span[NR - 2]) VSTAB_COMMA [span7] "v"(span[NR - 1])
-                                            VSTAB_COMMA [w4] "v"(aw[NR - 4]) VSTAB_COMMA [w5] "v"(aw[NR - 3]) VSTAB_COMMA [w6] "v"(aw[NR - 2]) VSTAB_COMMA [w7] "v"(aw[NR - 1])
-                                            VSTAB_COMMA [y4] "v"(ay[NR - 4]) VSTAB_COMMA [y5] "v"(ay[NR - 3]) VSTAB_COMMA [y6] "v"(ay[NR - 2]) VSTAB_COMMA [y7] "v"(ay[NR - 1])));
-            } else if constexpr (BM == 64) {
+            if constexpr (BM == 64) {
                 asm volatile(VSTAB_KLOOP_ASM_64x128
                              VSTAB_KLOOP_IO([c00] "+a"(acc[0][0]) VSTAB_COMMA [c10] "+a"(acc[1][0])));
             } else if constexpr (BN == 128) {
@@ -663,7 +650,6 @@ hipError_t conv_set_attributes()
     if (e != hipSuccess) return e;
     VSTAB_SET((conv_mfma_kernel<128, 32, 4, 1, true, true>), 128, 32)
     VSTAB_SET((conv_mfma_kernel<64, 128, 1, 4, true, true>), 64, 128)
-    VSTAB_SET((conv_mfma_kernel<256, 64, 4, 1, true, true>), 256, 64)
 #ifdef VSTAB_HARNESS
     VSTAB_SET((conv_mfma_kernel<256, 32, 4, 1, true, true>), 256, 32)
     VSTAB_SET((conv_mfma_kernel<64, 64, 2, 2, true, true>), 64, 64)
@@ -677,7 +663,6 @@ hipError_t conv_set_attributes()
     VSTAB_SET2(128, 128, 2, 2)
     VSTAB_SET2(128, 64, 2, 2)
     VSTAB_SET2(64, 128, 1, 4)
-    VSTAB_SET2(256, 64, 4, 1)
 #undef VSTAB_SET2
     return hipSuccess;
 }
@@ -714,8 +699,8 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
 #ifdef VSTAB_HARNESS
     if (getenv("VSTAB_NO_VEC_EPILOGUE")) p.out_vec4 = 0;                                 // A/B switch of tools/conv_bench
 #endif
-    const int BM = (tile == TILE_64x128 || tile == TILE_64x64) ? 64 : ((tile == TILE_256x32 || tile == TILE_256x64) ? 256 : 128);
-    const int BN = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : ((tile == TILE_128x64 || tile == TILE_64x64 || tile == TILE_256x64) ? 64 : 32);
+    const int BM = (tile == TILE_64x128 || tile == TILE_64x64) ? 64 : (tile == TILE_256x32 ? 256 : 128);
+    const int BN = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : ((tile == TILE_128x64 || tile == TILE_64x64) ? 64 : 32);
     if (p.in_bytes >= 0x80000000u || p.w_bytes >= 0x80000000u) return hipErrorInvalidValue;
     if (p.Npad % BN != 0 || p.SEGP % 32 != 0 || p.SEGP < p.SEG || p.NSEG < 1 || p.ksplit < 1 || p.nphase < 1 || p.nphase > 16)
         return hipErrorInvalidValue;
@@ -752,8 +737,6 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
         VSTAB_LAUNCH((conv_mfma_kernel<128, 32, 4, 1, true, true>), (conv_lds_bytes<128, 32>()));
     else if (tile == TILE_64x128 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<64, 128, 1, 4, true, true>), (conv_lds_bytes<64, 128>()));
-    else if (tile == TILE_256x64 && vec4 && use_dma)
-        VSTAB_LAUNCH((conv_mfma_kernel<256, 64, 4, 1, true, true>), (conv_lds_bytes<256, 64>()));
 #ifdef VSTAB_HARNESS      // predict_flow2's tap table ran on this shape through round 3; it is tap_panel_kernel's now (tap_panel.hip)
     else if (tile == TILE_256x32 && vec4)
         VSTAB_LAUNCH((conv_mfma_kernel<256, 32, 4, 1, true, true>), (conv_lds_bytes<256, 32>()));
@@ -791,7 +774,7 @@ hipError_t launch_conv(const ConvParams &p_in, ConvTile tile, bool vec4, hipStre
 hipError_t launch_conv_dual(const ConvParams &pa_in, ConvTile tile_a, const ConvParams &pb_in, ConvTile tile_b, hipStream_t stream,
                             hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    if (!lds_dma_enabled() || tile_b != TILE_128x32 || (tile_a != TILE_128x128 && tile_a != TILE_128x64 && tile_a != TILE_64x128 && tile_a != TILE_256x64))
+    if (!lds_dma_enabled() || tile_b != TILE_128x32 || (tile_a != TILE_128x128 && tile_a != TILE_128x64 && tile_a != TILE_64x128))
         return hipErrorNotSupported;
     ConvParams pa = pa_in, pb = pb_in;
     for (ConvParams *q : {&pa, &pb}) {
@@ -803,7 +786,7 @@ hipError_t launch_conv_dual(const ConvParams &pa_in, ConvTile tile_a, const Conv
         if (q->ksplit > 1 && ((q->N & 3) || (q->Cs_out & 3) || (q->c_off & 3) || q->partial == nullptr || ((uintptr_t)q->partial & 15)))
             return hipErrorInvalidValue;
     }
-    const int BMa = tile_a == TILE_64x128 ? 64 : (tile_a == TILE_256x64 ? 256 : 128), BNa = (tile_a == TILE_128x64 || tile_a == TILE_256x64) ? 64 : 128;
+    const int BMa = tile_a == TILE_64x128 ? 64 : 128, BNa = tile_a == TILE_128x64 ? 64 : 128;
     if (pa.Npad % BNa != 0 || pb.Npad % 32 != 0) return hipErrorInvalidValue;
     const uint3 gA = make_uint3((unsigned)((pa.Mmax + BMa - 1) / BMa), (unsigned)(pa.Npad / BNa), (unsigned)(pa.nphase * pa.ksplit));
     const uint3 gB = make_uint3((unsigned)((pb.Mmax + 127) / 128), (unsigned)(pb.Npad / 32), (unsigned)(pb.nphase * pb.ksplit));
@@ -817,14 +800,13 @@ hipError_t launch_conv_dual(const ConvParams &pa_in, ConvTile tile_a, const Conv
 #define VSTAB_LAUNCH2(BM, BN, WM, WN)                                                                                                   \
     do {                                                                                                                                \
         size_t lds = std::max(conv_lds_bytes<BM, BN>(), conv_lds_bytes<128, 32>());                                                     \
-        if (BM == 128 && BN == 64 && nA > 2 * CONV_CUS && nA <= 4 * CONV_CUS && nA % (2 * CONV_CUS) == 0) lds = CONV_LDS_TWO_PER_CU;  /* as launch_conv */ \
+        if (BN == 64 && nA > 2 * CONV_CUS && nA <= 4 * CONV_CUS && nA % (2 * CONV_CUS) == 0) lds = CONV_LDS_TWO_PER_CU;  /* as launch_conv */ \
         if (timed) hipExtLaunchKernelGGL((conv_dual_kernel<BM, BN, WM, WN, 128, 32, 4, 1>), grid, block, lds, stream, ev_start, ev_stop, 0, \
                                          pa, pb, (unsigned)nA, (unsigned)nB, b_first, gA, gB);                                          \
         else conv_dual_kernel<BM, BN, WM, WN, 128, 32, 4, 1><<<grid, block, lds, stream>>>(pa, pb, (unsigned)nA, (unsigned)nB, b_first, gA, gB); \
     } while (0)
     if (tile_a == TILE_128x128) VSTAB_LAUNCH2(128, 128, 2, 2);
     else if (tile_a == TILE_128x64) VSTAB_LAUNCH2(128, 64, 2, 2);
-    else if (tile_a == TILE_256x64) VSTAB_LAUNCH2(256, 64, 4, 1);
     else VSTAB_LAUNCH2(64, 128, 1, 4);
 #undef VSTAB_LAUNCH2
     return hipGetLastError();

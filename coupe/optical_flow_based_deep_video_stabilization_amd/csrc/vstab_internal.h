@@ -155,8 +155,7 @@ __device__ __forceinline__ void splitk_combine_item(const ConvParams &p, const l
 #endif
 
 enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x128 = 3, TILE_64x64 = 4, TILE_256x32 = 5,
-                TILE_SKINNY = 6,       // conv_skinny.hip: 32/64 rows x 32 columns per workgroup, weights streamed through registers
-                TILE_256x64 = 7 };     // 64-column layers with many rows (deconv2 at B=8 512x512): 4 x 1 waves of 64 x 64, the 128x128 tile's wave shape
+                TILE_SKINNY = 6 };     // conv_skinny.hip: 32/64 rows x 32 columns per workgroup, weights streamed through registers
 
 // Launch the implicit-GEMM kernel (and the split-K combine when p.ksplit > 1).
 // ev_start/ev_stop (optional) are recorded immediately around the GEMM kernel itself.

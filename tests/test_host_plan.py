@@ -152,8 +152,8 @@ def test_split_k_plan_is_consistent():
                 assert p["N"] % 4 == 0 and p["Cs_out"] % 4 == 0 and p["c_off"] % 4 == 0
             if p["vec4"]:
                 assert p["Cs_in"] % 4 == 0 and p["SEG"] % 4 == 0 and p["SEG_STRIDE"] % 4 == 0
-            # tile ids: 128x128, 128x64, 128x32, 64x128, 64x64 (harness builds only), 256x32, weight-stream kernel (32 columns), 256x64
-            assert p["tile"] != 4 and p["Npad"] % (128, 64, 32, 128, 64, 32, 32, 64)[p["tile"]] == 0
+            # tile ids: 128x128, 128x64, 128x32, 64x128, 64x64 (harness builds only), 256x32, weight-stream kernel (32 columns)
+            assert p["tile"] != 4 and p["Npad"] % (128, 64, 32, 128, 64, 32, 32)[p["tile"]] == 0
             if p["tile"] == 6:                                           # few rows per phase, a ticket word per (phase, row tile, column block)
                 assert p["Mmax"] <= 64 and -(-p["Mmax"] // 32) * (p["Npad"] // 32) * p["nphase"] <= 4096
                 assert p["ksplit"] <= 16

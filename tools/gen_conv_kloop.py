@@ -51,7 +51,6 @@ class Gen:
         self.A_BUF = self.BM * 128           # bytes per A buffer
         self.B_BUF = self.BN * 128
         self.tag = str(BN) if BM == 128 else f"{BM}{BN}"
-        # (256 x 64, 4 x 1 waves: the 128 x 128 tile's wave shape -- 64 x 64 per wave, G = 16 -- over eight row passes and two weight passes)
         self.out = []
 
     def e(self, s):
@@ -687,11 +686,11 @@ def render():
         o.append("    \"\"")
         if BN == 128:
             o.append("#define VSTAB_KLOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in g.clobbers()))
-    for name, g in (("64x128", Gen(128, BM=64, WM=1, WN=4)), ("256x64", Gen(64, BM=256, WM=4, WN=1))):
-        o.append(f"#define VSTAB_KLOOP_ASM_{name} \\")
-        for l in g.generate():
-            o.append(f'    "{l}\\n" \\')
-        o.append("    \"\"")
+    g = Gen(128, BM=64, WM=1, WN=4)
+    o.append("#define VSTAB_KLOOP_ASM_64x128 \\")
+    for l in g.generate():
+        o.append(f'    "{l}\\n" \\')
+    o.append("    \"\"")
     r1 = RowWinGen(6, MB=1)
     o.append("#define VSTAB_ROWWIN1_ASM_KPR6 \\")
     for l in r1.generate():
