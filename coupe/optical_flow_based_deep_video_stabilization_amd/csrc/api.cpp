@@ -603,7 +603,7 @@ extern "C" int vstab_set_plan_batch(vstab_ctx *ctx, int batch)
 extern "C" int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags)
 {
     if (!ctx) return fail(nullptr, VSTAB_E_STATE, "set_plan_flags: ctx is NULL");
-    if (flags & ~(unsigned)(VSTAB_PLAN_NO_SKINNY | VSTAB_PLAN_NO_DUAL | VSTAB_PLAN_NO_TAIL | VSTAB_PLAN_NO_SLAB_FUSE)) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(unsigned)(VSTAB_PLAN_NO_SKINNY | VSTAB_PLAN_NO_DUAL | VSTAB_PLAN_NO_TAIL)) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
     ctx->plan_flags = flags;
     return VSTAB_OK;
 }
@@ -928,8 +928,6 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
     static const char *const DEC_RANGE[4] = {"deconv5", "deconv4", "deconv3", "deconv2"};
     static const char *const HEAD_RANGE[4] = {"predict_flow6+upsample6_5", "predict_flow5+upsample5_4", "predict_flow4+upsample4_3", "predict_flow3+upsample3_2"};
     TraceRange whole_range("flownetS_pyramid");
-    ConvParams slab_src{};            // a stage whose combine pass rides in the next stage's Winograd input transform
-    bool slabs_pending = false;
     // encoder (model.py:807-844)
     for (int i = 0; i < 10; ++i) {
         TraceRange layer_range(ENC_RANGE[i]);
@@ -973,10 +971,6 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         if (pl.wino[i]) {       // transform, 16-position GEMM on the MFMA kernel, inverse transform (+ bias, leaky relu)
             ConvParams q = pl.wcp[i];
             const int cin_i = ENC[i - 1].cout;
-            if (slabs_pending) {     // the producer left its split-K slabs uncombined: the transform sums them (and writes the producer's tensor)
-                HIP_TRY(ctx, launch_wino_input_slabs(slab_src, B, pl.eh[i], pl.ew[i], buf(B_WINO_V), stream));
-                slabs_pending = false;
-            } else
             HIP_TRY(ctx, launch_wino_input(buf(ENC_IO[i].in_buf), B, pl.eh[i], pl.ew[i], ENC_IO[i].cs_in, 0, cin_i, buf(B_WINO_V), stream));
             q.in = buf(B_WINO_V); q.out = buf(B_WINO_M);
             q.wpk = dw + ctx->wino_w[i]; q.bias = dw + ctx->zero_b; q.partial = buf(B_PARTIAL);
@@ -1003,12 +997,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
             ctx->prof_kernel[i] = "conv_skinny_kernel<1, 4>";
             continue;
         }
-        // a split-K stage whose ONLY consumer is the next stage's Winograd input transform (conv3 -> conv3_1, conv4 -> conv4_1, conv5 ->
-        // conv5_1, conv6 -> conv6_1) skips its combine launch: the transform reads the slabs (launch_wino_input_slabs)
-        const bool fuse_combine = p.ksplit > 1 && i + 1 < 10 && pl.wino[i + 1] && ENC_IO[i + 1].in_buf == ENC_IO[i].out_buf && p.c_off == 0 &&
-                                  p.Cs_out == p.N && ENC[i].cout == p.N && !(pin.flags & VSTAB_PLAN_NO_SLAB_FUSE);
-        HIP_TRY(ctx, launch_conv(p, pl.tile[i], pl.vec4[i], stream, EV_A(i), EV_B(i), !fuse_combine));
-        if (fuse_combine) { slab_src = p; slabs_pending = true; }
+        HIP_TRY(ctx, launch_conv(p, pl.tile[i], pl.vec4[i], stream, EV_A(i), EV_B(i)));
         ctx->prof_kernel[i] = conv_kernel_name(pl.tile[i], pl.vec4[i]);
     }
     // decoder (model.py:847-880)

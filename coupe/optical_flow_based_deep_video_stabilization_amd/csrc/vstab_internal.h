@@ -99,11 +99,18 @@ struct ConvParams {
 #ifdef __HIPCC__
 // One work item of the split-K combine (splitk_combine_kernel; also the first workgroups of combine_predict_up_kernel): item idx sums
 // the slabs of four consecutive output columns of one GEMM row in slab order, adds the bias, applies the activation, scatters.
-// the value itself: slabs of GEMM row m, columns 4 c4 .. 4 c4 + 3 of `phase`, summed in slab order from zero, + bias, activation (1 leaky
-// relu, 2 relu).  ONE definition for every consumer of split-K slabs, so that they all produce the same bits.
-__device__ __forceinline__ float __attribute__((ext_vector_type(4))) splitk_value(const ConvParams &p, const int phase, const int m, const int c4)
+__device__ __forceinline__ void splitk_combine_item(const ConvParams &p, const long long idx)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+    const int n4 = p.N >> 2;
+    const long long per_phase = (long long)p.Mmax * n4;
+    if (idx >= per_phase * p.nphase) return;
+    const int phase = (int)(idx / per_phase);
+    const long long rem = idx - phase * per_phase;
+    const int m = (int)(rem / n4), c4 = (int)(rem - (long long)m * n4);
+    const ConvPhase ph = p.ph[phase];
+    if (m >= ph.M) return;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     const float *src = p.partial + (((long long)(phase * p.ksplit) * p.Mmax + m) * p.Npad + c4 * 4);
     const long long slab = (long long)p.Mmax * p.Npad;
@@ -138,22 +145,6 @@ __device__ __forceinline__ float __attribute__((ext_vector_type(4))) splitk_valu
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] = fmaxf(s[e], slope * s[e]);
     }
-    return s;
-}
-
-__device__ __forceinline__ void splitk_combine_item(const ConvParams &p, const long long idx)
-{
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-    const int n4 = p.N >> 2;
-    const long long per_phase = (long long)p.Mmax * n4;
-    if (idx >= per_phase * p.nphase) return;
-    const int phase = (int)(idx / per_phase);
-    const long long rem = idx - phase * per_phase;
-    const int m = (int)(rem / n4), c4 = (int)(rem - (long long)m * n4);
-    const ConvPhase ph = p.ph[phase];
-    if (m >= ph.M) return;
-    f32x4 s = splitk_value(p, phase, m, c4);
     const int hw = ph.Hg * ph.Wg;
     const int n = m / hw, r2 = m - n * hw;
     const int j = r2 / ph.Wg, i = r2 - j * ph.Wg;
@@ -252,10 +243,6 @@ hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_
                              bool pos_major = false);       // pos_major: V as [16][B*tiles][C] instead of [B][16][tiles][C]
 // device-side weight transform for training: Wt [16][K][N] from W [3,3,cin,cout]; transpose = the input gradient's operand
 hipError_t launch_wino_weights(const float *W, int cin, int cout, int transpose, float *Wt, hipStream_t stream);
-// The same transform fed by the split-K slabs of the PRODUCING convolution (plain one-phase launch whose combine pass was skipped):
-// a pixel's value is splitk_value() -- the bits the combine launch would have written -- and the thread whose tile holds the pixel in its
-// central 2x2 also writes it to the producer's output tensor, so that tensor exists as before.  One launch instead of two.
-hipError_t launch_wino_input_slabs(const ConvParams &producer, int B, int H, int W, float *V, hipStream_t stream);
 hipError_t launch_wino_output(const float *M, int B, int Ho, int Wo, int C, const float *bias, int act, float *out, int Cs_out, int c_off,
                               hipStream_t stream);
 

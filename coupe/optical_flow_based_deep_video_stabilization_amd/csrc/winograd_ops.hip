@@ -61,52 +61,6 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
     }
 }
 
-// wino_input_kernel fed by a producer's split-K slabs (see launch_wino_input_slabs in vstab_internal.h)
-__global__ __launch_bounds__(256) void wino_input_slabs_kernel(const ConvParams pc, int H, int W, int C4, float *__restrict__ V, int TH, int TW,
-                                                               long long sample_stride, long long pos_stride)
-{
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)TH * TW * C4) return;
-    const int n = blockIdx.y;
-    const int c = (int)(idx % C4);
-    const int tile = (int)(idx / C4);
-    const int ty = tile / TW, tx = tile - ty * TW;
-    f32x4 d[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = 2 * ty - 1 + i;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int xx = 2 * tx - 1 + j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                const int m = (n * H + y) * W + xx;               // the producer's GEMM row of this pixel (one phase: rows are (n, y, x))
-                v = splitk_value(pc, 0, m, c);
-                if (i >= 1 && i <= 2 && j >= 1 && j <= 2)         // the tile's own 2x2 pixels: every pixel of the image is exactly one tile's
-                    *reinterpret_cast<f32x4 *>(pc.out + (long long)m * pc.Cs_out + pc.c_off + c * 4) = v;
-            }
-            d[i][j] = v;
-        }
-    }
-    f32x4 t[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        t[0][j] = d[0][j] - d[2][j];
-        t[1][j] = d[1][j] + d[2][j];
-        t[2][j] = d[2][j] - d[1][j];
-        t[3][j] = d[1][j] - d[3][j];
-    }
-    float *vb = V + (long long)n * sample_stride + (long long)tile * (C4 * 4) + c * 4;
-    const long long xs = pos_stride;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 0) * xs) = t[i][0] - t[i][2];
-        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 1) * xs) = t[i][1] + t[i][2];
-        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 2) * xs) = t[i][2] - t[i][1];
-        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 3) * xs) = t[i][1] - t[i][3];
-    }
-}
-
 __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ M, int TH, int TW, int C4, const float *__restrict__ bias,
                                                           int act, float *__restrict__ out, int Ho, int Wo, int Cs_out, int c_off)
 {
@@ -285,19 +239,6 @@ hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_
     const long long per = (long long)TH * TW * (C / 4), tc = (long long)TH * TW * C;
     wino_input_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(x, H, W, Cs, c_off, C / 4, V, TH, TW,
                                                                                               pos_major ? tc : 16 * tc, pos_major ? B * tc : tc);
-    return hipGetLastError();
-}
-
-hipError_t launch_wino_input_slabs(const ConvParams &pc, int B, int H, int W, float *V, hipStream_t stream)
-{
-    // the producer: one phase whose GEMM rows are the pixels (n, y, x) of a B x H x W output, all N channels of it, stride 1 scatter
-    if (pc.nphase != 1 || pc.ksplit < 2 || pc.partial == nullptr || (pc.N & 3) || (pc.Cs_out & 3) || (pc.c_off & 3) || pc.Ho != H || pc.Wo != W ||
-        pc.B != B || pc.s_out != 1 || pc.ph[0].o_y != 0 || pc.ph[0].o_x != 0 || pc.ph[0].M != B * H * W || (pc.act != 0 && pc.act != 1 && pc.act != 2))
-        return hipErrorInvalidValue;
-    const int C = pc.N;
-    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
-    const long long per = (long long)TH * TW * (C / 4), tc = (long long)TH * TW * C;
-    wino_input_slabs_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(pc, H, W, C / 4, V, TH, TW, 16 * tc, tc);
     return hipGetLastError();
 }
 

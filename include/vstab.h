@@ -420,12 +420,10 @@ VSTAB_API int vstab_warp_perspective_u8(const uint8_t *src, int B, int sh, int s
 /* ---- plan flags (A/B measurements and the bit-equality tests; 3 = the round-3 schedule): VSTAB_PLAN_NO_SKINNY keeps few-row
  * layers on the tiled kernel with a split-K combine launch, VSTAB_PLAN_NO_DUAL launches a refinement level's flow head and
  * transposed convolution one after the other, VSTAB_PLAN_NO_TAIL keeps vstab_stabilise_originalsize's last two launches apart (it changes
- * no sum: A/B of the fused tail), VSTAB_PLAN_NO_SLAB_FUSE gives a split-K stage in front of a Winograd stage its own combine launch back
- * (no sum changes either).  Context state; workspace sizes then come from vstab_workspace_bytes_ctx. */
+ * no sum: A/B of the fused tail).  Context state; workspace sizes then come from vstab_workspace_bytes_ctx. */
 #define VSTAB_PLAN_NO_SKINNY 1u
 #define VSTAB_PLAN_NO_DUAL 2u      /* a refinement level as four launches (tap table, predict_up, transposed conv, combine) instead of two */
 #define VSTAB_PLAN_NO_TAIL 4u      /* vstab_stabilise_originalsize: predict_flow2's gather and the glue + warp as two launches (bit-identical) */
-#define VSTAB_PLAN_NO_SLAB_FUSE 8u /* a split-K stage in front of a Winograd stage keeps its own combine launch (bit-identical) */
 VSTAB_API int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags);
 
 /* ---- measurement support.  With profiling enabled every conv-like launch of

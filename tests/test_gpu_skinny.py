@@ -213,32 +213,3 @@ def test_four_phase_transposed_convolutions_on_the_weight_stream_kernel(ctx, B, 
         mag = max(1.0, float(ref[k].abs().max()))
         assert float((a[k] - b[k]).abs().max()) <= PLAN_TO_PLAN_EPS * EPS32 * mag, (k, mag)
         assert float((a[k].double().cpu() - ref[k]).abs().max()) <= 1e-3, k
-
-
-@pytest.mark.parametrize("B,H,W", [(1, 384, 512), (8, 512, 512), (2, 360, 488), (16, 256, 256), (1, 720, 1280)])
-def test_combine_riding_in_the_winograd_input_transform_is_bit_identical(ctx, B, H, W):
-    # a split-K stage whose only consumer is a Winograd stage (conv3 -> conv3_1, conv4 -> conv4_1, conv5 -> conv5_1, conv6 -> conv6_1) leaves
-    # its slabs uncombined and the next stage's input transform sums them -- splitk_value(), the combine launch's own arithmetic -- and
-    # writes the producer's tensor from the threads that own each pixel.  Plan flag 8 gives the combine launch back: every internal
-    # tensor (the producers' outputs included) and every flow must be bit-identical, odd level sizes included.
-    import ctypes
-    tiles = layer_tiles(B, H, W)
-    fused = [(i, i + 1) for i in (2, 4, 6, 8) if tiles[i][1] > 1 and tiles[i][0] != 6 and tiles[i + 1][2] == 1]
-    assert fused, "this shape should have a split-K stage in front of a Winograd stage"
-    g = torch.Generator().manual_seed(B * 17 + H + W)
-    feats = torch.rand(B, H, W, 27, generator=g).cuda()
-    names = ("conv3", "concat3", "conv4", "concat4", "conv5", "concat5", "conv6", "conv6_1")
-    ctx.set_plan_flags(8)
-    a = vs.flownetS_pyramid(feats, B)
-    a = {k: a[k].clone() for k in KEYS}
-    ia = {k: v.clone() for k, v in ctx.internals(B, H, W, 27).items() if k in names}
-    ctx.set_plan_flags(0)
-    for k, v in ctx.internals(B, H, W, 27).items():
-        if k in names:
-            v.fill_(float("nan"))                    # the producers' tensors must be (re)written by the fused transform
-    b = vs.flownetS_pyramid(feats, B)
-    ib = {k: v for k, v in ctx.internals(B, H, W, 27).items() if k in names}
-    for k in names:
-        assert torch.equal(ia[k], ib[k]), k
-    for k in KEYS:
-        assert torch.equal(a[k], b[k]), k
