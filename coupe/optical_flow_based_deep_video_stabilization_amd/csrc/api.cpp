@@ -1538,6 +1538,7 @@ extern "C" int vstab_assemble_input(const uint8_t *const *slots9, int B, int h, 
     for (int j = 0; j < 9; ++j)
         if (!slots9[j]) return fail(nullptr, VSTAB_E_STATE, "assemble_input: slot %d is NULL", j);
     if (B < 1 || h < 1 || w < 1) return fail(nullptr, VSTAB_E_SHAPE, "assemble_input: bad shape");
+    if ((uintptr_t)feats & 15) return fail(nullptr, VSTAB_E_ALIGN, "assemble_input: feats must be 16-byte aligned");
     HIP_TRY(nullptr, launch_assemble_input(slots9, B, h, w, feats, (hipStream_t)stream));
     return VSTAB_OK;
 }
@@ -1547,6 +1548,7 @@ extern "C" int vstab_assemble_input_resized(const uint8_t *const *slots8, const 
 {
     if (!slots8 || !frame || !feats) return fail(nullptr, VSTAB_E_STATE, "assemble_input_resized: NULL buffer");
     if (B < 1 || h < 1 || w < 1 || sh < 1 || sw < 1) return fail(nullptr, VSTAB_E_SHAPE, "assemble_input_resized: bad shape");
+    if ((uintptr_t)feats & 15) return fail(nullptr, VSTAB_E_ALIGN, "assemble_input_resized: feats must be 16-byte aligned");
     HIP_TRY(nullptr, launch_assemble_input_resized(slots8, frame, B, h, w, sh, sw, feats, (hipStream_t)stream));
     return VSTAB_OK;
 }

@@ -53,18 +53,40 @@ __global__ __launch_bounds__(256) void resize_u8_kernel(const unsigned char *__r
 // curinput (main:550-558): feats[n,y,x,3j+c] = hist_j[n,y,x,2-c]/255 for the 8 history slots and the current
 // small frame (slot 8).  slots: 9 device pointers to u8 [B,h,w,3] frames (BGR as cv2 stores them).
 struct Slots9 { const unsigned char *p[9]; };
+// The 27 floats of a pixel are 108 bytes, so a thread storing its own pixel's values scatters 4-byte stores 108 bytes apart (round 4:
+// 144 us for the 170 MB of eight 384x512 stacks, 1.2 TB/s) and divides by 255 twenty-seven times.  A workgroup's 256 pixels are
+// CONTIGUOUS in the output (27 648 bytes): the values go through LDS -- [pixel][27], an odd stride: conflict-free -- and leave as
+// 16-byte stores of the whole block; value / 255.0f comes from a 256-entry table of the same IEEE quotients.
+typedef float f32x4_clip __attribute__((ext_vector_type(4)));
+struct AssembleLds { float lut[256]; float v[256 * 27 + 4]; };
+__device__ __forceinline__ void assemble_store_block(AssembleLds &L, float *__restrict__ feats, long long first_px, long long total_px)
+{
+    __syncthreads();
+    const long long n_valid = min((long long)256, total_px - first_px);          // pixels of this block that exist
+    const int nfl = (int)n_valid * 27;
+    float *o = feats + first_px * 27;                                           // 16-byte aligned: first_px is a multiple of 256
+    for (int e = threadIdx.x * 4; e < nfl; e += 1024) {
+        if (e + 4 <= nfl) *reinterpret_cast<f32x4_clip *>(o + e) = *reinterpret_cast<const f32x4_clip *>(L.v + e);
+        else for (int i = 0; e + i < nfl; ++i) o[e + i] = L.v[e + i];
+    }
+}
 __global__ __launch_bounds__(256) void assemble_input_kernel(Slots9 s, int B, int h, int w, float *__restrict__ feats)
 {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)B * h * w) return;
-    float *o = feats + idx * 27;
+    __shared__ __attribute__((aligned(16))) AssembleLds L;
+    L.lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+    __syncthreads();
+    const long long total = (long long)B * h * w, first = (long long)blockIdx.x * 256, idx = first + threadIdx.x;
+    if (idx < total) {
+        float *o = L.v + threadIdx.x * 27;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const unsigned char *q = s.p[j] + idx * 3;
-        o[3 * j + 0] = (float)q[2] / 255.0f;        // cv2.cvtColor(.., COLOR_RGB2BGR) swaps channels 0 and 2
-        o[3 * j + 1] = (float)q[1] / 255.0f;
-        o[3 * j + 2] = (float)q[0] / 255.0f;
+        for (int j = 0; j < 9; ++j) {
+            const unsigned char *q = s.p[j] + idx * 3;
+            o[3 * j + 0] = L.lut[q[2]];        // cv2.cvtColor(.., COLOR_RGB2BGR) swaps channels 0 and 2
+            o[3 * j + 1] = L.lut[q[1]];
+            o[3 * j + 2] = L.lut[q[0]];
+        }
     }
+    assemble_store_block(L, feats, first, total);
 }
 
 // resizedInput (main:568): swap(frame)/255 as float
@@ -150,30 +172,35 @@ hipError_t launch_resize_u8(const unsigned char *src, int B, int sh, int sw, uns
 __global__ __launch_bounds__(256) void assemble_input_resized_kernel(Slots9 s, const unsigned char *__restrict__ frame, int B, int h, int w, int sh,
                                                                      int sw, float *__restrict__ feats)
 {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)B * h * w) return;
-    const int n = (int)(idx / (h * w));
-    const int rem = (int)(idx - (long long)n * h * w);
-    const int dy = rem / w, dx = rem - dy * w;
-    const Tap X = cv_tap(dx, w, sw), Y = cv_tap(dy, h, sh);
-    const unsigned char *b = frame + (long long)n * sh * sw * 3;
-    const unsigned char *r0 = b + (long long)Y.i0 * sw * 3, *r1 = b + (long long)Y.i1 * sw * 3;
-    unsigned char cur[3];
+    __shared__ __attribute__((aligned(16))) AssembleLds L;
+    L.lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+    __syncthreads();
+    const long long total = (long long)B * h * w, first = (long long)blockIdx.x * 256, idx = first + threadIdx.x;
+    if (idx < total) {
+        const int n = (int)(idx / (h * w));
+        const int rem = (int)(idx - (long long)n * h * w);
+        const int dy = rem / w, dx = rem - dy * w;
+        const Tap X = cv_tap(dx, w, sw), Y = cv_tap(dy, h, sh);
+        const unsigned char *b = frame + (long long)n * sh * sw * 3;
+        const unsigned char *r0 = b + (long long)Y.i0 * sw * 3, *r1 = b + (long long)Y.i1 * sw * 3;
+        unsigned char cur[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int R0 = r0[X.i0 * 3 + c] * X.a0 + r0[X.i1 * 3 + c] * X.a1;
-        const int R1 = r1[X.i0 * 3 + c] * X.a0 + r1[X.i1 * 3 + c] * X.a1;
-        const int v = (((Y.a0 * (R0 >> 4)) >> 16) + ((Y.a1 * (R1 >> 4)) >> 16) + 2) >> 2;
-        cur[c] = (unsigned char)min(max(v, 0), 255);
-    }
-    float *o = feats + idx * 27;
+        for (int c = 0; c < 3; ++c) {
+            const int R0 = r0[X.i0 * 3 + c] * X.a0 + r0[X.i1 * 3 + c] * X.a1;
+            const int R1 = r1[X.i0 * 3 + c] * X.a0 + r1[X.i1 * 3 + c] * X.a1;
+            const int v = (((Y.a0 * (R0 >> 4)) >> 16) + ((Y.a1 * (R1 >> 4)) >> 16) + 2) >> 2;
+            cur[c] = (unsigned char)min(max(v, 0), 255);
+        }
+        float *o = L.v + threadIdx.x * 27;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const unsigned char *q = (j < 8 && s.p[j] != nullptr) ? s.p[j] + idx * 3 : cur;
-        o[3 * j + 0] = (float)q[2] / 255.0f;
-        o[3 * j + 1] = (float)q[1] / 255.0f;
-        o[3 * j + 2] = (float)q[0] / 255.0f;
+        for (int j = 0; j < 9; ++j) {
+            const unsigned char *q = (j < 8 && s.p[j] != nullptr) ? s.p[j] + idx * 3 : cur;
+            o[3 * j + 0] = L.lut[q[2]];
+            o[3 * j + 1] = L.lut[q[1]];
+            o[3 * j + 2] = L.lut[q[0]];
+        }
     }
+    assemble_store_block(L, feats, first, total);
 }
 
 hipError_t launch_assemble_input_resized(const unsigned char *const *slots8, const unsigned char *frame, int B, int h, int w, int sh, int sw,

@@ -229,7 +229,7 @@ VSTAB_API int vstab_resize_u8(const uint8_t *src, int B, int sh, int sw, uint8_t
  * float bilinear resize with cv2's half-pixel centres, * 255, channels 0 and 2 swapped, truncated to 8 bits.  src [B,sh,sw,3]. */
 VSTAB_API int vstab_resize_f32_to_u8(const float *src, int B, int sh, int sw, uint8_t *dst, int dh, int dw, void *stream);
 /* curinput (main:550-558): feats[B,h,w,27]; slot j < 8 = history frame of lag {31,23,15,7,4,3,2,1}[j], slot 8 = current
- * frame, each u8 [B,h,w,3] at network resolution; channels swapped (COLOR_RGB2BGR) and divided by 255. */
+ * frame, each u8 [B,h,w,3] at network resolution; channels swapped (COLOR_RGB2BGR) and divided by 255.  feats 16-byte aligned. */
 VSTAB_API int vstab_assemble_input(const uint8_t *const *slots9, int B, int h, int w, float *feats, void *stream);
 /* The same with the current frame's cv2.resize inside (main:550 + 553-558 as one launch): frame u8 [B,sh,sw,3] at its own resolution;
  * slots8[j] == NULL reads the resized current frame (the first frame of a clip, main:548-549). */
