@@ -152,7 +152,10 @@ static double split_cost_us(long long tiles, int KT, int ks, double slab_bytes, 
     const double TAU2 = 4.2 * (BN >= 128 ? 1.0 : (BN == 64 ? 0.58 : 0.36)) * (BM == 64 ? 0.55 : 1.0);
     const double TAU1 = 0.525 * TAU2, T0 = 5.0;     // in-situ: 2.10 vs 4.00 us per K-tile (conv4_1), 2.20 vs 4.19 (conv4); with the assembly K loop
                                                     // 1.87 vs 3.52: same ratio, and 3.55 / 0.53 / T0 3..11 pick the same splits at B=8 512x512 (r03k sweep)
-    const double BW = 1.2e7;                                        // bytes per us for the slab traffic (L2 / MALL resident)
+    // bytes per us for the slab traffic: slabs that stay in the L2s (32 MB across the 8 XCDs; one sample's) move at ~12 TB/s, a launch's
+    // worth beyond that goes through the Infinity Cache / HBM (round 5 A/B, profiles/ab_r05t_slab_bandwidth.txt: B=8 512x512 conv5 /
+    // deconv5 / deconv4 with 34 / 34 / 17 MB of slabs at split 8 / 8 / 4 are faster at 4 / 4 / 2)
+    const double BW = slab_bytes * ((KT + ((KT + ks - 1) / ks) - 1) / ((KT + ks - 1) / ks)) > 16e6 ? 5.0e6 : 1.2e7;
     const int kts = (KT + ks - 1) / ks, ks_eff = (KT + kts - 1) / kts;
     const long long blocks = tiles * ks_eff, full = blocks / 512, rem = blocks % 512;
     double t = (double)full * (kts * TAU2 + T0);
