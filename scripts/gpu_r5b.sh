@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, second visit: the 64 x 128 tile's assembly K loop (bit check against the build that keeps hipcc's loop for that tile, then the
+# round 5, second visit (build tools/libvstab_hip_cxx64.so first: scripts/build_variant_lib.sh cxx64 -DVSTAB_NO_ASM_KLOOP_64): the 64 x 128 tile's assembly K loop (bit check against the build that keeps hipcc's loop for that tile, then the
 # interleaved A/B at the two one-sample shapes), the one-call clip step (tests + bench_stream), the changed tests.
 set -u
 tag=${1:-r05b}
