@@ -107,8 +107,8 @@ class Trainer:
         # (vstab.h: VSTAB_CONV_PACK_ONLY / VSTAB_CONV_PREPACKED).  The first step records the calls (their order and arguments never
         # change), later steps replay them.
         self.prepack = True
-        self._pp_mode, self._pp_sites, self._pp_ws, self._pp_i = None, None, [], 0
-        self._pp_stream, self._pp_valid_t = None, -1
+        self._pp_mode, self._pp_sites, self._pp_ws, self._pp_ev, self._pp_i = None, None, [], [], 0
+        self._pp_stream = None
         self._alloc_buffers()
 
     # ------------------------------------------------------------------ parameters
@@ -242,9 +242,6 @@ class Trainer:
         single stream would run one after the other -- dealt round-robin to four side streams; the main stream waits for all of them
         and only then starts the forward.  (Gathering BESIDE the first layers was tried first: the small launches take CUs from conv1 ...
         conv3 and the step got slower, 11.48 -> 11.73 ms.)"""
-        if self._pp_stream is None:          # first use: the sites are known -- their workspaces and the side streams
-            self._pp_stream = [torch.cuda.Stream(device=self.dev) for _ in range(4)]
-            self._pp_ws = [torch.empty(nb + 256, dtype=torch.uint8, device=self.dev) for nb, _c in self._pp_sites]
         main = torch.cuda.current_stream()
         self._refresh_head_matrices()
         for side in self._pp_stream:
@@ -600,9 +597,11 @@ class Trainer:
                 if self._pp_sites is None:
                     self._pp_mode, self._pp_sites = "record", []
                 else:
-                    if self._pp_valid_t != self.t:   # (not gathered at the end of the previous step: the first replay, or `weights_changed()`)
-                        self._prepack_all()
+                    if self._pp_stream is None:      # second step: the sites are known -- their workspaces and the side streams
+                        self._pp_stream = [torch.cuda.Stream(device=self.dev) for _ in range(4)]
+                        self._pp_ws = [torch.empty(nb + 256, dtype=torch.uint8, device=self.dev) for nb, _c in self._pp_sites]
                     self._pp_mode, self._pp_i = "replay", 0
+                    self._prepack_all()
             try:
                 self.forward(feats)
                 self._dp_group, self._dp_handles, self._dp_sent = (group if parallel else False), [], 0
@@ -616,17 +615,7 @@ class Trainer:
                 self._pp_mode = None
             self.sync_replicas(group)
             self.adam(lr, beta1)
-            if self.prepack and self._pp_sites is not None:
-                # the NEXT step's operands, now: the weights are final once Adam has run, the host is far ahead of the GPU here (the
-                # forty calls are issued while the backward pass still computes), and on the GPU the gathers follow Adam on four streams
-                # at once.  (Issued at the start of the next step instead, the GPU waited for the host: 11.48 -> 11.79 ms.)
-                self._prepack_all()
-                self._pp_valid_t = self.t
         return loss
-
-    def weights_changed(self):
-        """Tell the trainer that `self.p` was edited in place outside `adam()`: the operands gathered ahead for the next step are stale."""
-        self._pp_valid_t = -1
 
 
 # ---------------------------------------------------------------------- the training graph behind model.flownetS_pyramid(is_train=True)
