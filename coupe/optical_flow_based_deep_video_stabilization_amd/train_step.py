@@ -102,10 +102,9 @@ class Trainer:
         self.overlap_single_rank = False      # tests: run the overlapped exchange even when the process group has one rank
         self.wino_min_flops = 3.0e9           # a 3x3 stride-1 stage runs in Winograd form once its GEMM issues this much
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.dev)
-        # step(): every layer's MFMA operand is gathered from the raw weights at the START of the step -- the weights are final by then --
-        # on four side streams at once instead of one small launch in front of every layer; the layers then skip their own gather
-        # (vstab.h: VSTAB_CONV_PACK_ONLY / VSTAB_CONV_PREPACKED).  The first step records the calls (their order and arguments never
-        # change), later steps replay them.
+        # step(): every layer's MFMA operand is gathered from the raw weights on a SECOND stream at the start of the step -- the weights
+        # are final by then -- while the first layers already run; the layers then skip their own gather (vstab.h: VSTAB_CONV_PACK_ONLY /
+        # VSTAB_CONV_PREPACKED).  The first step records the calls (their order and arguments never change), later steps replay them.
         self.prepack = True
         self._pp_mode, self._pp_sites, self._pp_ws, self._pp_ev, self._pp_i = None, None, [], [], 0
         self._pp_stream = None
@@ -229,6 +228,7 @@ class Trainer:
         if self._pp_mode == "replay":
             i = self._pp_i
             self._pp_i += 1
+            torch.cuda.current_stream().wait_event(self._pp_ev[i])
             ws = self._pp_ws[i]
             self._timed(kind, flops, lambda: self._check(call(ws, PREPACKED, self.st)))
             return
@@ -238,21 +238,17 @@ class Trainer:
         self._timed(kind, flops, lambda: self._check(call(ws, 0, self.st)))
 
     def _prepack_all(self):
-        """Start of a replayed step: the head matrices, then every recorded site's operand gather -- some forty launches of ~10 us that a
-        single stream would run one after the other -- dealt round-robin to four side streams; the main stream waits for all of them
-        and only then starts the forward.  (Gathering BESIDE the first layers was tried first: the small launches take CUs from conv1 ...
-        conv3 and the step got slower, 11.48 -> 11.73 ms.)"""
+        """Start of a replayed step: head matrices, then every recorded site's gather, on the side stream (ordered after whatever the main
+        stream has queued: the previous step's Adam); one event per site."""
         main = torch.cuda.current_stream()
-        self._refresh_head_matrices()
-        for side in self._pp_stream:
-            side.wait_stream(main)
-        n = len(self._pp_stream)
-        for i, ((nb, call), ws) in enumerate(zip(self._pp_sites, self._pp_ws)):
-            side = self._pp_stream[i % n]
-            with torch.cuda.stream(side):
-                self._check(call(ws, PACK_ONLY, C.c_void_p(side.cuda_stream)))
-        for side in self._pp_stream:
-            main.wait_stream(side)
+        side = self._pp_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._refresh_head_matrices()
+            st = C.c_void_p(side.cuda_stream)
+            for (nb, call), ws, ev in zip(self._pp_sites, self._pp_ws, self._pp_ev):
+                self._check(call(ws, PACK_ONLY, st))
+                ev.record(side)
 
     def _conv_fwd(self, x, cx_off, cin, W, b, k, s, p, y, cy_off, cout, act=0):
         B, Hi, Wi, cs_x = x.shape
@@ -597,9 +593,10 @@ class Trainer:
                 if self._pp_sites is None:
                     self._pp_mode, self._pp_sites = "record", []
                 else:
-                    if self._pp_stream is None:      # second step: the sites are known -- their workspaces and the side streams
-                        self._pp_stream = [torch.cuda.Stream(device=self.dev) for _ in range(4)]
+                    if self._pp_stream is None:      # second step: the sites are known -- their workspaces, events and the side stream
+                        self._pp_stream = torch.cuda.Stream(device=self.dev)
                         self._pp_ws = [torch.empty(nb + 256, dtype=torch.uint8, device=self.dev) for nb, _c in self._pp_sites]
+                        self._pp_ev = [torch.cuda.Event() for _ in self._pp_sites]
                     self._pp_mode, self._pp_i = "replay", 0
                     self._prepack_all()
             try:
