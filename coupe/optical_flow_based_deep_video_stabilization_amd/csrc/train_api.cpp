@@ -321,9 +321,6 @@ extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs
                                 void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!gout || !W || !dx || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv_dgrad: NULL buffer");
-    const int mode = accumulate & (VSTAB_CONV_PACK_ONLY | VSTAB_CONV_PREPACKED);      // the two flags ride in `accumulate` here
-    accumulate &= ~(VSTAB_CONV_PACK_ONLY | VSTAB_CONV_PREPACKED);
-    if (mode == (VSTAB_CONV_PACK_ONLY | VSTAB_CONV_PREPACKED)) return fail(nullptr, VSTAB_E_SHAPE, "conv_dgrad: PACK_ONLY and PREPACKED exclude each other");
     if (B < 1 || Ho < 1 || Wo < 1 || Hi < 1 || Wi < 1 || k < 1 || k > 7 || (stride != 1 && stride != 2) || pad < 0 || pad > k - 1 ||
         cin < 1 || cout < 1 || cg_off < 0 || cx_off < 0 || cg_off + cout > cs_g || cx_off + cin > cs_x)
         return fail(nullptr, VSTAB_E_SHAPE, "conv_dgrad: bad shape (stride must be 1 or 2)");
@@ -352,16 +349,15 @@ extern "C" int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs
     char *ws = reinterpret_cast<char *>(workspace);
     float *wpk = reinterpret_cast<float *>(ws);
     float *bias = reinterpret_cast<float *>(ws + bias_off);
-    if (mode != VSTAB_CONV_PREPACKED) HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
+    HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
     // the bias vector the kernel reads has Npad entries: a shared zero vector when there is none, the caller's own when it is
     // already that long, a padded copy otherwise
     if (!bias_in && d.p.Npad <= 8192 && zero_bias()) bias = const_cast<float *>(zero_bias());
     else if (bias_in && cin == d.p.Npad) bias = const_cast<float *>(bias_in);
-    else if (mode != VSTAB_CONV_PREPACKED) {
+    else {
         HIP_TRY(nullptr, hipMemsetAsync(bias, 0, (size_t)d.p.Npad * sizeof(float), st));
         if (bias_in) HIP_TRY(nullptr, hipMemcpyAsync(bias, bias_in, (size_t)cin * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
-    if (mode == VSTAB_CONV_PACK_ONLY) return VSTAB_OK;
     const int nl = d.nsub ? d.nsub : 1;
     for (int s = 0; s < nl; ++s) {
         ConvParams p = d.nsub ? d.sp[s] : d.p;
@@ -474,10 +470,6 @@ extern "C" int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_
                                   void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!x || !W || !y || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv_forward: NULL buffer");
-    // VSTAB_CONV_PACK_ONLY / VSTAB_CONV_PREPACKED (vstab.h) ride in `act`: the operand gather + bias vector alone / everything but them
-    const int mode = act & (VSTAB_CONV_PACK_ONLY | VSTAB_CONV_PREPACKED);
-    act &= ~(VSTAB_CONV_PACK_ONLY | VSTAB_CONV_PREPACKED);
-    if (mode == (VSTAB_CONV_PACK_ONLY | VSTAB_CONV_PREPACKED)) return fail(nullptr, VSTAB_E_SHAPE, "conv_forward: PACK_ONLY and PREPACKED exclude each other");
     if (B < 1 || Hi < 1 || Wi < 1 || k < 1 || k > 7 || stride < 1 || pad < 0 || cin < 1 || cout < 1 || cx_off < 0 || cy_off < 0 ||
         cx_off + cin > cs_x || cy_off + cout > cs_y || act < 0 || act > 3)
         return fail(nullptr, VSTAB_E_SHAPE, "conv_forward: bad shape");
@@ -494,17 +486,14 @@ extern "C" int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_
     char *ws = reinterpret_cast<char *>(workspace);
     float *wpk = reinterpret_cast<float *>(ws);
     float *bias = reinterpret_cast<float *>(ws + bias_off);
-    if (mode != VSTAB_CONV_PREPACKED) {
-        if (d.blocked_K) HIP_TRY(nullptr, launch_pack_blocked(W, d.blocked_K, cout, d.p.Npad, 1, wpk, st));
-        else HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
-    }
+    if (d.blocked_K) HIP_TRY(nullptr, launch_pack_blocked(W, d.blocked_K, cout, d.p.Npad, 1, wpk, st));
+    else HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
     if (!bias_in && d.p.Npad <= 8192 && zero_bias()) bias = const_cast<float *>(zero_bias());
     else if (bias_in && cout == d.p.Npad) bias = const_cast<float *>(bias_in);
-    else if (mode != VSTAB_CONV_PREPACKED) {
+    else {
         HIP_TRY(nullptr, hipMemsetAsync(bias, 0, (size_t)d.p.Npad * sizeof(float), st));
         if (bias_in) HIP_TRY(nullptr, hipMemcpyAsync(bias, bias_in, (size_t)cout * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
-    if (mode == VSTAB_CONV_PACK_ONLY) return VSTAB_OK;
     ConvParams p = d.p;
     p.in = x + cx_off;
     p.in_bytes = (unsigned)((long long)B * Hi * Wi * cs_x * 4 - (long long)cx_off * 4);
@@ -752,9 +741,6 @@ extern "C" int vstab_conv3x3_winograd(const float *x, int B, int H, int W, int c
                                       void *stream)
 {
     if (!x || !Wf || !y || !workspace) return fail(nullptr, VSTAB_E_STATE, "conv3x3_winograd: NULL buffer");
-    const int mode = act & (VSTAB_CONV_PACK_ONLY | VSTAB_CONV_PREPACKED);           // as in vstab_conv_forward
-    act &= ~(VSTAB_CONV_PACK_ONLY | VSTAB_CONV_PREPACKED);
-    if (mode == (VSTAB_CONV_PACK_ONLY | VSTAB_CONV_PREPACKED)) return fail(nullptr, VSTAB_E_SHAPE, "conv3x3_winograd: PACK_ONLY and PREPACKED exclude each other");
     const int K = transpose ? cout : cin, N = transpose ? cin : cout;             // reduction / output channels of this call
     if (B < 1 || H < 1 || W < 1 || cin < 1 || cout < 1 || cx_off < 0 || cy_off < 0 || cx_off + K > cs_x || cy_off + N > cs_y ||
         (act != 0 && act != 1 && act != 3))
@@ -775,12 +761,9 @@ extern "C" int vstab_conv3x3_winograd(const float *x, int B, int H, int W, int c
     float *V = reinterpret_cast<float *>(ws); ws += a256(tiles * K * 4);
     float *M = reinterpret_cast<float *>(ws); ws += a256(tiles * N * 4);
     float *bz = reinterpret_cast<float *>(ws);
-    if (mode != VSTAB_CONV_PREPACKED) {
-        HIP_TRY(nullptr, launch_wino_weights(Wf, cin, cout, transpose, Wt, st));
-        HIP_TRY(nullptr, launch_pack_blocked(Wt, K, N, N, 16, wpk, st));           // 16 x [K][N] -> 16 x [K/32][N][32]
-        HIP_TRY(nullptr, hipMemsetAsync(bz, 0, (size_t)N * sizeof(float), st));
-    }
-    if (mode == VSTAB_CONV_PACK_ONLY) return VSTAB_OK;
+    HIP_TRY(nullptr, launch_wino_weights(Wf, cin, cout, transpose, Wt, st));
+    HIP_TRY(nullptr, launch_pack_blocked(Wt, K, N, N, 16, wpk, st));           // 16 x [K][N] -> 16 x [K/32][N][32]
+    HIP_TRY(nullptr, hipMemsetAsync(bz, 0, (size_t)N * sizeof(float), st));
     HIP_TRY(nullptr, launch_wino_input(x, B, H, W, cs_x, cx_off, K, V, st));
     ConvParams p = d.p;
     p.in = V; p.out = M; p.wpk = wpk; p.bias = bz; p.partial = nullptr;

@@ -15,7 +15,6 @@ column only ever receives a zero gradient, so the padding stays zero under Adam 
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 from typing import Dict, Tuple
 
@@ -43,7 +42,6 @@ DEC = (("deconv5", "conv6_1", 1024, "concat5", 512, 512, "predict6", "upsample6_
 PRED_IN = {"predict6": ("conv6_1", 1024), "predict5": ("concat5", 1026), "predict4": ("concat4", 770), "predict3": ("concat3", 386),
            "predict2": ("concat2", 194)}
 BN_DECAY, BN_EPS = 0.9, 1e-5        # TensorLayer BatchNormLayer defaults
-PACK_ONLY, PREPACKED = 0x100, 0x200     # VSTAB_CONV_PACK_ONLY / VSTAB_CONV_PREPACKED (vstab.h)
 LR_INIT, LR_DECAY, DECAY_EVERY, BETA1 = 1e-4, 0.8, 20, 0.9     # config.py:19-25 (config.TRAIN.*)
 
 
@@ -102,12 +100,6 @@ class Trainer:
         self.overlap_single_rank = False      # tests: run the overlapped exchange even when the process group has one rank
         self.wino_min_flops = 3.0e9           # a 3x3 stride-1 stage runs in Winograd form once its GEMM issues this much
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.dev)
-        # step(): every layer's MFMA operand is gathered from the raw weights on a SECOND stream at the start of the step -- the weights
-        # are final by then -- while the first layers already run; the layers then skip their own gather (vstab.h: VSTAB_CONV_PACK_ONLY /
-        # VSTAB_CONV_PREPACKED).  The first step records the calls (their order and arguments never change), later steps replay them.
-        self.prepack = True
-        self._pp_mode, self._pp_sites, self._pp_ws, self._pp_ev, self._pp_i = None, None, [], [], 0
-        self._pp_stream = None
         self._alloc_buffers()
 
     # ------------------------------------------------------------------ parameters
@@ -221,35 +213,6 @@ class Trainer:
             out[kind] = (ms + a.elapsed_time(b), f + fl, n + 1)
         return out
 
-    def _packable(self, kind, flops, nbytes, call):
-        """One conv-family library call whose operand gather can run ahead (`call(workspace, flags, stream)`).  Outside step(): gather +
-        layer in the shared workspace.  step() recording: the same, and the call is remembered.  step() replaying: the layer alone
-        (VSTAB_CONV_PREPACKED) in the site's own workspace, once the side stream's gather for this site has finished."""
-        if self._pp_mode == "replay":
-            i = self._pp_i
-            self._pp_i += 1
-            torch.cuda.current_stream().wait_event(self._pp_ev[i])
-            ws = self._pp_ws[i]
-            self._timed(kind, flops, lambda: self._check(call(ws, PREPACKED, self.st)))
-            return
-        ws = self._workspace(nbytes)
-        if self._pp_mode == "record":
-            self._pp_sites.append((int(nbytes), call))
-        self._timed(kind, flops, lambda: self._check(call(ws, 0, self.st)))
-
-    def _prepack_all(self):
-        """Start of a replayed step: head matrices, then every recorded site's gather, on the side stream (ordered after whatever the main
-        stream has queued: the previous step's Adam); one event per site."""
-        main = torch.cuda.current_stream()
-        side = self._pp_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._refresh_head_matrices()
-            st = C.c_void_p(side.cuda_stream)
-            for (nb, call), ws, ev in zip(self._pp_sites, self._pp_ws, self._pp_ev):
-                self._check(call(ws, PACK_ONLY, st))
-                ev.record(side)
-
     def _conv_fwd(self, x, cx_off, cin, W, b, k, s, p, y, cy_off, cout, act=0):
         B, Hi, Wi, cs_x = x.shape
         cs_y = y.shape[3]
@@ -257,10 +220,10 @@ class Trainer:
         n = self.L.vstab_conv_forward_workspace_bytes(B, Hi, Wi, cs_x, cin, k, s, p, cout, cs_y, cy_off, act, Ho, Wo)
         if n == 0:
             raise ValueError("conv_forward: unsupported geometry")
-        args = (x.data_ptr(), B, Hi, Wi, cs_x, cx_off, cin, W.data_ptr(), b.data_ptr() if b is not None else None, k, s, p, y.data_ptr(), Ho, Wo,
-                cs_y, cy_off, cout)
-        self._packable("conv_forward", 2.0 * B * Ho * Wo * k * k * cin * cout, n,
-                       lambda ws, flags, st: self.L.vstab_conv_forward(*args, act | flags, ws.data_ptr(), ws.numel(), st))
+        ws = self._workspace(n)
+        self._timed("conv_forward", 2.0 * B * Ho * Wo * k * k * cin * cout, lambda: self._check(self.L.vstab_conv_forward(
+            x.data_ptr(), B, Hi, Wi, cs_x, cx_off, cin, W.data_ptr(), b.data_ptr() if b is not None else None,
+            k, s, p, y.data_ptr(), Ho, Wo, cs_y, cy_off, cout, act, ws.data_ptr(), ws.numel(), self.st)))
 
     def _conv1_rowwin(self, x, W, b, k, s, p, y, cout):
         """model.py:807-808 on conv_rowwin_kernel (vstab_conv_rowwin_forward): x [B,H,W,27] as given, W the padded device filter
@@ -284,11 +247,10 @@ class Trainer:
         n = self.L.vstab_conv_dgrad_workspace_bytes(B, Ho, Wo, cs_g, cout, k, s, p, Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0)
         if n == 0:
             raise ValueError("conv_dgrad: unsupported geometry")
-        args = (g.data_ptr(), B, Ho, Wo, cs_g, cg_off, cout, W.data_ptr(), b.data_ptr() if b is not None else None, k, s, p, dx.data_ptr(), Hi, Wi,
-                cs_x, cx_off, cin)
-        acc = 1 if accumulate else 0
-        self._packable("conv_dgrad", 2.0 * B * Ho * Wo * k * k * cin * cout, n,
-                       lambda ws, flags, st: self.L.vstab_conv_dgrad(*args, acc | flags, ws.data_ptr(), ws.numel(), st))
+        ws = self._workspace(n)
+        self._timed("conv_dgrad", 2.0 * B * Ho * Wo * k * k * cin * cout, lambda: self._check(self.L.vstab_conv_dgrad(
+            g.data_ptr(), B, Ho, Wo, cs_g, cg_off, cout, W.data_ptr(), b.data_ptr() if b is not None else None,
+            k, s, p, dx.data_ptr(), Hi, Wi, cs_x, cx_off, cin, 1 if accumulate else 0, ws.data_ptr(), ws.numel(), self.st)))
 
     def _wino(self, x, cx_off, W, transpose, bias, y, cy_off, act):
         """3x3 stride-1 stage (or its input gradient) in Winograd F(2x2,3x3) form; False when the geometry does not qualify."""
@@ -300,11 +262,11 @@ class Trainer:
         n = self.L.vstab_conv3x3_winograd_workspace_bytes(B, H, Wd, cin, cout, 1 if transpose else 0)
         if n == 0:
             return False
+        ws = self._workspace(n)
         # flops as the direct 3x3 convolution SURVEY.md 8d prices (the Winograd form issues 4/9 of them)
-        args = (x.data_ptr(), B, H, Wd, cs_x, cx_off, W.data_ptr(), cin, cout, 1 if transpose else 0, bias.data_ptr() if bias is not None else None,
-                y.data_ptr(), y.shape[3], cy_off)
-        self._packable("conv3x3_winograd", 2.0 * B * H * Wd * 9 * cin * cout, n,
-                       lambda ws, flags, st: self.L.vstab_conv3x3_winograd(*args, act | flags, ws.data_ptr(), ws.numel(), st))
+        self._timed("conv3x3_winograd", 2.0 * B * H * Wd * 9 * cin * cout, lambda: self._check(self.L.vstab_conv3x3_winograd(
+            x.data_ptr(), B, H, Wd, cs_x, cx_off, W.data_ptr(), cin, cout, 1 if transpose else 0,
+            bias.data_ptr() if bias is not None else None, y.data_ptr(), y.shape[3], cy_off, act, ws.data_ptr(), ws.numel(), self.st)))
         return True
 
     def _wgrad(self, x, cx_off, cin, g, cg_off, cout, k, s, p, dW, db):
@@ -369,8 +331,6 @@ class Trainer:
             raise ValueError(f"feats must be a float32 CUDA tensor {(self.B, self.H, self.W, 27)}")
         self.st = runtime.stream_ptr()
         a, p = self.a, self.p
-        if self._pp_mode != "replay":
-            self._refresh_head_matrices()           # (a replayed step did this on the side stream)
         a["x0"][..., :27].copy_(feats)              # the 28-channel copy the first layer's filter gradient reads
         for name, k, s, pad, cout in ENC:                                                # model.py:807-844
             ib, ioff, cin = ENC_IN[name]
@@ -409,18 +369,12 @@ class Trainer:
         self.pf["predict_flow2"][..., :2].copy_(self.pf2c)
         return {k: v[..., :2] for k, v in self.pf.items()}
 
-    def _refresh_head_matrices(self):
-        """The five 3x3 -> 2 heads' filters [3,3,cs,4] as the matrices of their tap tables' 1x1 convs, WT[c][tap*2+o] = W[tap][c][o] (o < 2),
-        and the transposes the backward pass multiplies with, into persistent buffers (strided copies; columns 18..31 stay zero).  They
-        depend on the parameters alone: once per forward, or on the side stream at the start of a replayed step."""
-        for pname, (pin, _c) in PRED_IN.items():
-            level = "predict_flow" + pname[-1]
-            cs = BUF_C[pin]
-            self.WTh[level][0, 0, :, :18].view(cs, 3, 3, 2).copy_(self.p[f"{pname}/W_conv2d"][..., :2].permute(2, 0, 1, 3))
-            self.WTth[level][0, 0].copy_(self.WTh[level][0, 0].t())
-
     def _head_matrix(self, pname, level, cs):
-        return self.WTh[level]
+        """The 3x3 -> 2 head's filter [3,3,cs,4] as the matrix of its tap table's 1x1 conv: WT[c][tap*2+o] = W[tap][c][o] (o < 2), into the
+        level's persistent [1,1,cs,32] buffer (one strided copy; columns 18..31 stay zero)."""
+        WT = self.WTh[level]
+        WT[0, 0, :, :18].view(cs, 3, 3, 2).copy_(self.p[f"{pname}/W_conv2d"][..., :2].permute(2, 0, 1, 3))
+        return WT
 
     def _head_forward(self, pname, level, x, cs):
         """predict_flowN's 3x3 pad-1 conv to 2 channels (model.py:848, 856, 865, 874) through its tap table, as the inference path and the
@@ -445,7 +399,9 @@ class Trainer:
         self._wgrad(x, 0, cs, dT, 0, 32, 1, 1, 0, dWT, None)
         self.g[f"{pname}/W_conv2d"][..., :2].copy_(dWT[0, 0, :, :18].view(cs, 3, 3, 2).permute(1, 2, 0, 3))
         self._colsum(d, 0, 4, self.g[f"{pname}/b_conv2d"])
-        self._conv_fwd(dT, 0, 32, self.WTth[level], None, 1, 1, 0, Gx, 0, cs, act=3 if acc else 0)
+        WTt = self.WTth[level]
+        WTt[0, 0].copy_(self.WTh[level][0, 0].t())
+        self._conv_fwd(dT, 0, 32, WTt, None, 1, 1, 0, Gx, 0, cs, act=3 if acc else 0)
 
     def lrelu_masks(self) -> Dict[str, torch.Tensor]:
         """{BatchNorm layer: y > 0} of the last forward (host bool tensors): which side of the leaky relu every element is on."""
@@ -500,7 +456,9 @@ class Trainer:
         self._wgrad(c2, 0, 196, self.dT, 0, 32, 1, 1, 0, dWT, None)
         # (the padded output channels of predict2's filter gradient keep the zeros they were created with)
         g["predict2/W_conv2d"][..., :2].copy_(dWT[0, 0, :, :18].view(196, 3, 3, 2).permute(1, 2, 0, 3))
-        self._conv_fwd(self.dT, 0, 32, self.WTth["predict_flow2"], None, 1, 1, 0, G["concat2"], 0, 196, act=3 if self._acc("concat2") else 0)
+        WTt = self.WTth["predict_flow2"]
+        WTt[0, 0].copy_(self.WT[0, 0].t())
+        self._conv_fwd(self.dT, 0, 32, WTt, None, 1, 1, 0, G["concat2"], 0, 196, act=3 if self._acc("concat2") else 0)
         # decoder levels, fine to coarse
         levels = ["predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3"]
         for i in range(3, -1, -1):
@@ -589,27 +547,12 @@ class Trainer:
         import torch.distributed as dist
         parallel = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.overlap_single_rank)
         with torch.cuda.device(self.dev):
-            if self.prepack:
-                if self._pp_sites is None:
-                    self._pp_mode, self._pp_sites = "record", []
-                else:
-                    if self._pp_stream is None:      # second step: the sites are known -- their workspaces, events and the side stream
-                        self._pp_stream = torch.cuda.Stream(device=self.dev)
-                        self._pp_ws = [torch.empty(nb + 256, dtype=torch.uint8, device=self.dev) for nb, _c in self._pp_sites]
-                        self._pp_ev = [torch.cuda.Event() for _ in self._pp_sites]
-                    self._pp_mode, self._pp_i = "replay", 0
-                    self._prepack_all()
+            self.forward(feats)
+            self._dp_group, self._dp_handles, self._dp_sent = (group if parallel else False), [], 0
             try:
-                self.forward(feats)
-                self._dp_group, self._dp_handles, self._dp_sent = (group if parallel else False), [], 0
-                try:
-                    loss = self.loss_and_backward(gtstab, unstab)      # finished gradient buckets go on the wire as it proceeds
-                finally:
-                    self._dp_group = False
-                if self._pp_mode == "replay" and self._pp_i != len(self._pp_sites):
-                    raise RuntimeError("the step's conv-family calls changed since they were recorded")
+                loss = self.loss_and_backward(gtstab, unstab)      # finished gradient buckets go on the wire as it proceeds
             finally:
-                self._pp_mode = None
+                self._dp_group = False
             self.sync_replicas(group)
             self.adam(lr, beta1)
         return loss

@@ -311,14 +311,6 @@ VSTAB_API int vstab_conv_dgrad(const float *gout, int B, int Ho, int Wo, int cs_
                                const float *bias /* device [cin] added to every output pixel, or NULL */, int k, int stride, int pad,
                                float *dx, int Hi, int Wi, int cs_x, int cx_off, int cin, int accumulate, void *workspace,
                                size_t workspace_bytes, void *stream);
-/* Taking the operand gather off the critical path (round 5): the weights of a training step are final before its first launch, so a
- * caller may prepare every layer's MFMA operand early -- e.g. on a second stream beside the first layers -- and run the layers without
- * it.  Two flags, OR'ed into `act` of vstab_conv_forward / vstab_conv3x3_winograd and into `accumulate` of vstab_conv_dgrad:
- *   VSTAB_CONV_PACK_ONLY   gather the operand (and the padded bias vector) into the HEAD of `workspace` and return;
- *   VSTAB_CONV_PREPACKED   run the layer on the operand a PACK_ONLY call with the SAME arguments left in the SAME workspace.
- * Without either flag a call does both, as before.  Same results bit for bit. */
-#define VSTAB_CONV_PACK_ONLY 0x100
-#define VSTAB_CONV_PREPACKED 0x200
 /* PadLayer(pad) -> Conv2d(k, stride, VALID) + bias with DEVICE-resident raw weights W [k,k,cin,cout] (training: the weights
  * change every step, so the MFMA operand is gathered on the device from an index table cached per geometry).
  * act: 0 none, 1 leaky relu 0.1, 2 relu, 3 none and ADD to what is in y. */

@@ -222,32 +222,3 @@ def test_overlapped_gradient_exchange_on_one_rank():
     assert sent[0][1] == sent[1][0] and sent[1][1] == sent[2][0]
     # the middle range (conv6_1 .. conv4) carries most of the 38.7 M parameters
     assert sent[1][1] - sent[1][0] > 0.5 * tr.gbucket.flat.numel()
-
-
-def test_step_with_operands_gathered_ahead_on_a_side_stream_is_bit_identical():
-    """Trainer.step() gathers every layer's MFMA operand on a second stream at the start of the step (VSTAB_CONV_PACK_ONLY) and runs the
-    layers on the prepared operands (VSTAB_CONV_PREPACKED); the first step records the calls, the later ones replay them.  Four steps
-    with and without it: the same losses and the same parameters, Adam moments and BatchNorm statistics, bit for bit."""
-    import coupe.optical_flow_based_deep_video_stabilization_amd.train_step as ts
-    B, H, W = 2, 128, 160
-    w = wts.synthetic_weights(seed=5, cin=27, random_bn=True, flow_gain=0.3)
-    g = torch.Generator().manual_seed(9)
-    batches = [(torch.rand(B, H, W, 27, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda(), torch.rand(B, H, W, 3, generator=g).cuda())
-               for _ in range(2)]
-    runs = []
-    for prepack in (False, True):
-        tr = ts.Trainer(w, B, H, W)
-        tr.prepack = prepack
-        losses = [float(tr.step(*batches[i & 1], lr=1e-3)) for i in range(4)]
-        torch.cuda.synchronize()
-        if prepack:
-            assert tr._pp_sites is not None and len(tr._pp_sites) > 30 and tr._pp_stream is not None     # recorded once, replayed three times
-        else:
-            assert tr._pp_sites is None
-        runs.append((losses, tr.pbucket.flat.clone(), tr.mbucket.flat.clone(), tr.vbucket.flat.clone(),
-                     {k: v.clone() for k, v in tr.p.items() if "moving_" in k}))
-    assert runs[0][0] == runs[1][0]
-    for a, b in zip(runs[0][1:4], runs[1][1:4]):
-        assert torch.equal(a, b)
-    for k in runs[0][4]:
-        assert torch.equal(runs[0][4][k], runs[1][4][k]), k
