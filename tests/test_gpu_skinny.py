@@ -213,3 +213,34 @@ def test_four_phase_transposed_convolutions_on_the_weight_stream_kernel(ctx, B, 
         mag = max(1.0, float(ref[k].abs().max()))
         assert float((a[k] - b[k]).abs().max()) <= PLAN_TO_PLAN_EPS * EPS32 * mag, (k, mag)
         assert float((a[k].double().cpu() - ref[k]).abs().max()) <= 1e-3, k
+
+
+def test_workspace_layout_of_a_pinned_context_matches_what_the_forward_uses(ctx):
+    # vstab_workspace_layout_ctx / vstab_workspace_bytes_ctx describe the plan THIS context runs: under a pinned batch the plan-dependent
+    # buffers (split-K slabs, Winograd V / M: always the last three entries) may differ from the unpinned plan's, the activation offsets
+    # never do; a workspace of exactly vstab_workspace_bytes_ctx bytes is enough for the forward, one byte less is refused.
+    import ctypes
+    L = _lib.lib()
+    B, H, W = 3, 256, 256
+    ent_u, ent_p = (_lib.VstabWsEntry * 24)(), (_lib.VstabWsEntry * 24)()
+    nu = L.vstab_workspace_layout(B, H, W, 27, ent_u, 24)
+    ctx.set_plan_batch(8)
+    npn = L.vstab_workspace_layout_ctx(ctx._h, B, H, W, 27, ent_p, 24)
+    assert nu == npn == 19
+    for a, b in zip(ent_u[:nu - 3], ent_p[:npn - 3]):
+        assert (a.name, a.offset_bytes, a.h, a.w, a.c, a.c_stride) == (b.name, b.offset_bytes, b.h, b.w, b.c, b.c_stride)
+    assert [e.name for e in ent_p[npn - 3:npn]] == [b"splitk", b"winograd_in", b"winograd_out"]
+    need = L.vstab_workspace_bytes_ctx(ctx._h, B, H, W, 27)
+    last = ent_p[npn - 1]
+    assert last.offset_bytes + 4 * last.w <= need
+    feats = torch.rand(B, H, W, 27).cuda()
+    lv = vs.netspec.sizes_for(H, W).level
+    flows = [torch.empty((B, lv[k][0], lv[k][1], 2), device="cuda") for k in (6, 5, 4, 3)] + [torch.empty((B, H - 2, W - 2, 2), device="cuda")]
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    args = [ctx._h, feats.data_ptr(), B, H, W, 27] + [f.data_ptr() for f in flows]
+    assert L.vstab_flownets_forward(*args, ws.data_ptr(), need, runtime.stream_ptr()) == 0
+    assert L.vstab_flownets_forward(*args, ws.data_ptr(), need - 1, runtime.stream_ptr()) == -4        # VSTAB_E_NOMEM
+    torch.cuda.synchronize()
+    ref = vs.flownetS_pyramid(feats, B)
+    assert torch.equal(flows[4], ref["predict_flow2"])
+    ctx.set_plan_batch(0)
