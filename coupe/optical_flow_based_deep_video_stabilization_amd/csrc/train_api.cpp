@@ -134,12 +134,30 @@ const float *zero_bias()
     return p;
 }
 
+// Does a gather table read its source contiguously along the output column?  Sampled: for logical k, the entries of columns n and n + 1
+// (both live) differ by one.  Rows of the packed operand are [K-tile][Npad][32] with the 16-byte chunks of column n swizzled by (n >> 1) & 7.
+bool table_is_n_fast(const std::vector<int32_t> &tbl, int npad)
+{
+    long long hit = 0, seen = 0;
+    const size_t rows = tbl.size() / 32;
+    for (size_t r = 0; r + 1 < rows && seen < 4096; r += 7) {
+        const int n = (int)(r % npad);
+        if (n + 1 >= npad) continue;
+        for (int k = 0; k < 32; k += 5) {
+            const int32_t a = tbl[r * 32 + swz32(n, k)], b = tbl[(r + 1) * 32 + swz32(n + 1, k)];
+            if (a > 0 && b > 0) { ++seen; hit += (b == a + 1); }
+        }
+    }
+    return seen >= 16 && hit * 10 >= seen * 9;
+}
+
 struct DgradPlan {
     ConvParams p;
     ConvTile tile;
     bool vec4;
     size_t packed_floats;       // all phases
     int32_t *tbl;               // device index table, owned by the cache (NULL when `blocked`)
+    bool tbl_nfast;             // the table's sources run contiguously along the output column: the LDS-transposing replay (train_ops.hip)
     int blocked_K;              // > 0: the operand is a plain [K][N] matrix -> launch_pack_blocked instead of the table
     // odd-k stride-2 input gradients: the four output-parity phases have DIFFERENT tap counts ((k+1)/2 or (k-1)/2 per axis), so each
     // is its own launch with exactly its taps instead of one 4-phase launch padded to ceil(k/2)^2 (44 % / 31 % of the MACs of a
@@ -447,6 +465,7 @@ bool fwd_plan(int B, int Hi, int Wi, int cs_x, int cin, int k, int stride, int p
     } else {
         std::vector<int32_t> tbl(d.packed_floats);
         pack_index_conv(k, k, cin, cs_x, cout, d.p.Npad, L, tbl.data());
+        d.tbl_nfast = table_is_n_fast(tbl, d.p.Npad);
         if (hipMalloc(reinterpret_cast<void **>(&d.tbl), tbl.size() * sizeof(int32_t)) != hipSuccess) return false;
         if (hipMemcpy(d.tbl, tbl.data(), tbl.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d.tbl); return false; }
     }
@@ -487,7 +506,7 @@ extern "C" int vstab_conv_forward(const float *x, int B, int Hi, int Wi, int cs_
     float *wpk = reinterpret_cast<float *>(ws);
     float *bias = reinterpret_cast<float *>(ws + bias_off);
     if (d.blocked_K) HIP_TRY(nullptr, launch_pack_blocked(W, d.blocked_K, cout, d.p.Npad, 1, wpk, st));
-    else HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st));
+    else HIP_TRY(nullptr, launch_pack_apply(W, d.tbl, (long long)d.packed_floats, wpk, st, d.tbl_nfast));
     if (!bias_in && d.p.Npad <= 8192 && zero_bias()) bias = const_cast<float *>(zero_bias());
     else if (bias_in && cout == d.p.Npad) bias = const_cast<float *>(bias_in);
     else {

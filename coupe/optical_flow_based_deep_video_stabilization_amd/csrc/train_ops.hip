@@ -693,8 +693,42 @@ hipError_t launch_pack_blocked(const float *W, int K, int N, int Npad, int batch
     return hipGetLastError();
 }
 
-hipError_t launch_pack_apply(const float *W, const int32_t *tbl, long long n, float *wpk, hipStream_t stream)
+// The table replay for operands whose SOURCE is contiguous along the output column n (a forward convolution's HWIO filter read in tap
+// mode: conv3 ... conv6 over the concat buffers, the transposed convolutions' input gradients): pack_apply_kernel walks a packed row --
+// 32 consecutive k of one column -- and so gathers 4-byte words a whole filter row (N floats) apart.  Here a workgroup owns 64 consecutive
+// packed rows (one K-tile x 64 columns, 8 KB): the table block is read coalesced into LDS, thread (k, n) fetches W[index of (n, k)] with
+// n running fastest -- neighbouring lanes read neighbouring words -- and the block leaves as coalesced 16-byte stores.
+__global__ __launch_bounds__(256) void pack_apply_nfast_kernel(const float *__restrict__ W, const int32_t *__restrict__ tbl, long long rows,
+                                                               float *__restrict__ wpk)
 {
+    __shared__ int32_t idx[64][33];
+    __shared__ float val[64][33];
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int nr = (int)min((long long)64, rows - r0);
+    for (int e = threadIdx.x; e < nr * 32; e += 256) idx[e >> 5][e & 31] = tbl[r0 * 32 + e];
+    __syncthreads();
+    const int nl = threadIdx.x & 63;
+    if (nl < nr) {
+        const int n = (int)((r0 + nl) & 0x7fffffff);                        // only bits 1..3 of the row number enter the swizzle
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int k = (threadIdx.x >> 6) + 4 * it;
+            const int pos = ((((k >> 2) ^ ((n >> 1) & 7)) << 2) | (k & 3));
+            const int32_t t = idx[nl][pos];
+            val[nl][pos] = t ? W[t - 1] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nr * 32; e += 256) wpk[r0 * 32 + e] = val[e >> 5][e & 31];
+}
+
+hipError_t launch_pack_apply(const float *W, const int32_t *tbl, long long n, float *wpk, hipStream_t stream, bool n_fast)
+{
+    if (n_fast && (n & 31) == 0) {
+        const long long rows = n >> 5;
+        pack_apply_nfast_kernel<<<dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, stream>>>(W, tbl, rows, wpk);
+        return hipGetLastError();
+    }
     pack_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(W, tbl, n, wpk);
     return hipGetLastError();
 }

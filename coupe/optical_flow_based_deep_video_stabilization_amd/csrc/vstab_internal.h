@@ -474,7 +474,9 @@ void pack_index_dgrad_s1(int k, int cin, int cout, int cs_g, const KLayout &L, i
 void pack_index_dgrad_s2(int k, int pad, int cin, int cout, int cs_g, const KLayout &L, int npad, int32_t *tbl);   // 4 phases of ceil(k/2)^2 taps
 void pack_index_phase(int k, int cin, int cout, int cs_g, const KLayout &L, int npad, int t0y, int nty, int t0x, int ntx, int32_t *tbl);
 // wpk[i] = tbl[i] ? W[tbl[i]-1] : 0
-hipError_t launch_pack_apply(const float *W, const int32_t *tbl, long long n, float *wpk, hipStream_t stream);
+// n_fast: the table's sources are contiguous along the output column (see pack_apply_nfast_kernel); rows of the packed operand are numbered
+// (K-tile, column), so "row number mod 16" is "column mod 16" only when Npad is a multiple of 16 (it is a multiple of 32 everywhere)
+hipError_t launch_pack_apply(const float *W, const int32_t *tbl, long long n, float *wpk, hipStream_t stream, bool n_fast = false);
 // table-free packing of a plain [batch][K][N] matrix (K % 32 == 0, N % 4 == 0, Npad % 64 == 0) into [batch][K/32][Npad][32]
 hipError_t launch_pack_blocked(const float *W, int K, int N, int Npad, int batch, float *wpk, hipStream_t stream);
 
