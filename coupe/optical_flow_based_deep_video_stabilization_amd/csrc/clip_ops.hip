@@ -58,20 +58,7 @@ struct Slots9 { const unsigned char *p[9]; };
 // CONTIGUOUS in the output (27 648 bytes): the values go through LDS -- [pixel][27], an odd stride: conflict-free -- and leave as
 // 16-byte stores of the whole block; value / 255.0f comes from a 256-entry table of the same IEEE quotients.
 typedef float f32x4_clip __attribute__((ext_vector_type(4)));
-struct AssembleLds { float lut[256]; float v[256 * 27 + 4]; unsigned raw[9][192]; };       // raw: a slot's 768 bytes of this block's 256 pixels
-// a history slot's bytes of the workgroup's 256 consecutive pixels: one coalesced dword per thread (192 of them) when the slot is 4-byte
-// aligned and the block is whole, bytes otherwise; then every thread picks its own three
-__device__ __forceinline__ void assemble_stage_slot(AssembleLds &L, int j, const unsigned char *__restrict__ p, long long first, long long total)
-{
-    const unsigned char *b = p + first * 3;
-    if (first + 256 <= total && ((unsigned long long)(size_t)b & 3ull) == 0) {
-        if (threadIdx.x < 192) L.raw[j][threadIdx.x] = reinterpret_cast<const unsigned *>(b)[threadIdx.x];
-    } else {
-        unsigned char *r = reinterpret_cast<unsigned char *>(L.raw[j]);
-        const long long nb = (min((long long)256, total - first)) * 3;
-        for (int e = threadIdx.x; e < nb; e += 256) r[e] = b[e];
-    }
-}
+struct AssembleLds { float lut[256]; float v[256 * 27 + 4]; };
 __device__ __forceinline__ void assemble_store_block(AssembleLds &L, float *__restrict__ feats, long long first_px, long long total_px)
 {
     __syncthreads();
@@ -89,14 +76,11 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(Slots9 s, int B, in
     L.lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
     __syncthreads();
     const long long total = (long long)B * h * w, first = (long long)blockIdx.x * 256, idx = first + threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) assemble_stage_slot(L, j, s.p[j], first, total);
-    __syncthreads();
     if (idx < total) {
         float *o = L.v + threadIdx.x * 27;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            const unsigned char *q = reinterpret_cast<const unsigned char *>(L.raw[j]) + threadIdx.x * 3;
+            const unsigned char *q = s.p[j] + idx * 3;
             o[3 * j + 0] = L.lut[q[2]];        // cv2.cvtColor(.., COLOR_RGB2BGR) swaps channels 0 and 2
             o[3 * j + 1] = L.lut[q[1]];
             o[3 * j + 2] = L.lut[q[0]];
@@ -192,10 +176,6 @@ __global__ __launch_bounds__(256) void assemble_input_resized_kernel(Slots9 s, c
     L.lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
     __syncthreads();
     const long long total = (long long)B * h * w, first = (long long)blockIdx.x * 256, idx = first + threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        if (s.p[j] != nullptr) assemble_stage_slot(L, j, s.p[j], first, total);      // (kernel-argument pointers: uniform branches)
-    __syncthreads();
     if (idx < total) {
         const int n = (int)(idx / (h * w));
         const int rem = (int)(idx - (long long)n * h * w);
@@ -214,7 +194,7 @@ __global__ __launch_bounds__(256) void assemble_input_resized_kernel(Slots9 s, c
         float *o = L.v + threadIdx.x * 27;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            const unsigned char *q = (j < 8 && s.p[j] != nullptr) ? reinterpret_cast<const unsigned char *>(L.raw[j]) + threadIdx.x * 3 : cur;
+            const unsigned char *q = (j < 8 && s.p[j] != nullptr) ? s.p[j] + idx * 3 : cur;
             o[3 * j + 0] = L.lut[q[2]];
             o[3 * j + 1] = L.lut[q[1]];
             o[3 * j + 2] = L.lut[q[0]];
