@@ -46,6 +46,16 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def host_cpu_share():
     """Cores this process may really use: cgroup quota if one is set, else the affinity mask,
     capped at 16 (a 1-GPU box's CPU share; more threads than that only oversubscribe)."""
@@ -63,6 +73,13 @@ def host_cpu_share():
     except Exception:
         pass
     return max(1, min(n, 16))
+
+
+def newest_steady_trace():
+    """The newest committed steady-state rocprofv3 summary of the headline command (profiles/rocprof_rNN*_cfg1_steady.md, by name)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "rocprof_r*_cfg1_steady.md")))
+    return "profiles/" + os.path.basename(c[-1]) if c else "profiles/ (no steady-state trace committed)"
 
 
 def cpu_baseline(feats, frame, weights, seconds_budget=20.0):
@@ -85,11 +102,14 @@ def cpu_baseline(feats, frame, weights, seconds_budget=20.0):
         if not times:
             times = [warm]
     med = float(np.median(times))
-    return {"value": nb / med, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+    return {"value": nb / med, "unit": "frame-pairs/s", "cores": threads, "cores_box": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
+            "cores_note": "cores = threads the timed pass used (this process's CPU share: cgroup quota / affinity, capped at 16); "
+                          "cores_box = logical CPUs the host reports",
             "sample": f"{len(times)} timed passes of the first {nb} samples of the timed GPU batch ({H}x{W}x{Cin}: "
                       f"network + flow glue + warp), torch-CPU fp32 restatement of the TF graph"}, ref
 
 
+EPS32 = 1.1920929e-07
 FLOW_ERR_TOL = 1e-3          # BASELINE.json north_star: flows and warped frames within 1e-3 max-abs on fp32
 
 
@@ -120,7 +140,9 @@ def flow_error(gpu_out, feats, frame, weights, ref32=None, want_fp64=True):
         return {"max_abs": {k: float(f"{v:.3e}") for k, v in lv.items()},
                 "warped_max_abs_masked": float(f"{float(dw[mask].max()):.3e}"),
                 "warped_pixels_masked_out": int((~mask).sum()),
-                "max_abs_flow": {k: round(float(rf[k].abs().max()), 2) for k in vo.FLOW_KEYS}}
+                "max_abs_flow": {k: round(float(rf[k].abs().max()), 2) for k in vo.FLOW_KEYS},
+                # the error is a RELATIVE one: in fp32 epsilons of the level's largest flow
+                "eps_of_max_flow": {k: round(lv[k] / (EPS32 * max(float(rf[k].abs().max()), 1e-30)), 2) for k in vo.FLOW_KEYS}}
 
     with torch.no_grad():
         if ref32 is None:
@@ -130,11 +152,13 @@ def flow_error(gpu_out, feats, frame, weights, ref32=None, want_fp64=True):
     worst = max(list(r32["max_abs"].values()) + [r32["warped_max_abs_masked"]])
     res = {"max_abs": r32["max_abs"], "warped_max_abs_masked": r32["warped_max_abs_masked"],
            "warped_pixels_masked_out": r32["warped_pixels_masked_out"], "max_abs_flow": r32["max_abs_flow"],
+           "eps_of_max_flow": r32["eps_of_max_flow"],
            "vs": "torch-CPU fp32 restatement of the TF graph on the same inputs (parity unpinned: TensorFlow 1.10 cannot run here)",
            "samples": nb, "of_step": "last timed step", "tol": FLOW_ERR_TOL, "worst": worst, "within_tol": bool(worst <= FLOW_ERR_TOL)}
     if r64 is not None:
         w64 = max(list(r64["max_abs"].values()) + [r64["warped_max_abs_masked"]])
         res["vs_fp64"] = {"max_abs": r64["max_abs"], "warped_max_abs_masked": r64["warped_max_abs_masked"], "worst": w64,
+                          "eps_of_max_flow": r64["eps_of_max_flow"],
                           "within_tol": bool(w64 <= FLOW_ERR_TOL), "vs": "the same restatement in fp64 (the parity tests' arbiter)"}
     return res
 
@@ -494,7 +518,7 @@ def main():
                             "what is left is prologue + epilogue that the workgroups of a launch run in lockstep.  Launches are grouped by kernel instantiation as "
                             "rocprofv3 names them: since round 4 a refinement level's transposed convolution shares its launch with the level's tap-table GEMM "
                             "(conv_dual_kernel: its own group; the events bracket both, the flops counted are the transposed convolution's), so this group is the "
-                            "plain conv_mfma_kernel launches (conv2 ... conv6 at B=8 512x512); profiles/rocprof_r04z_steady.md is the steady-state rocprofv3 "
+                            "plain conv_mfma_kernel launches (conv2 ... conv6 at B=8 512x512); " + newest_steady_trace() + " is the steady-state rocprofv3 "
                             "trace of the same command, whose average for this kernel agrees with avg_launch_us",
                     "achieved_direct": round(d_dfl / (d_ms * 1e-3) / 1e12, 2),
                     "frac_direct": round(d_dfl / (d_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
@@ -515,7 +539,7 @@ def main():
         name = max(hp, key=lambda k: hp[k][0])
         ms_sum, nl, by = hp[name]
         if nl > 0 and ms_sum > 0:
-            kernels = {"pf2_glue_warp": "pf2_glue_warp_kernel<true, " + ("true" if W % 4 == 0 else "false") + ">",
+            kernels = {"pf2_glue_warp": "pf2_glue_warp_kernel<true, " + ("true" if W % 4 == 0 else "false") + ", false>",      # <WRITE_FLOW, STAGE, U8>
                        "flow_glue_warp": "warp3_tile_kernel<true, true, 4, 16, 32, 2, true, false, " + ("true" if W % 4 == 0 else "false") + ">",
                        "warp_flow": "warp3_tile_kernel<false, false, ...>", "flow_resize_scale": "flow_resize_scale_kernel"}
             gbs = by / (ms_sum * 1e-3) / 1e9

@@ -23,6 +23,12 @@ STAB_LAGS = (31, 23, 15, 7, 4, 3, 2, 1)          # stabidxs, main:553
 RING = 32
 
 
+def _overlaps(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """do the storages' byte ranges of two dense tensors intersect?"""
+    a0, b0 = a.data_ptr(), b.data_ptr()
+    return a0 < b0 + b.numel() * b.element_size() and b0 < a0 + a.numel() * a.element_size()
+
+
 def _u8(t, name):
     if not torch.is_tensor(t) or not t.is_cuda or t.dtype != torch.uint8 or t.dim() != 4 or t.shape[3] != 3:
         raise ValueError(f"{name} must be a uint8 CUDA tensor [n,H,W,3]")
@@ -124,6 +130,9 @@ class ClipStabiliser:
         if out is not None and (self.flow_filter is not None or out.dtype != torch.uint8 or tuple(out.shape) != tuple(f.shape)
                                 or not out.is_contiguous() or out.device != f.device):
             raise ValueError("out must be a contiguous uint8 tensor of the frame's shape on its device (and no flow_filter)")
+        if out is not None and (_overlaps(out, f) or _overlaps(out, self.ring)):
+            # the warp gathers frame pixels while other workgroups already write `out`, and the history slot is resized from `out`
+            raise ValueError("out must not overlap the input frame or the history ring")
         L = _lib.lib()
         i = self.i
         if self.flow_filter is None:

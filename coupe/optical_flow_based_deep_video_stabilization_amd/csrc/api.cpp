@@ -20,8 +20,14 @@ int fail(vstab_ctx *ctx, int code, const char *fmt, ...)
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_last_error = buf;
-    if (ctx) ctx->err = buf;
+    if (ctx) { std::lock_guard<std::mutex> g(ctx->err_mu); ctx->err = buf; }
     return code;
+}
+
+// a context-less callee failed: its message becomes the context's
+static void adopt_last_error(vstab_ctx *ctx)
+{
+    if (ctx) { std::lock_guard<std::mutex> g(ctx->err_mu); ctx->err = g_last_error; }
 }
 
 // ------------------------------------------------------------------------- roctx ranges
@@ -340,7 +346,8 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl, const PlanPin *pin = null
         pl.bytes[b] = (size_t)n * 4;
     }
     // ticket words of the in-launch split-K reductions (conv_skinny.hip): per WORKSPACE, so forwards on one context that use distinct
-    // workspaces never share them; zeroed by a memset node at the start of every forward that has such a layer
+    // workspaces never share them; zeroed at the start of every forward that has such a layer -- by the first layer's own launch
+    // (conv_rowwin's first workgroup), or by a memset node when that layer runs on another kernel
     pl.bytes[B_TICKETS] = SKINNY_MAX_TILES * sizeof(unsigned);
 
     // ---- encoder convs
@@ -824,7 +831,8 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
 struct FusedTail { const float *frame; float *outflow; float *warped; int oh, ow; bool fused; const uint8_t *frame8; uint8_t *out8; };      // fp32 frames, or the clip driver's 8-bit ones (frame8 / out8)
 static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5,
                          float *pf4, float *pf3, float *pf2, void *workspace, size_t workspace_bytes, void *stream_, FusedTail *tail);
-static std::string conv_kernel_name(ConvTile t, bool vec4);
+static const char *conv_kernel_name(ConvTile t, bool vec4);
+static const char *dual_kernel_name(ConvTile t);
 static int forward_impl(vstab_ctx *ctx, const float *feats, int B, int H, int W, int Cin, float *pf6, float *pf5, float *pf4, float *pf3,
                         float *pf2, void *workspace, size_t workspace_bytes, void *stream_, FusedTail *tail);
 
@@ -924,6 +932,8 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
             ctx->prof_flops_direct[i] += 2.0 * dmac;
         }
     }
+    // (the context is written only while profiling: plain forwards on one context may be issued from several host threads)
+#define PROF_NAME(slot, name) do { if (ev) ctx->prof_kernel[slot] = (name); } while (0)
 #define EV_A(slot) (ev ? ev[2 * (slot)] : nullptr)
 #define EV_B(slot) (ev ? ev[2 * (slot) + 1] : nullptr)
 
@@ -960,13 +970,13 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
                     if (rowwin_applicable(t)) {
                         HIP_TRY(ctx, launch_conv_rowwin(r, stream, EV_A(0), nullptr));
                         HIP_TRY(ctx, launch_conv_rowwin(t, stream, nullptr, EV_B(0)));
-                        ctx->prof_kernel[0] = "conv_rowwin_kernel<7, 2> + <4, 1> tail";
+                        PROF_NAME(0, "conv_rowwin_kernel<7, 2> + <4, 1> tail");
                         continue;
                     }
                     r.ntile_x = 0;
                 }
                 HIP_TRY(ctx, launch_conv_rowwin(r, stream, EV_A(0), EV_B(0)));
-                ctx->prof_kernel[0] = r.MB == 2 ? "conv_rowwin_kernel<7, 2>" : "conv_rowwin_kernel<4, 1>";
+                PROF_NAME(0, r.MB == 2 ? "conv_rowwin_kernel<7, 2>" : "conv_rowwin_kernel<4, 1>");
                 continue;
             }
         }
@@ -981,10 +991,10 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
             const int P_i = wino_gemm_stream_positions(B, T_i, cin_i, ENC[i].cout);
             if (P_i > 0) {       // streams of positions (wino_gemm_stream.hip): B=8 512x512 conv3_1 (8 positions per workgroup), conv4_1 (4)
                 HIP_TRY(ctx, launch_wino_gemm_stream(q.in, q.wpk, q.out, B, T_i, cin_i, ENC[i].cout, P_i, stream, EV_A(i), EV_B(i)));
-                ctx->prof_kernel[i] = "wino_gemm_stream_kernel";
+                PROF_NAME(i, "wino_gemm_stream_kernel");
             } else {
                 HIP_TRY(ctx, launch_conv(q, pl.wtile[i], true, stream, EV_A(i), EV_B(i)));
-                ctx->prof_kernel[i] = conv_kernel_name(pl.wtile[i], true);
+                PROF_NAME(i, conv_kernel_name(pl.wtile[i], true));
             }
             HIP_TRY(ctx, launch_wino_output(buf(B_WINO_M), B, pl.eh[i], pl.ew[i], ENC[i].cout, dw + ctx->enc_b[i], 1, buf(ENC_IO[i].out_buf),
                                             ENC_IO[i].cs_out, 0, stream));
@@ -997,11 +1007,11 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         p.partial = buf(B_PARTIAL);
         if (pl.skinny[i]) {
             HIP_TRY(ctx, launch_conv_skinny(p, tickets, stream, EV_A(i), EV_B(i)));
-            ctx->prof_kernel[i] = "conv_skinny_kernel<1, 4>";
+            PROF_NAME(i, "conv_skinny_kernel<1, 4>");
             continue;
         }
         HIP_TRY(ctx, launch_conv(p, pl.tile[i], pl.vec4[i], stream, EV_A(i), EV_B(i)));
-        ctx->prof_kernel[i] = conv_kernel_name(pl.tile[i], pl.vec4[i]);
+        PROF_NAME(i, conv_kernel_name(pl.tile[i], pl.vec4[i]));
     }
     // decoder (model.py:847-880)
     float *pfs[5] = {pf6, pf5, pf4, pf3, pf2};
@@ -1033,10 +1043,10 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
                 if (e == hipErrorNotSupported) {        // a tile shape the two-problem kernel is not built for: one launch each, the combine still rides with predict_up
                     HIP_TRY(ctx, launch_conv(pt, pl.tile[15 + l], true, stream, nullptr, nullptr, false));
                     HIP_TRY(ctx, launch_conv(pd, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l), false));
-                    ctx->prof_kernel[10 + l] = conv_kernel_name(pl.tile[10 + l], true);
+                    PROF_NAME(10 + l, conv_kernel_name(pl.tile[10 + l], true));
                 } else {
                     HIP_TRY(ctx, e);
-                    ctx->prof_kernel[10 + l] = "conv_dual_kernel: " + conv_kernel_name(pl.tile[10 + l], true) + " + <128, 32> tap table";
+                    PROF_NAME(10 + l, dual_kernel_name(pl.tile[10 + l]));
                 }
             }
             TraceRange r3(HEAD_RANGE[l]);
@@ -1053,10 +1063,10 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         TraceRange layer_range(DEC_RANGE[l]);
         if (pl.skinny[10 + l]) {
             HIP_TRY(ctx, launch_conv_skinny(pd, tickets, stream, EV_A(10 + l), EV_B(10 + l)));
-            ctx->prof_kernel[10 + l] = "conv_skinny_kernel<1, 4>";
+            PROF_NAME(10 + l, "conv_skinny_kernel<1, 4>");
         } else {
             HIP_TRY(ctx, launch_conv(pd, pl.tile[10 + l], true, stream, EV_A(10 + l), EV_B(10 + l)));
-            ctx->prof_kernel[10 + l] = conv_kernel_name(pl.tile[10 + l], true);
+            PROF_NAME(10 + l, conv_kernel_name(pl.tile[10 + l], true));
         }
     }
     // full-resolution head (model.py:882-887)
@@ -1067,7 +1077,7 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         const long long M2 = (long long)B * pl.eh[1] * pl.ew[1];
         if (!tap_panel_applicable(M2, p.Cs_in, p.in, p.out)) return fail(ctx, VSTAB_E_SHAPE, "predict_flow2 tap table: unsupported geometry");
         HIP_TRY(ctx, launch_tap_panel(p.in, M2, dw + ctx->tab_wp, p.out, stream, EV_A(14), EV_B(14)));
-        ctx->prof_kernel[14] = "tap_panel_kernel";
+        PROF_NAME(14, "tap_panel_kernel");
         hipError_t te = hipErrorNotSupported;
         if (tail && !(pin.flags & VSTAB_PLAN_NO_TAIL)) {       // gather + glue + warp of this chunk's frames in one launch, when the geometry allows
             TraceRange tail_range("predict_flow2 gather+flow_glue+tf_warp");
@@ -1084,22 +1094,49 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
     }
 #undef EV_A
 #undef EV_B
+#undef PROF_NAME
     if (ev) ctx->prof_forwards++;
     return VSTAB_OK;
 }
 
-static std::string conv_kernel_name(ConvTile t, bool vec4)
+// (string literals: the profiler's name slots are plain pointers, nothing a forward does allocates)
+static const char *conv_kernel_name(ConvTile t, bool vec4)
 {
-    const char *shape = t == TILE_128x128 ? "128, 128, 2, 2" : (t == TILE_128x64 ? "128, 64, 2, 2" : (t == TILE_64x128 ? "64, 128, 1, 4" : (t == TILE_64x64 ? "64, 64, 2, 2" : (t == TILE_256x32 ? "256, 32, 4, 1" : "128, 32, 4, 1"))));
     const bool dma = conv_uses_lds_dma(t, vec4);
-    return std::string("conv_mfma_kernel<") + shape + (vec4 ? ", true" : ", false") + (dma ? ", true>" : ", false>");
+#define VSTAB_KN(shape) (vec4 ? (dma ? "conv_mfma_kernel<" shape ", true, true>" : "conv_mfma_kernel<" shape ", true, false>") \
+                              : (dma ? "conv_mfma_kernel<" shape ", false, true>" : "conv_mfma_kernel<" shape ", false, false>"))
+    switch (t) {
+    case TILE_128x128: return VSTAB_KN("128, 128, 2, 2");
+    case TILE_128x64: return VSTAB_KN("128, 64, 2, 2");
+    case TILE_64x128: return VSTAB_KN("64, 128, 1, 4");
+    case TILE_64x64: return VSTAB_KN("64, 64, 2, 2");
+    case TILE_256x32: return VSTAB_KN("256, 32, 4, 1");
+    default: return VSTAB_KN("128, 32, 4, 1");
+    }
+#undef VSTAB_KN
+}
+
+static const char *dual_kernel_name(ConvTile t)
+{
+    const bool dma = conv_uses_lds_dma(t, true);
+#define VSTAB_DN(shape) (dma ? "conv_dual_kernel: conv_mfma_kernel<" shape ", true, true> + <128, 32> tap table" \
+                             : "conv_dual_kernel: conv_mfma_kernel<" shape ", true, false> + <128, 32> tap table")
+    switch (t) {
+    case TILE_128x128: return VSTAB_DN("128, 128, 2, 2");
+    case TILE_128x64: return VSTAB_DN("128, 64, 2, 2");
+    case TILE_64x128: return VSTAB_DN("64, 128, 1, 4");
+    case TILE_64x64: return VSTAB_DN("64, 64, 2, 2");
+    case TILE_256x32: return VSTAB_DN("256, 32, 4, 1");
+    default: return VSTAB_DN("128, 32, 4, 1");
+    }
+#undef VSTAB_DN
 }
 
 // ------------------------------------------------------------------------- profiling
 extern "C" int vstab_profile_kernel_name(vstab_ctx *ctx, int slot, char *buf, int cap)
 {
     if (!ctx || !buf || cap < 1 || slot < 0 || slot > 14) return fail(ctx, VSTAB_E_STATE, "profile_kernel_name: bad argument");
-    std::snprintf(buf, (size_t)cap, "%s", ctx->prof_kernel[slot].c_str());
+    std::snprintf(buf, (size_t)cap, "%s", ctx->prof_kernel[slot] ? ctx->prof_kernel[slot] : "");
     return VSTAB_OK;
 }
 
@@ -1219,7 +1256,7 @@ extern "C" int vstab_stabilise_originalsize(vstab_ctx *ctx, const float *feats, 
     if (rc != VSTAB_OK) return rc;
     if (tail.fused) return VSTAB_OK;
     const int rc2 = vstab_flow_glue_warp(pf2, B, H - 2, W - 2, frame, outflow, warped, oh, ow, 3, H, W, stream);
-    if (rc2 != VSTAB_OK && ctx) ctx->err = g_last_error;
+    if (rc2 != VSTAB_OK) adopt_last_error(ctx);
     return rc2;
 }
 
@@ -1592,16 +1629,26 @@ extern "C" int vstab_clip_step(vstab_ctx *ctx, const uint8_t *const *slots8, con
     if (!ctx) return fail(nullptr, VSTAB_E_STATE, "clip_step: ctx is NULL");
     if (!slots8 || !frame || !feats || !out || !ring_slot) return fail(ctx, VSTAB_E_STATE, "clip_step: NULL buffer");
     if (n < 1 || net_h < 3 || net_w < 4 || oh < 1 || ow < 1) return fail(ctx, VSTAB_E_SHAPE, "clip_step: bad shape");
+    {   // the warp GATHERS frame pixels while other workgroups already write `out`, and the history slot is resized from `out`:
+        // neither may overlap the frame, nor each other
+        const size_t fb = (size_t)n * oh * ow * 3, sb = (size_t)n * net_h * net_w * 3;
+        auto overlap = [](const void *a, size_t na, const void *b, size_t nb) {
+            const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+            return x < y + nb && y < x + na;
+        };
+        if (overlap(out, fb, frame, fb) || overlap(ring_slot, sb, frame, fb) || overlap(ring_slot, sb, out, fb))
+            return fail(ctx, VSTAB_E_STATE, "clip_step: out / ring_slot / frame must not overlap");
+    }
     int rc = vstab_assemble_input_resized(slots8, frame, n, net_h, net_w, oh, ow, feats, stream);
     // the network; its last launch also does the 8-bit glue + warp of the frame when the geometry allows (flow_ops.hip, pf2_glue_warp_kernel)
     FusedTail tail{nullptr, outflow, nullptr, oh, ow, false, frame, out};
     const bool try_fused = (((uintptr_t)outflow & 7) | ((uintptr_t)out & 3)) == 0 && (long long)n * oh * ow < (1ll << 31) / 3;
     if (rc == VSTAB_OK) rc = forward_impl(ctx, feats, n, net_h, net_w, 27, pf6, pf5, pf4, pf3, pf2, workspace, workspace_bytes, stream, try_fused ? &tail : nullptr);
-    else ctx->err = g_last_error;
+    else adopt_last_error(ctx);
     if (rc != VSTAB_OK) return rc;
     if (!tail.fused) rc = vstab_flow_glue_warp_u8(pf2, n, net_h - 2, net_w - 2, frame, outflow, out, oh, ow, net_h, net_w, stream);
     if (rc == VSTAB_OK) rc = vstab_resize_u8(out, n, oh, ow, ring_slot, net_h, net_w, stream);
-    if (rc != VSTAB_OK) ctx->err = g_last_error;
+    if (rc != VSTAB_OK) adopt_last_error(ctx);
     return rc;
 }
 

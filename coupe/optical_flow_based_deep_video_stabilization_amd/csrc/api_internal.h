@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <initializer_list>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -15,7 +16,8 @@ struct vstab_ctx {
     int device = 0;
     bool loaded = false;
     int cin = 0;
-    std::string err;
+    std::string err;                     // last failure message; written under err_mu (failure paths only)
+    std::mutex err_mu;
     float *dev_weights = nullptr;        // one allocation holding every packed tensor
     size_t dev_weight_floats = 0;
     // float offsets into dev_weights
@@ -35,7 +37,7 @@ struct vstab_ctx {
     int prof_forwards = 0;
     double prof_flops[15] = {0};         // flops the launches ISSUE (Winograd-form stages: 4/9 of the direct convolution)
     double prof_flops_direct[15] = {0};  // the same layers counted as direct convolutions
-    std::string prof_kernel[15];         // kernel instantiation each slot launched last
+    const char *prof_kernel[15] = {nullptr};   // kernel instantiation each slot launched last (string literals; written only while profiling)
     // VGG16 trunk (vstab_vgg16_*)
     void *nldf = nullptr;                // NLDF head state (nldf_api.cpp)
     bool vgg_loaded = false;

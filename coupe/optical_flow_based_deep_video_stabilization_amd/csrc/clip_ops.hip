@@ -9,15 +9,20 @@ namespace vstab {
 // un-vendored dependency of the reference and is not installed here, so this restates its published 8u
 // path (imgproc/resize.cpp: half-pixel centres, 11-bit fixed-point coefficients, HResizeLinear then
 // VResizeLinear<uchar,int,short>):
-//   fx = (dx+0.5)*sw/dw - 0.5; sx = floor(fx); fx -= sx; sx<0 -> (0, fx=0); sx>=sw-1 -> (sw-1, fx=0)
+//   scale_x = 1. / ((double)dw / sw)   (cv::resize: inv_scale_x = (double)dsize.width / ssize.width; hal::resize: scale_x = 1./inv_scale_x)
+//   fx = (float)((dx+0.5)*scale_x - 0.5)  [the product and difference in double]; sx = floor(fx); fx -= sx;
+//   sx<0 -> (0, fx=0); sx>=sw-1 -> (sw-1, fx=0)
 //   a = {sat16(round((1-fx)*2048)), sat16(round(fx*2048))};   row value  R = S[sx]*a0 + S[sx+1]*a1
 //   dst = ( ((b0*(R0>>4))>>16) + ((b1*(R1>>4))>>16) + 2 ) >> 2
-// UNVERIFIED against cv2 (documented in DESIGN.md); the oracle restates the same arithmetic.
+// (exact x2 reductions, which cv2 routes to INTER_AREA, give the same bytes: both coefficients are 1024 and the formula collapses to
+// (a+b+c+d+2)>>2).  cv2 itself cannot run here; what pins this restatement: hand-derived known answers of the formula above and an
+// independent float bilinear at half-pixel centres (scipy.ndimage) within 1 LSB -- tests/test_oracle_kat.py, tests/test_gpu_clip.py.
+// Builds of cv2 that dispatch 8-bit linear resizing to a vendor library (IPP) may differ from the generic path by 1 LSB.
 struct Tap { int i0, i1; int a0, a1; };
-__device__ __forceinline__ Tap cv_tap(int d, int dn, int sn)
+static inline double cv_scale(int dn, int sn) { return 1.0 / ((double)dn / (double)sn); }     // host side: one division pair per launch
+__device__ __forceinline__ Tap cv_tap(int d, double scale, int sn)
 {
-    const float scale = (float)((double)sn / (double)dn);
-    float f = (float)(((double)d + 0.5) * (double)scale - 0.5);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     f -= (float)s;
     if (s < 0) { f = 0.f; s = 0; }
@@ -31,14 +36,14 @@ __device__ __forceinline__ Tap cv_tap(int d, int dn, int sn)
 
 // src u8 [B,sh,sw,3] -> dst u8 [B,dh,dw,3]
 __global__ __launch_bounds__(256) void resize_u8_kernel(const unsigned char *__restrict__ src, int B, int sh, int sw,
-                                                        unsigned char *__restrict__ dst, int dh, int dw)
+                                                        unsigned char *__restrict__ dst, int dh, int dw, double scale_x, double scale_y)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)B * dh * dw) return;
     const int n = (int)(idx / (dh * dw));
     const int rem = (int)(idx - (long long)n * dh * dw);
     const int dy = rem / dw, dx = rem - dy * dw;
-    const Tap X = cv_tap(dx, dw, sw), Y = cv_tap(dy, dh, sh);
+    const Tap X = cv_tap(dx, scale_x, sw), Y = cv_tap(dy, scale_y, sh);
     const unsigned char *b = src + (long long)n * sh * sw * 3;
     const unsigned char *r0 = b + (long long)Y.i0 * sw * 3, *r1 = b + (long long)Y.i1 * sw * 3;
 #pragma unroll
@@ -120,18 +125,18 @@ __global__ __launch_bounds__(256) void quantise_output_kernel(const float *__res
 // history as  totaloutputFrame[i] = cv2.cvtColor(cv2.resize(warped, (512, 384)) * 255, COLOR_RGB2BGR)  (main:861) and reads it back
 // through np.uint8 (main:849, 863): cv2.resize on a float32 image is the same half-pixel-centre bilinear as the 8-bit path with float
 // coefficients (HResizeLinear: S[x0]*a0 + S[x1]*a1, then VResizeLinear: b0*R0 + b1*R1), then * 255, channels swapped, truncated.
-// UNVERIFIED against cv2 like resize_u8_kernel; the oracle restates the same arithmetic.  src f32 [B,sh,sw,3] -> dst u8 [B,dh,dw,3].
+// Pinned like resize_u8_kernel (known answers + an independent float bilinear), not against cv2 itself; the oracle restates the same
+// arithmetic.  src f32 [B,sh,sw,3] -> dst u8 [B,dh,dw,3].
 __global__ __launch_bounds__(256) void resize_f32_to_u8_kernel(const float *__restrict__ src, int B, int sh, int sw,
-                                                               unsigned char *__restrict__ dst, int dh, int dw)
+                                                               unsigned char *__restrict__ dst, int dh, int dw, double scale_x, double scale_y)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)B * dh * dw) return;
     const int n = (int)(idx / (dh * dw));
     const int rem = (int)(idx - (long long)n * dh * dw);
     const int dy = rem / dw, dx = rem - dy * dw;
-    auto tap = [](int d, int dn, int sn, int &i0, int &i1, float &a0, float &a1) {
-        const float scale = (float)((double)sn / (double)dn);
-        float f = (float)(((double)d + 0.5) * (double)scale - 0.5);
+    auto tap = [](int d, double scale, int sn, int &i0, int &i1, float &a0, float &a1) {
+        float f = (float)(((double)d + 0.5) * scale - 0.5);
         int s = (int)floorf(f);
         f -= (float)s;
         if (s < 0) { f = 0.f; s = 0; }
@@ -140,8 +145,8 @@ __global__ __launch_bounds__(256) void resize_f32_to_u8_kernel(const float *__re
     };
     int x0, x1, y0, y1;
     float ax0, ax1, ay0, ay1;
-    tap(dx, dw, sw, x0, x1, ax0, ax1);
-    tap(dy, dh, sh, y0, y1, ay0, ay1);
+    tap(dx, scale_x, sw, x0, x1, ax0, ax1);
+    tap(dy, scale_y, sh, y0, y1, ay0, ay1);
     const float *b = src + (long long)n * sh * sw * 3;
     const float *r0 = b + (long long)y0 * sw * 3, *r1 = b + (long long)y1 * sw * 3;
 #pragma unroll
@@ -156,21 +161,21 @@ __global__ __launch_bounds__(256) void resize_f32_to_u8_kernel(const float *__re
 hipError_t launch_resize_f32_to_u8(const float *src, int B, int sh, int sw, unsigned char *dst, int dh, int dw, hipStream_t stream)
 {
     const long long total = (long long)B * dh * dw;
-    resize_f32_to_u8_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(src, B, sh, sw, dst, dh, dw);
+    resize_f32_to_u8_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(src, B, sh, sw, dst, dh, dw, cv_scale(dw, sw), cv_scale(dh, sh));
     return hipGetLastError();
 }
 
 hipError_t launch_resize_u8(const unsigned char *src, int B, int sh, int sw, unsigned char *dst, int dh, int dw, hipStream_t stream)
 {
     const long long total = (long long)B * dh * dw;
-    resize_u8_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(src, B, sh, sw, dst, dh, dw);
+    resize_u8_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(src, B, sh, sw, dst, dh, dw, cv_scale(dw, sw), cv_scale(dh, sh));
     return hipGetLastError();
 }
 
 // assemble_input with the current frame's cv2.resize inside (main:550 + 553-558 in one launch): slot 8 (and every history slot whose
 // pointer is null: the first frame of a clip, main:548-549) is resize_u8_kernel's pixel computed here from the full-resolution frame
 __global__ __launch_bounds__(256) void assemble_input_resized_kernel(Slots9 s, const unsigned char *__restrict__ frame, int B, int h, int w, int sh,
-                                                                     int sw, float *__restrict__ feats)
+                                                                     int sw, float *__restrict__ feats, double scale_x, double scale_y)
 {
     __shared__ __attribute__((aligned(16))) AssembleLds L;
     L.lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256) void assemble_input_resized_kernel(Slots9 s, c
         const int n = (int)(idx / (h * w));
         const int rem = (int)(idx - (long long)n * h * w);
         const int dy = rem / w, dx = rem - dy * w;
-        const Tap X = cv_tap(dx, w, sw), Y = cv_tap(dy, h, sh);
+        const Tap X = cv_tap(dx, scale_x, sw), Y = cv_tap(dy, scale_y, sh);
         const unsigned char *b = frame + (long long)n * sh * sw * 3;
         const unsigned char *r0 = b + (long long)Y.i0 * sw * 3, *r1 = b + (long long)Y.i1 * sw * 3;
         unsigned char cur[3];
@@ -210,7 +215,8 @@ hipError_t launch_assemble_input_resized(const unsigned char *const *slots8, con
     for (int j = 0; j < 8; ++j) s.p[j] = slots8[j];
     s.p[8] = nullptr;
     const long long total = (long long)B * h * w;
-    assemble_input_resized_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(s, frame, B, h, w, sh, sw, feats);
+    assemble_input_resized_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(s, frame, B, h, w, sh, sw, feats, cv_scale(w, sw),
+                                                                                                cv_scale(h, sh));
     return hipGetLastError();
 }
 

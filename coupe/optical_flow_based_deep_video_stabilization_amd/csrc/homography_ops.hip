@@ -307,7 +307,8 @@ size_t homography_workspace_bytes(int B, int H, int W, int K)
 // cv2.warpPerspective(src, M, (ow, oh)) with the default flags (INTER_LINEAR, BORDER_CONSTANT 0, M maps src -> dst
 // so the sampler uses M^-1; main:736) on 8-bit frames.  Restated from OpenCV's published behaviour
 // (imgproc/imgwarp.cpp: source coordinates rounded to 1/32 px -- INTER_BITS = 5 -- and a 15-bit fixed-point bilinear
-// blend); cv2 is not installed here, so this is UNVERIFIED against the library (the oracle restates the same arithmetic):
+// blend); cv2 is not installed here: pinned by hand-derived known answers and an exact float bilinear at the 1/32-pixel coordinates
+// (tests/test_oracle_kat.py, tests/test_gpu_postfilters.py), not against the library itself (the oracle restates the same arithmetic):
 //   X = rint(32 * X0 / W0), sx = X >> 5, a = X & 31 (same for Y);   w = {(32-a)(32-b), a(32-b), (32-a)b, ab} * 32
 //   dst = (sum w_i * src_i + 2^14) >> 15,  taps outside the image read 0.
 __global__ __launch_bounds__(256) void warp_perspective_u8_kernel(const unsigned char *__restrict__ src, int B, int sh, int sw,

@@ -694,7 +694,8 @@ hipError_t launch_pack_blocked(const float *W, int K, int N, int Npad, int batch
 }
 
 // The table replay for operands whose SOURCE is contiguous along the output column n (a forward convolution's HWIO filter read in tap
-// mode: conv3 ... conv6 over the concat buffers, the transposed convolutions' input gradients): pack_apply_kernel walks a packed row --
+// mode: conv3 ... conv6 over the concat buffers -- whatever table table_is_n_fast() accepts in train_api.cpp's forward plans; the
+// input-gradient plans build their operands with their own kernels): pack_apply_kernel walks a packed row --
 // 32 consecutive k of one column -- and so gathers 4-byte words a whole filter row (N floats) apart.  Here a workgroup owns 64 consecutive
 // packed rows (one K-tile x 64 columns, 8 KB): the table block is read coalesced into LDS, thread (k, n) fetches W[index of (n, k)] with
 // n running fastest -- neighbouring lanes read neighbouring words -- and the block leaves as coalesced 16-byte stores.

@@ -22,9 +22,13 @@
  *     vstab_last_error() gives the message for the last failure on that context
  *     (or the last context-less failure when ctx == NULL);
  *   - one context per device; forwards on one context may overlap in time (different
- *     streams) when each uses its OWN workspace: they only read the context.  Calls that
- *     write the context (vstab_load_weights, vstab_set_plan_batch, the DIAGNOSTIC section
- *     at the end of this header) must not overlap with anything on that context;
+ *     streams, also issued from different host threads) when each uses its OWN workspace:
+ *     a successful forward only reads the context (a failing one writes its message under a
+ *     lock; with two threads failing at once vstab_last_error(ctx) is either message, and
+ *     vstab_last_error(NULL) is always the calling thread's own).  Calls that write the
+ *     context (vstab_load_weights, vstab_set_plan_batch, the DIAGNOSTIC section at the end
+ *     of this header -- vstab_profile_enable(ctx, 1) makes every forward write its event
+ *     and name slots) must not overlap with anything on that context;
  *   - product surface first; everything under "DIAGNOSTIC AND TEST SURFACE" at the end
  *     (plan flags, per-launch profilers, roctx ranges, self-tests, host-only views of the
  *     launch plan) exists for measurements and tests, is process- or context-global state,
@@ -245,7 +249,8 @@ VSTAB_API int vstab_flow_glue_warp_u8(const float *flow, int B, int h, int w, co
  * vstab_flow_glue_warp_u8(pf2, frame) -> out u8 [n,oh,ow,3] (and outflow [n,oh,ow,2] unless NULL); vstab_resize_u8(out) -> ring_slot
  * u8 [n,net_h,net_w,3], the slot later frames read this one back from.  slots8: HOST array of 8 device pointers (lags 31,23,15,7,4,3,2,1;
  * NULL = the resized current frame).  Every buffer is the caller's, allocated once; identical bytes to the four calls.  The network
- * takes 27 input channels (8 history frames + the current one). */
+ * takes 27 input channels (8 history frames + the current one).  `out`, `ring_slot` and `frame` must not overlap (the warp gathers
+ * frame pixels while `out` is being written): VSTAB_E_STATE otherwise. */
 VSTAB_API int vstab_clip_step(vstab_ctx *ctx, const uint8_t *const *slots8, const uint8_t *frame, int n, int net_h, int net_w, int oh, int ow,
                               float *feats, float *pf6, float *pf5, float *pf4, float *pf3, float *pf2, float *outflow, uint8_t *out,
                               uint8_t *ring_slot, void *workspace, size_t workspace_bytes, void *stream);

@@ -543,12 +543,14 @@ def nldf_build_model(x, vgg_dict, hw, dtype=torch.float64):
 def cv_resize_u8(src: np.ndarray, dh: int, dw: int) -> np.ndarray:
     """cv2.resize(src, (dw, dh)) INTER_LINEAR for uint8 HxWxC, restating OpenCV's 8-bit path (imgproc/resize.cpp:
     half-pixel centres, 11-bit coefficients, HResizeLinear + VResizeLinear<uchar,int,short>).  cv2 is not
-    installed here: UNVERIFIED against the real library; the HIP kernel restates the same arithmetic."""
+    installed here; the restatement is pinned by hand-derived known answers of the published fixed-point formula and by an
+    independent float bilinear at half-pixel centres (scipy.ndimage) within 1 LSB (tests/test_oracle_kat.py).  What stays
+    unverifiable offline: cv2 builds that dispatch 8-bit linear resizing to a vendor library (IPP) may differ by 1 LSB."""
     sh, sw = src.shape[:2]
 
     def taps(dn, sn):
-        scale = np.float32(np.float64(sn) / np.float64(dn))
-        f = ((np.arange(dn, dtype=np.float64) + 0.5) * np.float64(scale) - 0.5).astype(np.float32)
+        scale = np.float64(1.0) / (np.float64(dn) / np.float64(sn))        # cv::resize: inv_scale = (double)dsize / ssize; hal::resize: scale = 1. / inv_scale
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)     # fx = (float)((dx+0.5)*scale_x - 0.5)
         s = np.floor(f).astype(np.int64)
         f = (f - s.astype(np.float32)).astype(np.float32)
         lo = s < 0
@@ -650,7 +652,8 @@ def homography_fit(flow, K=256, seed=0, thresh=3.0, refine=2, stride=1, sample_i
 def cv_warp_perspective_u8(src, M, oh, ow):
     """cv2.warpPerspective(src, M, (ow, oh)) on uint8 HxWxC (main:736): default INTER_LINEAR / BORDER_CONSTANT 0, M maps
     src -> dst.  Restates OpenCV's published 8-bit path (imgwarp.cpp: coordinates rounded to 1/32 px, 15-bit fixed-point
-    bilinear weights); cv2 is not installed here: UNVERIFIED against the library."""
+    bilinear weights); cv2 is not installed here: pinned by hand-derived known answers and by an exact float bilinear at the
+    1/32-pixel coordinates (tests/test_oracle_kat.py), not against the library itself."""
     sh, sw = src.shape[:2]
     Mi = np.linalg.inv(np.asarray(M, dtype=np.float64))
     dx, dy = np.meshgrid(np.arange(ow, dtype=np.float64), np.arange(oh, dtype=np.float64))
@@ -706,12 +709,12 @@ def clip_loop(frames_bgr_u8: np.ndarray, weights, net_hw, dtype=torch.float32, t
 
 def cv_resize_f32(src: np.ndarray, dh: int, dw: int) -> np.ndarray:
     """cv2.resize(src, (dw, dh)) INTER_LINEAR on a float32 HxWxC image (main:861): the taps of cv_resize_u8 with float coefficients,
-    horizontal pass then vertical pass in float32.  UNVERIFIED against cv2 (not installed)."""
+    horizontal pass then vertical pass in float32.  Pinned against an independent float bilinear (scipy.ndimage), not against cv2 itself."""
     sh, sw = src.shape[:2]
 
     def taps(dn, sn):
-        scale = np.float32(np.float64(sn) / np.float64(dn))
-        f = ((np.arange(dn, dtype=np.float64) + 0.5) * np.float64(scale) - 0.5).astype(np.float32)
+        scale = np.float64(1.0) / (np.float64(dn) / np.float64(sn))        # cv::resize: inv_scale = (double)dsize / ssize; hal::resize: scale = 1. / inv_scale
+        f = ((np.arange(dn, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)     # fx = (float)((dx+0.5)*scale_x - 0.5)
         s = np.floor(f).astype(np.int64)
         f = (f - s.astype(np.float32)).astype(np.float32)
         lo = s < 0

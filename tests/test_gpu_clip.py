@@ -21,6 +21,39 @@ def test_resize_u8_matches_restated_cv2(sh, sw, dh, dw):
         assert np.array_equal(out, src)            # same size is the identity
 
 
+def test_resize_u8_kernel_hand_derived_known_answers():
+    """The KERNEL against the literal known answers derived by hand from OpenCV's published 8-bit arithmetic (derivations:
+    tests/test_oracle_kat.py::test_cv_resize_u8_hand_derived_known_answers) -- no restatement in between."""
+    from tests.test_oracle_kat import CV_KAT_RAMP_2X, CV_KAT_THREE_QUARTERS, CV_KAT_CHECKER_2X
+
+    def run(a, dh, dw):                             # a: [h, w] grey levels -> 3 equal channels
+        src = torch.from_numpy(np.repeat(np.asarray(a, dtype=np.uint8)[None, ..., None], 3, axis=3)).cuda()
+        out = clip_driver.resize_u8(src, (dh, dw)).cpu().numpy()
+        assert np.array_equal(out[..., 0], out[..., 1]) and np.array_equal(out[..., 0], out[..., 2])
+        return out[0, ..., 0]
+    assert run([[0, 10, 20, 30]], 1, 8)[0].tolist() == CV_KAT_RAMP_2X
+    assert run([[0], [10], [20], [30]], 8, 1)[:, 0].tolist() == CV_KAT_RAMP_2X
+    assert run([[0, 100, 200, 40]], 1, 3)[0].tolist() == CV_KAT_THREE_QUARTERS
+    assert run([[0, 255], [255, 0]], 4, 4).tolist() == CV_KAT_CHECKER_2X
+    edge = run([[7, 200]], 1, 16)[0]
+    assert edge[:4].tolist() == [7] * 4 and edge[-4:].tolist() == [200] * 4
+    img = np.random.default_rng(0).integers(0, 256, (8, 12), dtype=np.uint8)
+    i64 = img.astype(np.int64)
+    area = (i64[0::2, 0::2] + i64[0::2, 1::2] + i64[1::2, 0::2] + i64[1::2, 1::2] + 2) >> 2          # cv2's INTER_AREA shortcut for exact x2
+    assert np.array_equal(run(img, 4, 6), area.astype(np.uint8))
+
+
+@pytest.mark.parametrize("sh,sw", [(720, 1280), (1000, 1777)])
+def test_resize_u8_kernel_at_the_drivers_size_against_a_float_bilinear(sh, sw):
+    """cv2.resize(frame, (512, 384)) (main:550) at real sizes: the kernel equals the restatement byte for byte (also for ratios that are
+    not exact in binary: 1000/384, 1777/512) and is never a full grey level from an independent float64 bilinear at half-pixel centres."""
+    from tests.test_oracle_kat import _float_bilinear_half_pixel
+    img = np.random.default_rng(sw).integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+    out = clip_driver.resize_u8(torch.from_numpy(img[None]).cuda(), (384, 512)).cpu().numpy()[0]
+    assert np.array_equal(out, vo.cv_resize_u8(img, 384, 512))
+    assert np.abs(out.astype(np.float64) - _float_bilinear_half_pixel(img, 384, 512)).max() <= 0.8
+
+
 def smooth_clip(T, H, W, seed):
     """A drifting smooth pattern: consecutive frames differ by a small shift (a video, not noise)."""
     rng = np.random.default_rng(seed)
@@ -234,4 +267,31 @@ def test_one_call_frame_equals_the_four_call_sequence(H, W, keep):
     other.step(clip[3])
     assert torch.equal(drv.last_flows["predict_flow2"], vs.flownetS_pyramid(drv.feats, 1)["predict_flow2"])
     assert a.shape == (1, H, W, 3)
+    runtime.reset()
+
+
+def test_clip_step_rejects_an_output_that_overlaps_its_inputs():
+    """The fused tail gathers frame pixels while other workgroups already write `out`, and the history slot is resized from `out`: an `out`
+    that is the frame (or a view of the history ring) would silently corrupt frames -- refused by the driver and by vstab_clip_step itself."""
+    import ctypes as C
+    from coupe.optical_flow_based_deep_video_stabilization_amd import _lib
+    H, W = 48, 64
+    w = wts.synthetic_weights(seed=21, cin=27, random_bn=True, flow_gain=0.5)
+    runtime.reset()
+    vs.assign_weights(w)
+    drv = clip_driver.ClipStabiliser(H, W, n_clips=1, net_hw=(H, W))
+    f = torch.randint(0, 256, (1, H, W, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError, match="overlap"):
+        drv.step(f, out=f)
+    with pytest.raises(ValueError, match="overlap"):
+        drv.step(f, out=drv.ring[3])                       # same shape here (net size == frame size): a view of the history ring
+    good = drv.step(f)                                      # and the driver still works
+    assert good.shape == f.shape
+    # the C ABI's own check
+    oc = drv._one_call
+    ptrs = (C.c_void_p * 8)(*[None] * 8)
+    rc = oc["fn"](oc["ctx"]._h, ptrs, f.data_ptr(), *oc["mid"], f.data_ptr(), drv.ring[5].data_ptr(), oc["ws"].data_ptr(), oc["ws"].numel(),
+                  runtime.stream_ptr())
+    assert rc == -6                                         # VSTAB_E_STATE
+    assert b"overlap" in _lib.lib().vstab_last_error(oc["ctx"]._h)
     runtime.reset()

@@ -15,8 +15,14 @@ pytestmark = pytest.mark.gpu
 FLOW_TOL = 1e-3
 
 
-def _run_case(B, H, W, cin, oracle_dtype):
-    w = wts.synthetic_weights(seed=1, cin=cin, random_bn=False)
+EPS32 = 1.1920929e-07
+
+
+def _run_case(B, H, W, cin, oracle_dtype, wkw=None, rel_eps=None):
+    """wkw: keyword arguments of the weight set (default: He-normal filters, identity BatchNorm -- what bench.py times).
+    rel_eps: None = the absolute 1e-3 gate; k = |err(pf_k)| <= k * eps32 * max|pf_k| per level instead (flows wider than the image:
+    the error is a relative one)."""
+    w = wts.synthetic_weights(cin=cin, **(wkw or dict(seed=1, random_bn=False)))
     runtime.reset()
     vs.assign_weights(w)
     rng = np.random.default_rng(H + W)
@@ -37,7 +43,12 @@ def _run_case(B, H, W, cin, oracle_dtype):
     assert torch.equal(again, pf2)                     # deterministic
     ref = vo.flownetS_pyramid(two[:1], w, oracle_dtype)
     errs = {k: float((flows[k][0].double().cpu() - ref[k][0].double()).abs().max()) for k in vo.FLOW_KEYS}
-    assert all(e <= FLOW_TOL for e in errs.values()), errs
+    if rel_eps is None:
+        assert all(e <= FLOW_TOL for e in errs.values()), errs
+    else:
+        mags = {k: float(ref[k].abs().max()) for k in vo.FLOW_KEYS}
+        in_eps = {k: errs[k] / (EPS32 * max(1.0, mags[k])) for k in vo.FLOW_KEYS}
+        assert all(v <= rel_eps for v in in_eps.values()), (in_eps, errs, mags)
     # glue + warp of sample 0 against the oracle run on the GPU's own flow (isolates W1/G1)
     of_ref = vo.flow_to_output_res(pf2[:1].cpu(), H, W, H, W)
     assert float((outflow[:1].cpu() - of_ref).abs().max()) <= 2e-5
@@ -108,3 +119,35 @@ def test_cfg2_full_pipeline_ends_in_the_spatial_transformer_warp():
     for i in range(B):
         assert torch.equal(out[i], out[int(pattern[i])]) and torch.equal(warped[i], warped[int(pattern[i])]), i
     assert torch.equal(out[:1].cpu(), vo.st_transform(warped[:1].cpu(), th2[:1], (H, W), matmul="unfused"))
+
+
+# ---- the parity envelope at full size ("what's weak" 2).  The cases above use the weight set bench.py times (0.22-0.27 of
+# the 1e-3 budget).  These pin the harder sets of profiles/flow_err_margin_r05.md at BASELINE's own sizes, against the fp64 restatement:
+# random BatchNorm statistics with flow_gain 1 (flows of ~200 px; 0.56-0.62 of the budget) under the ABSOLUTE gate, and flow_gain 2
+# (flows of 420-446 px, wider than the image) under the RELATIVE bound the error really follows -- 32 fp32 epsilons of the level's
+# largest flow (measured 14-21) -- because an absolute 1e-3 on a 420 px flow is 20 eps: below any fp32 evaluation's noise floor (the
+# torch-CPU fp32 restatement is off by 1.84e-3 on that cell).  A regression in summation order shows up in either.
+GAIN1 = dict(seed=2, random_bn=True, flow_gain=1.0)
+GAIN2 = dict(seed=1, random_bn=True, flow_gain=2.0)
+
+
+def test_cfg1_random_bn_gain1_absolute_gate():
+    errs = _run_case(8, 512, 512, 27, torch.float64, GAIN1)
+    assert max(errs.values()) <= 0.8e-3, errs              # measured 0.62e-3: the headroom itself is pinned
+
+
+def test_cfg2_size_random_bn_gain1_absolute_gate():
+    errs = _run_case(32, 720, 1280, 27, torch.float64, GAIN1)
+    assert max(errs.values()) <= 0.8e-3, errs              # measured 0.56e-3
+
+
+def test_cfg4_size_random_bn_gain1_absolute_gate():
+    _run_case(16, 1080, 1920, 27, torch.float64, GAIN1)
+
+
+def test_cfg1_random_bn_gain2_relative_bound():
+    _run_case(8, 512, 512, 27, torch.float64, GAIN2, rel_eps=32)
+
+
+def test_720p_random_bn_gain2_relative_bound():
+    _run_case(4, 720, 1280, 27, torch.float64, GAIN2, rel_eps=32)

@@ -359,7 +359,7 @@ def test_batch_independence_and_determinism():
     halves = torch.cat([vs.flownetS_pyramid(dev(feats[:2]), 2)["predict_flow2"].clone(),
                         vs.flownetS_pyramid(dev(feats[2:]), 2)["predict_flow2"].clone()])
     # split-K factors may differ with the batch -> not bitwise (vstab_set_plan_batch pins them: test_gpu_skinny.py); two plans for the same
-    # layers differ by a few fp32 epsilons of the flow itself (profiles/flow_err_margin_r05.md: <= 9.5 measured, 16 allowed)
+    # layers differ by a few fp32 epsilons of the flow itself (profiles/flow_err_margin_r05.md: <= 11.9 measured, 16 allowed)
     assert maxabs(full, halves.cpu()) <= 16 * 1.1920929e-07 * max(1.0, float(full.abs().max()))
 
 

@@ -168,3 +168,12 @@ def test_widening_golden_gpu():
     for k in vo.LOSS_LEVELS:
         r = z["loss_grad_" + k]
         assert np.abs(grads[k].cpu().numpy() - r).max() <= 2e-5 * max(float(np.abs(r).max()), 1e-6) + 1e-9, k
+
+
+def test_warp_perspective_u8_kernel_hand_derived_known_answer():
+    """The KERNEL against the literal answer derived by hand from OpenCV's published rule (1/32-pixel positions, 15-bit weights, (sum + 2^14) >> 15;
+    derivation: tests/test_oracle_kat.py::test_cv_warp_perspective_u8_hand_derived_and_exact_blend): a 0.26-pixel shift is sampled at 8/32."""
+    row = np.repeat(np.array([[[10], [100], [200], [41]]], dtype=np.uint8), 3, axis=2)[None]          # [1, 1, 4, 3]
+    M = torch.tensor([[[1, 0, 0.26], [0, 1, 0], [0, 0, 1.0]]], dtype=torch.float64).cuda()
+    got = pf.warp_perspective_u8(torch.from_numpy(row).cuda(), M).cpu().numpy()
+    assert got[0, 0, :, 0].tolist() == [8, 78, 175, 81] and np.array_equal(got[..., 0], got[..., 2])

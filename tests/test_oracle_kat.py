@@ -1,6 +1,7 @@
 """Known-answer tests that pin the oracle: every expectation here is
 derivable by hand from the op definitions, none comes from running the oracle."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import vstab_oracle as vo
@@ -268,3 +269,117 @@ def test_homography_oracle_known_answers():
     half = vo.cv_warp_perspective_u8(img, np.array([[1, 0, 0.5], [0, 1, 0.0], [0, 0, 1.0]]), H, W)
     want = (img[:, :-1].astype(np.int64) + img[:, 1:] + 1) >> 1                                          # a = 16: equal weights
     assert np.array_equal(half[:, 1:], want.astype(np.uint8))
+
+
+# ---- cv2 restatements (missing 3): cv2.resize(..., (512,384)) main:550,556-558 and cv2.warpPerspective main:736,740-741 are
+# OpenCV calls; OpenCV is not installed here.  What pins the restatements: (a) known answers derived BY HAND from OpenCV's published 8-bit
+# arithmetic (imgproc/resize.cpp: half-pixel centres, 11-bit coefficients, ((b0*(R0>>4))>>16 + (b1*(R1>>4))>>16 + 2)>>2; imgwarp.cpp:
+# 1/32-pixel coordinates, 15-bit weights, (sum + 2^14)>>15) -- the literal arrays below, each derived in the comment next to it; (b) an
+# INDEPENDENT float bilinear (scipy.ndimage.map_coordinates, order 1) at the same sample positions: within 1 LSB everywhere.
+CV_KAT_RAMP_2X = [0, 3, 8, 13, 18, 23, 28, 30]
+CV_KAT_THREE_QUARTERS = [17, 150, 67]
+CV_KAT_CHECKER_2X = [[0, 64, 191, 255], [64, 96, 159, 191], [191, 159, 96, 64], [255, 191, 64, 0]]
+
+
+def test_cv_resize_u8_hand_derived_known_answers():
+    # 1x4 ramp -> 1x8 (scale 0.5): fx = 0.5 dx - 0.25 -> dx=0: sx=-1 -> clamped to (0, f=0): 0;  dx=1: (sx=0, f=.25) a = (1536, 512):
+    # R = 10*512 = 5120, (2048*(5120>>4))>>16 = 10, (10+2)>>2 = 3;  dx=2: f=.75: R = 15360 -> 30 -> 8;  dx=3: (1, .25): 25600 -> 50 -> 13;
+    # dx=4: 35840 -> 70 -> 18;  dx=5: 46080 -> 90 -> 23;  dx=6: 56320 -> 110 -> 28;  dx=7: sx=3 = sw-1 -> f=0: 30
+    ramp = np.array([[0, 10, 20, 30]], dtype=np.uint8)[..., None]
+    assert vo.cv_resize_u8(ramp, 1, 8)[0, :, 0].tolist() == CV_KAT_RAMP_2X
+    assert vo.cv_resize_u8(ramp.transpose(1, 0, 2), 8, 1)[:, 0, 0].tolist() == CV_KAT_RAMP_2X        # the vertical pass alone: same values here
+    # 4 -> 3 (scale = 1/(3/4) = 1.333...): dx=0: fx = float32(0.1666..) -> a = (rint(1706.67), rint(341.33)) = (1707, 341): R = 100*341 = 34100,
+    # 34100>>4 = 2131, (2048*2131)>>16 = 66, (66+2)>>2 = 17;  dx=1: fx = 1.5 -> (1024, 1024): R = 307200 -> 19200 -> 600 -> 150;
+    # dx=2: fx = 2.8333 -> (341, 1707): R = 200*341 + 40*1707 = 136480 -> 8530 -> 266 -> 67
+    row = np.array([[0, 100, 200, 40]], dtype=np.uint8)[..., None]
+    assert vo.cv_resize_u8(row, 1, 3)[0, :, 0].tolist() == CV_KAT_THREE_QUARTERS
+    # 2x2 checker -> 4x4: both passes interpolate.  Row 0 after the horizontal pass, >>4: [0, 8160, 24480, 32640], row 1 mirrored.
+    # dy=0 (b = 2048, 0): (2048*8160)>>16 = 255 -> 257>>2 = 64; 24480 -> 765 -> 191; 32640 -> 1020 -> 255.
+    # dy=1 (b = 1536, 512): col 1: (1536*8160)>>16 = 191, (512*24480)>>16 = 191 -> 384>>2 = 96; col 2: 573 + 63 + 2 = 638>>2 = 159; ...
+    chk = np.array([[0, 255], [255, 0]], dtype=np.uint8)[..., None]
+    assert vo.cv_resize_u8(chk, 4, 4)[..., 0].tolist() == CV_KAT_CHECKER_2X
+    # edge replication: every output left of the first / right of the last source centre repeats the edge pixel
+    edge = np.array([[7, 200]], dtype=np.uint8)[..., None]
+    out = vo.cv_resize_u8(edge, 1, 16)[0, :, 0]
+    assert out[:4].tolist() == [7] * 4 and out[-4:].tolist() == [200] * 4 and np.all(np.diff(out.astype(int)) >= 0)
+    # an exact 2x reduction (cv2 routes INTER_LINEAR to INTER_AREA there): both coefficients are 1024 and the formula collapses to (a+b+c+d+2)>>2
+    img = np.random.default_rng(0).integers(0, 256, (8, 12, 3), dtype=np.uint8).astype(np.int64)
+    area = (img[0::2, 0::2] + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(vo.cv_resize_u8(img.astype(np.uint8), 4, 6), area.astype(np.uint8))
+
+
+def _float_bilinear_half_pixel(src, dh, dw):
+    """Independent reference: float64 bilinear at half-pixel centres, edge-replicated (scipy.ndimage), NOT the fixed-point code."""
+    from scipy import ndimage
+    sh, sw = src.shape[:2]
+    fy = np.clip((np.arange(dh) + 0.5) * (sh / dh) - 0.5, 0, sh - 1)
+    fx = np.clip((np.arange(dw) + 0.5) * (sw / dw) - 0.5, 0, sw - 1)
+    yy, xx = np.meshgrid(fy, fx, indexing="ij")
+    return np.stack([ndimage.map_coordinates(src[..., c].astype(np.float64), [yy, xx], order=1, mode="nearest") for c in range(src.shape[2])], -1)
+
+
+@pytest.mark.parametrize("sh,sw,dh,dw", [(720, 1280, 384, 512), (1080, 1920, 384, 512), (48, 64, 96, 128), (37, 53, 80, 100), (100, 75, 75, 100)])
+def test_cv_resize_u8_against_an_independent_float_bilinear(sh, sw, dh, dw):
+    rng = np.random.default_rng(sh + dw)
+    yy, xx = np.mgrid[0:sh, 0:sw].astype(np.float64)
+    smooth = np.stack([127 + 110 * np.sin(xx / (9.0 + c)) * np.cos(yy / (13.0 - c)) for c in range(3)], -1)
+    for name, img in (("noise", rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)), ("smooth", np.clip(smooth, 0, 255).astype(np.uint8))):
+        got = vo.cv_resize_u8(img, dh, dw).astype(np.int64)
+        ref = _float_bilinear_half_pixel(img, dh, dw)
+        # never a full grey level from the exact blend (measured 0.62-0.77: 11-bit coefficients, then R>>4, >>16 and >>2 all truncate)
+        assert np.abs(got - ref).max() <= 0.8, (name, float(np.abs(got - ref).max()))
+        exact = np.floor(ref + 0.5).astype(np.int64)
+        d = np.abs(got - exact)
+        assert d.max() <= 1, name
+        # ... so it equals the ROUNDED float blend on 86-91 % of the pixels and sits one level below it on the rest: that downward bias is
+        # the published formula's own (the hand-derived answers above show it: 7.5 -> 8 but 66.56 -> 66 -> 17 for a true 16.67), which is
+        # why "exact on 99 %" is not a property any faithful restatement can have
+        assert (d == 0).mean() >= 0.85, (name, float((d == 0).mean()))
+
+
+def test_cv_resize_f32_against_an_independent_float_bilinear():
+    rng = np.random.default_rng(3)
+    img = rng.random((45, 60, 3), dtype=np.float32)
+    for dh, dw in ((384 // 8, 512 // 8), (90, 120), (33, 47)):
+        got = vo.cv_resize_f32(img, dh, dw).astype(np.float64)
+        assert np.abs(got - _float_bilinear_half_pixel(img, dh, dw)).max() <= 2e-6
+
+
+def test_cv_warp_perspective_u8_hand_derived_and_exact_blend():
+    # a 0.26-pixel shift is rounded to 8/32: X = rint(32 (dx - 0.26)) = 32 dx - 8 -> sx = dx - 1, a = 24: weights (8, 24)/32 on (sx, sx+1):
+    # dst = ((8 S[dx-1] + 24 S[dx]) * 1024 + 2^14) >> 15 = (8 S[dx-1] + 24 S[dx] + 16) >> 5; the tap left of the image reads 0
+    row = np.array([[10, 100, 200, 41]], dtype=np.uint8)[..., None]
+    M = np.array([[1, 0, 0.26], [0, 1, 0], [0, 0, 1.0]])
+    assert vo.cv_warp_perspective_u8(row, M, 1, 4)[0, :, 0].tolist() == [(24 * 10 + 16) >> 5, (80 + 2400 + 16) >> 5, (800 + 4800 + 16) >> 5,
+                                                                         (1600 + 984 + 16) >> 5] == [8, 78, 175, 81]
+    # general homography: the published rule quantises the source position to 1/32 px; GIVEN those positions the 15-bit weights are exact
+    # ((32-a)(32-b)*32 / 2^15), so the result must EQUAL floor(exact float blend + 0.5) -- computed here in float64 with zero outside
+    rng = np.random.default_rng(9)
+    H, W = 40, 56
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    M = np.array([[1.02, 0.03, -1.7], [-0.02, 0.97, 2.3], [3e-4, -2e-4, 1.0]])
+    got = vo.cv_warp_perspective_u8(img, M, H, W)
+    Mi = np.linalg.inv(M)
+    dx, dy = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    den = Mi[2, 0] * dx + Mi[2, 1] * dy + Mi[2, 2]
+    qx = np.rint(32.0 * (Mi[0, 0] * dx + Mi[0, 1] * dy + Mi[0, 2]) / den) / 32.0
+    qy = np.rint(32.0 * (Mi[1, 0] * dx + Mi[1, 1] * dy + Mi[1, 2]) / den) / 32.0
+    P = 8                                                            # zero margin: BORDER_CONSTANT 0
+    pad = np.zeros((H + 2 * P, W + 2 * P, 3))
+    pad[P:-P, P:-P] = img
+    x0, y0 = np.floor(qx), np.floor(qy)
+    ax, ay = (qx - x0)[..., None], (qy - y0)[..., None]
+    assert x0.min() >= -P and x0.max() <= W + P - 2 and y0.min() >= -P and y0.max() <= H + P - 2
+    xi, yi = x0.astype(int) + P, y0.astype(int) + P
+    blend = (1 - ax) * (1 - ay) * pad[yi, xi] + ax * (1 - ay) * pad[yi, xi + 1] + (1 - ax) * ay * pad[yi + 1, xi] + ax * ay * pad[yi + 1, xi + 1]
+    assert np.array_equal(got, np.floor(blend + 0.5).astype(np.uint8))
+    # and against the UNquantised positions on a smooth image (gradient <= ~12 grey levels per pixel: 1/64 px of position is < 0.2 levels)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    smooth = np.clip(np.stack([127 + 100 * np.sin(xx / (9.0 + c)) * np.cos(yy / (11.0 - c)) for c in range(3)], -1), 0, 255).astype(np.uint8)
+    from scipy import ndimage
+    ex = (Mi[0, 0] * dx + Mi[0, 1] * dy + Mi[0, 2]) / den
+    ey = (Mi[1, 0] * dx + Mi[1, 1] * dy + Mi[1, 2]) / den
+    ref = np.stack([ndimage.map_coordinates(smooth[..., c].astype(np.float64), [ey, ex], order=1, mode="constant", cval=0.0) for c in range(3)], -1)
+    interior = (ex >= 0) & (ex <= W - 1) & (ey >= 0) & (ey <= H - 1)
+    g2 = vo.cv_warp_perspective_u8(smooth, M, H, W).astype(np.float64)
+    assert np.abs(g2 - ref)[interior].max() <= 1.0
