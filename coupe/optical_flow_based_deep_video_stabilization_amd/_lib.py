@@ -126,6 +126,8 @@ EXPORTS = {
     "vstab_host_layer_plan_pinned": (C.c_int, [C.c_int, C.c_uint] + [C.c_int] * 5 + [c_int32_p, C.c_int]),
     "vstab_host_pack_layer": (C.c_longlong, [C.c_int, C.c_int, c_float_p, C.POINTER(C.c_double), c_float_p,
                                              C.c_longlong]),
+    "vstab_host_wdec_plan": (C.c_int, [C.c_int] * 5 + [c_int32_p, C.c_int]),
+    "vstab_host_pack_wdec": (C.c_longlong, [C.c_int, c_float_p, C.POINTER(C.c_double), c_float_p, C.c_longlong]),
 }
 
 class LossLevelDesc(C.Structure):

@@ -121,6 +121,11 @@ struct Plan {
     bool wino[10];
     ConvParams wcp[10];
     ConvTile wtile[10];
+    // Winograd F(2x2,2x2) form of the transposed convolutions (winograd_ops.hip; cp[10 + l] stays the direct form): the 9-position GEMM
+    bool wdec[4];
+    ConvParams wdcp[4];
+    ConvTile wdtile[4];
+    WdecGeom wdg[4];
 };
 
 // What a context pins about its launch plans (vstab_set_plan_batch / vstab_set_plan_flags).  batch > 0: every per-layer decision that
@@ -291,6 +296,70 @@ bool wino_applies(int B, int H, int W, int cin, int cout)
     return 32.0 * B * TH * TW * cin * cout >= VSTAB_WINO_MIN_FLOPS;
 }
 
+// The 9-position 1x1 GEMM over F(2x2,2x2)-transformed tiles of a transposed convolution's input (winograd_ops.hip):
+// V [B][9][NTy][NTx][cs_in] -> M [B][9][NTy][NTx][4 cout]; position (i, j) multiplies only the nty[i] x ntx[j] tiles that are not zero
+void fill_wdec_gemm(ConvParams &p, int B, const WdecGeom &g, int cs_in, int cout)
+{
+    std::memset(&p, 0, sizeof p);
+    p.B = B; p.Hi = 9 * g.NTy; p.Wi = g.NTx; p.Cs_in = cs_in;
+    const KLayout L = klayout_run(1, 1, cs_in);
+    set_layout(p, L);
+    p.s_in = 1; p.s_out = 1; p.Ho = 9 * g.NTy; p.Wo = g.NTx; p.Cs_out = 4 * cout; p.c_off = 0;
+    p.N = 4 * cout; p.Npad = 4 * cout; p.act = 0; p.nphase = 9;
+    const size_t pos_floats = (size_t)L.ktiles() * p.Npad * 32;
+    p.Mmax = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            ConvPhase &ph = p.ph[i * 3 + j];
+            ph.Hg = g.nty[i]; ph.Wg = g.ntx[j]; ph.M = B * ph.Hg * ph.Wg;
+            ph.off_y = (i * 3 + j) * g.NTy; ph.off_x = 0; ph.o_y = (i * 3 + j) * g.NTy; ph.o_x = 0;
+            ph.w_off = (long long)(i * 3 + j) * pos_floats;
+            p.Mmax = std::max(p.Mmax, ph.M);
+        }
+    set_ranges(p);
+    p.ksplit = 1;
+}
+
+// does refinement level l's transposed convolution run in Winograd F(2x2,2x2) form?  9/16 of the multiply-adds, against two more HBM
+// passes (V and M), one more launch, a reduction of only Cin (25 / 33 K-tiles per workgroup instead of 100 / 132) and a ragged tile
+// grid (one more tile per axis than Hin/2).  Decided with the cost model that picks the split-K factors: the direct launch's modelled
+// time `t_direct_us` against the 9-position GEMM's (on 128- or 64-row tiles, whichever the model prefers: *tile_out) plus the two
+// transforms at the bandwidth they measure (4.5 TB/s over input + V + M + output; profiles/README.md r06).  Measured: at B=8 512x512
+// deconv3 gains a little (-12 us of 200) and deconv4 would lose (336 workgroups on 512 slots: as long as the direct form) -- the model
+// says the same; at 16 x 720p / 8 x 1080p per chunk deconv4 and deconv3 take 0.60 / 0.63 of their direct time and the step -3.7 % / -2.2 %.
+// deconv2 (Cin 386 -> 64: 13 K-tiles, N = 256, V and M larger than the layer's own tensors) is not built.
+bool wdec_applies(int l, int B, const WdecGeom &g, int Hi, int Wi, int Ho, int Wo, int cs_in, int cout, double t_direct_us, int ks_direct, bool force,
+                  ConvTile *tile_out)
+{
+    *tile_out = TILE_128x128;
+#ifdef VSTAB_HARNESS
+    static const bool wdec_on = getenv("VSTAB_NO_WDEC") == nullptr;           // A/B switch of the tuning harness builds
+    if (!wdec_on) return false;
+#endif
+    if (l < 0 || l > 2 || (cs_in & 3) || ((4 * cout) & 127) || 4 * cout > 2048) return false;     // (2048 = the zero bias the GEMMs share)
+    if ((long long)B * 9 * g.NTy * g.NTx * std::max(cs_in, 4 * cout) * 4 >= 0x80000000LL) return false;
+    const int KT = round_up(cs_in, 32) / 32;
+    double best = 1e30;
+    for (int BM : {128, 64}) {
+        long long tiles = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) tiles += ((long long)B * g.nty[i] * g.ntx[j] + BM - 1) / BM;
+        int eff;
+        const double t = split_cost_us(tiles * (4 * cout / 128), KT, 1, 0.0, 128, BM, &eff);
+        if (t < best) { best = t; *tile_out = BM == 128 ? TILE_128x128 : TILE_64x128; }
+    }
+    if (force) return true;                                                   // VSTAB_PLAN_FORCE_WDEC: small test shapes
+    const double plane = (double)B * g.NTy * g.NTx;
+    const double bytes = 4.0 * ((double)B * Hi * Wi * cs_in + 9.0 * plane * cs_in + 9.0 * plane * 4.0 * cout + (double)B * Ho * Wo * cout);
+#ifndef VSTAB_WDEC_MARGIN
+#define VSTAB_WDEC_MARGIN 0.92           // (A/B builds: scripts/build_variant_lib.sh -DVSTAB_WDEC_MARGIN=...)
+#endif
+    // a direct launch the model splits in K is a small one (B=8 512x512: deconv5 / deconv4, split 4 / 2): the model prices those 20-25 %
+    // too high (measured 71 / 133 us against 89 / 163) and the ragged 9-position grid quantises badly on 512 slots -- they stay direct
+    if (ks_direct > 1) return false;
+    return best + bytes / 4.5e6 + 3.0 < VSTAB_WDEC_MARGIN * t_direct_us;
+}
+
 namespace {
 int max_chunk(int B, int H, int W, int Cin);
 
@@ -402,8 +471,6 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl, const PlanPin *pin = null
         wino_m = std::max(wino_m, (size_t)B * 16 * TH * TW * e.cout);
         pl.wino[i] = true;
     }
-    pl.bytes[B_WINO_V] = wino_v * 4;
-    pl.bytes[B_WINO_M] = wino_m * 4;
     // ---- decoder transposed convs: 4 phases of a 2x2-tap conv
     const int dec_in[4] = {B_CONV6_1, B_CONCAT5, B_CONCAT4, B_CONCAT3};
     const int dec_out[4] = {B_CONCAT5, B_CONCAT4, B_CONCAT3, B_CONCAT2};
@@ -443,7 +510,28 @@ bool make_plan(int B, int H, int W, int Cin, Plan &pl, const PlanPin *pin = null
             if (pl.skinny[10 + l]) pl.tile[10 + l] = TILE_SKINNY;
         }
         if (p.ksplit > 1) partial_floats = std::max(partial_floats, (size_t)p.nphase * p.ksplit * p.Mmax * p.Npad);
+        // Winograd F(2x2,2x2) form (an arithmetic-changing decision: pinned like the others); rides in the two-problem launch only
+        pl.wdec[l] = false;
+        pl.wdg[l] = wdec_geom(p.Hi, p.Wi, p.Ho, p.Wo);
+        if (!(flags & (VSTAB_PLAN_NO_DUAL | VSTAB_PLAN_NO_WDEC)) && !pl.skinny[10 + l]) {
+            const ConvTile dt = pl.tile[10 + l];
+            int ks_d;
+            ConvParams pd1 = p;
+            const double t_direct = best_split(pd1, dt == TILE_128x64 ? 64 : 128, dt == TILE_64x128 ? 64 : 128, &ks_d);
+            ConvTile wt;
+            const bool on = wdec_applies(l, B, pl.wdg[l], p.Hi, p.Wi, p.Ho, p.Wo, p.Cs_in, p.N, t_direct, p.ksplit, (flags & VSTAB_PLAN_FORCE_WDEC) != 0, &wt);
+            if (ref ? ref->wdec[l] : on) {
+                const WdecGeom &g = pl.wdg[l];
+                fill_wdec_gemm(pl.wdcp[l], B, g, p.Cs_in, p.N);
+                pl.wdtile[l] = wt;                                               // (a tile shape changes no sum: not pinned)
+                wino_v = std::max(wino_v, (size_t)B * 9 * g.NTy * g.NTx * p.Cs_in);
+                wino_m = std::max(wino_m, (size_t)B * 9 * g.NTy * g.NTx * 4 * p.N);
+                pl.wdec[l] = true;
+            }
+        }
     }
+    pl.bytes[B_WINO_V] = wino_v * 4;
+    pl.bytes[B_WINO_M] = wino_m * 4;
     // ---- predict2 tap table: 1x1 conv concat2 -> 18 (pad 32) columns
     {
         ConvParams &p = pl.cp[14];
@@ -613,7 +701,7 @@ extern "C" int vstab_set_plan_batch(vstab_ctx *ctx, int batch)
 extern "C" int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags)
 {
     if (!ctx) return fail(nullptr, VSTAB_E_STATE, "set_plan_flags: ctx is NULL");
-    if (flags & ~(unsigned)(VSTAB_PLAN_NO_SKINNY | VSTAB_PLAN_NO_DUAL | VSTAB_PLAN_NO_TAIL)) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(unsigned)(VSTAB_PLAN_NO_SKINNY | VSTAB_PLAN_NO_DUAL | VSTAB_PLAN_NO_TAIL | VSTAB_PLAN_NO_WDEC | VSTAB_PLAN_FORCE_WDEC)) return fail(ctx, VSTAB_E_SHAPE, "set_plan_flags: unknown flag bits 0x%x", flags);
     ctx->plan_flags = flags;
     return VSTAB_OK;
 }
@@ -679,7 +767,8 @@ extern "C" int vstab_host_layer_plan_pinned(int plan_batch, unsigned flags, int 
     if (cap < need) return fail(nullptr, VSTAB_E_NOMEM, "layer_plan: need %d ints", need);
     const int v[26] = {p.B, p.Hi, p.Wi, p.Cs_in, p.KH, p.NSEG, p.SEG, p.SEGP, p.SEG_STRIDE, p.s_in, p.s_out, p.Ho, p.Wo,
                        p.Cs_out, p.c_off, p.N, p.Npad, p.act, p.nphase, p.ksplit, p.Mmax, (int)pl.tile[layer],
-                       (int)pl.vec4[layer], LAYER_IN[layer], LAYER_OUT[layer], (layer < 10 && pl.wino[layer]) ? 1 : 0};
+                       (int)pl.vec4[layer], LAYER_IN[layer], LAYER_OUT[layer],
+                       ((layer < 10 && pl.wino[layer]) || (layer >= 10 && layer < 14 && pl.wdec[layer - 10])) ? 1 : 0};
     for (int i = 0; i < 26; ++i) out[i] = v[i];
     for (int k = 0; k < p.nphase; ++k) {
         const ConvPhase &ph = p.ph[k];
@@ -687,6 +776,44 @@ extern "C" int vstab_host_layer_plan_pinned(int plan_batch, unsigned flags, int 
         for (int i = 0; i < 7; ++i) out[26 + 7 * k + i] = q[i];
     }
     return need;
+}
+
+// the 9-position GEMM of refinement level l's transposed convolution in Winograd F(2x2,2x2) form, whether or not the plan would choose
+// it: the fields of vstab_host_layer_plan (26 + 7 per position) followed by the tile geometry {NTy, NTx, nty[3], ntx[3]}
+extern "C" int vstab_host_wdec_plan(int B, int H, int W, int Cin, int l, int32_t *out, int cap)
+{
+    Plan pl;
+    if (!out || l < 0 || l > 3 || !make_plan(B, H, W, Cin, pl)) return fail(nullptr, VSTAB_E_SHAPE, "wdec_plan: bad arguments");
+    const ConvParams &d = pl.cp[10 + l];
+    ConvParams p;
+    const WdecGeom g = wdec_geom(d.Hi, d.Wi, d.Ho, d.Wo);
+    fill_wdec_gemm(p, B, g, d.Cs_in, d.N);
+    const int need = 26 + 7 * 9 + 8;
+    if (cap < need) return fail(nullptr, VSTAB_E_NOMEM, "wdec_plan: need %d ints", need);
+    const int v[26] = {p.B, p.Hi, p.Wi, p.Cs_in, p.KH, p.NSEG, p.SEG, p.SEGP, p.SEG_STRIDE, p.s_in, p.s_out, p.Ho, p.Wo,
+                       p.Cs_out, p.c_off, p.N, p.Npad, p.act, p.nphase, p.ksplit, p.Mmax, (int)TILE_128x128, 1, LAYER_IN[10 + l], LAYER_OUT[10 + l],
+                       pl.wdec[l] ? 1 : 0};
+    for (int i = 0; i < 26; ++i) out[i] = v[i];
+    for (int k = 0; k < 9; ++k) {
+        const ConvPhase &ph = p.ph[k];
+        const int q[7] = {ph.Hg, ph.Wg, ph.M, ph.off_y, ph.off_x, ph.o_y, ph.o_x};
+        for (int i = 0; i < 7; ++i) out[26 + 7 * k + i] = q[i];
+    }
+    const int gg[8] = {g.NTy, g.NTx, g.nty[0], g.nty[1], g.nty[2], g.ntx[0], g.ntx[1], g.ntx[2]};
+    for (int i = 0; i < 8; ++i) out[26 + 63 + i] = gg[i];
+    return need;
+}
+
+extern "C" long long vstab_host_pack_wdec(int l, const float *W, const double *scale, float *wpk, long long cap)
+{
+    if (!W || !wpk || l < 0 || l > 3) return fail(nullptr, VSTAB_E_SHAPE, "pack_wdec: bad arguments");
+    const int co = DEC_COUT[l];
+    const long long n = 9LL * klayout_run(1, 1, DEC_CS_IN[l]).ktiles() * 4 * co * 32;
+    if (cap < n) return fail(nullptr, VSTAB_E_NOMEM, "pack_wdec: need %lld floats", n);
+    std::vector<double> ones;
+    if (!scale) { ones.assign(co, 1.0); scale = ones.data(); }
+    pack_wdec(W, scale, DEC_CIN[l], DEC_CS_IN[l], co, wpk);
+    return n;
 }
 
 extern "C" long long vstab_host_pack_layer(int Cin, int layer, const float *W, const double *scale, float *wpk,
@@ -784,6 +911,11 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
         fold_bn(b->data, beta->data, mean->data, var->data, co, npad, scale.data(), host.data() + ctx->dec_b[l]);
         ctx->dec_w[l] = reserve(4 * (size_t)klayout_deconv(cs).ktiles() * npad * 32);
         pack_deconv(W->data, scale.data(), ci, cs, co, npad, host.data() + ctx->dec_w[l]);
+        ctx->wdec_w[l] = 0;
+        if (l <= 2) {                 // Winograd F(2x2,2x2)-domain operands (9 positions x 4 phases) of the levels wdec_applies() can choose
+            ctx->wdec_w[l] = reserve(9 * (size_t)klayout_run(1, 1, cs).ktiles() * 4 * co * 32);
+            pack_wdec(W->data, scale.data(), ci, cs, co, host.data() + ctx->wdec_w[l]);
+        }
 
         const std::string u = UP_NAME[l];
         NEED(uw, u + "/W_deconv2d", 4, 4, 2, 2)
@@ -807,7 +939,7 @@ extern "C" int vstab_load_weights(vstab_ctx *ctx, const vstab_tensor *t, int cou
         ctx->tab_b = reserve(32);
         ctx->tab_wp = reserve((size_t)200 * 32);
         pack_predict2_panel(W->data, 194, 200, host.data() + ctx->tab_wp);
-        ctx->zero_b = reserve(1024);             // zero bias for the Winograd-domain GEMMs (bias is added by the inverse transform)
+        ctx->zero_b = reserve(2048);             // zero bias for the Winograd-domain GEMMs (bias is added by the inverse transform)
         ctx->pred2_b = reserve(4);
         host[ctx->pred2_b] = b->data[0]; host[ctx->pred2_b + 1] = b->data[1];
     }
@@ -924,11 +1056,15 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
             double mac = 0;
             if (i < 10 && pl.wino[i]) mac = 16.0 * pl.wcp[i].Mmax * ENC[i - 1].cout * p.N;      // MACs the Winograd-domain GEMM issues (4/9 of direct)
             else if (i < 10) mac = (double)p.ph[0].M * ENC[i].k * ENC[i].k * (i == 0 ? Cin : ENC[i - 1].cout) * p.N;
+            else if (i < 14 && pl.wdec[i - 10]) {                          // MACs the 9-position GEMM issues (9/16 of direct, plus the ragged tile grid)
+                for (int k = 0; k < 9; ++k) mac += (double)pl.wdcp[i - 10].ph[k].M * DEC_CIN[i - 10] * 4.0 * p.N;
+            }
             else if (i < 14) mac = (double)B * p.Ho * p.Wo * 4.0 * DEC_CIN[i - 10] * p.N;
             else mac = (double)p.ph[0].M * 194.0 * 18.0;
             ctx->prof_flops[i] += 2.0 * mac;
             double dmac = mac;                           // the same layer as a direct convolution (SURVEY.md 8d's accounting)
             if (i < 10 && pl.wino[i]) dmac = (double)p.ph[0].M * 9.0 * ENC[i - 1].cout * p.N;
+            if (i >= 10 && i < 14 && pl.wdec[i - 10]) dmac = (double)B * p.Ho * p.Wo * 4.0 * DEC_CIN[i - 10] * p.N;
             ctx->prof_flops_direct[i] += 2.0 * dmac;
         }
     }
@@ -1036,6 +1172,34 @@ static int forward_chunk(vstab_ctx *ctx, const float *feats, int B, int H, int W
         pt.wpk = dw + ctx->pred_w[l]; pt.bias = dw + ctx->tab_b; pt.partial = buf(B_PARTIAL) + dec_slab;
         const float *tsrc = pt.ksplit > 1 ? pt.partial : pt.out;
         const bool fuse = !(pin.flags & VSTAB_PLAN_NO_DUAL) && !pl.skinny[10 + l];
+        if (fuse && pl.wdec[l]) {
+            // Winograd F(2x2,2x2): input transform, the 9-position GEMM beside the level's tap-table tiles, inverse transform (+ bias, leaky
+            // relu) into the concat slice; predict_up has no slabs of the transposed convolution to sum
+            {
+                TraceRange r2(DEC_RANGE[l]);
+                const WdecGeom &g = pl.wdg[l];
+                HIP_TRY(ctx, launch_wdec_input(pd.in, B, pd.Hi, pd.Wi, pd.Cs_in, buf(B_WINO_V), g, stream));
+                ConvParams q = pl.wdcp[l];
+                q.in = buf(B_WINO_V); q.out = buf(B_WINO_M); q.wpk = dw + ctx->wdec_w[l]; q.bias = dw + ctx->zero_b; q.partial = buf(B_PARTIAL);
+                pt.partial = buf(B_PARTIAL);
+                const hipError_t e = launch_conv_dual(q, pl.wdtile[l], pt, pl.tile[15 + l], stream, EV_A(10 + l), EV_B(10 + l));
+                if (e == hipErrorNotSupported) {
+                    HIP_TRY(ctx, launch_conv(pt, pl.tile[15 + l], true, stream, nullptr, nullptr, false));
+                    HIP_TRY(ctx, launch_conv(q, pl.wdtile[l], true, stream, EV_A(10 + l), EV_B(10 + l), false));
+                    PROF_NAME(10 + l, conv_kernel_name(pl.wdtile[l], true));
+                } else {
+                    HIP_TRY(ctx, e);
+                    PROF_NAME(10 + l, dual_kernel_name(pl.wdtile[l]));
+                }
+            }
+            // the inverse transform (+ bias, leaky relu) shares its launch with predict_up: different channel slices of the same concat
+            TraceRange r3(HEAD_RANGE[l]);
+            const float *tsrc2 = pt.ksplit > 1 ? pt.partial : pt.out;
+            const WdecOutArgs wo{buf(B_WINO_M), pd.N / 4, dw + ctx->dec_b[l], 1, buf(cat_buf[l]), pd.Ho, pd.Wo, pd.Cs_out, pd.c_off, pl.wdg[l]};
+            HIP_TRY(ctx, launch_predict_up(tsrc2, pt.ksplit, (long long)pt.Mmax * pt.Npad, B, pt.Hi, pt.Wi, dw + ctx->pred_b[l], prev, ph_, pw_,
+                                           pfs[l], ctx->up[l], buf(cat_buf[l]), oh, ow, CONCAT_CS[l], CONCAT_C[l] - 2, stream, nullptr, &wo));
+            continue;
+        }
         if (fuse) {
             {
                 TraceRange r2(DEC_RANGE[l]);

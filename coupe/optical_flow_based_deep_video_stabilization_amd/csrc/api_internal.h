@@ -26,6 +26,7 @@ struct vstab_ctx {
     size_t zero_b = 0;                   // 1024 zeros
     size_t wino_w[10] = {0};             // Winograd-domain operands of the 3x3 stride-1 stages (winograd_ops.hip)
     size_t dec_w[4], dec_b[4];
+    size_t wdec_w[4] = {0};              // Winograd F(2x2,2x2)-domain operands of deconv4 / deconv3 (winograd_ops.hip)
     size_t pred_w[4], pred_b[4];         // predict6,5,4,3
     size_t tab_wp, tab_b, pred2_b;       // predict2 tap table as plain [200][32] rows (tap_panel.hip); the zero bias the tap-table GEMMs of predict6..3 share; predict2's bias
     vstab::UpflowW up[4];

@@ -248,15 +248,39 @@ __global__ __launch_bounds__(256) void combine_predict_up_kernel(const ConvParam
     predict_up_body<PU_T>(A, W, (int)(r % tiles_x), (int)(r / tiles_x), (int)bz);
 }
 
+// The same pairing for a transposed convolution in Winograd F(2x2,2x2) form (winograd_ops.hip): its inverse transform (the first nC
+// workgroups; wdec_output_kernel's work items, sample-major) beside predict_flowN + upsample_flowN.
+template <int PU_T>
+__global__ __launch_bounds__(256) void wdec_output_predict_up_kernel(const WdecOutArgs O, const unsigned nC, const unsigned per_sample, const PredictUpArgs A,
+                                                                     const UpflowW W, const unsigned tiles_x, const unsigned tiles_y)
+{
+    if (blockIdx.x < nC) {                          // workgroup uniform
+        const unsigned n = blockIdx.x / per_sample, b = blockIdx.x - n * per_sample;
+        wdec_output_item(O, (long long)b * 256 + threadIdx.x, (int)n);
+        return;
+    }
+    const unsigned t = blockIdx.x - nC, per = tiles_x * tiles_y;
+    const unsigned bz = t / per, r = t - bz * per;
+    predict_up_body<PU_T>(A, W, (int)(r % tiles_x), (int)(r / tiles_x), (int)bz);
+}
+
 hipError_t launch_predict_up(const float *src, int ks, long long slab_stride, int B, int h, int w, const float *bias2,
                              const float *prev, int ph, int pw, float *out, const UpflowW &W, float *concat, int oh, int ow,
-                             int Cs, int c_off, hipStream_t stream, const ConvParams *combine)
+                             int Cs, int c_off, hipStream_t stream, const ConvParams *combine, const WdecOutArgs *wdec)
 {
     if ((Cs & 3) || (c_off & 3) || c_off + 4 > Cs || ks < 1 || oh > 2 * h || ow > 2 * w) return hipErrorInvalidValue;
     PredictUpArgs A{src, ks, slab_stride, h, w, bias2, prev, ph, pw, prev ? (float)ph / (float)h : 0.f, prev ? (float)pw / (float)w : 0.f,
                     out, concat, oh, ow, Cs, c_off};
     const int T = (long long)((w + 7) / 8) * ((h + 7) / 8) * B < 256 ? 4 : 8;       // 4 x 4 tiles while 8 x 8 ones would leave CUs idle
     const unsigned tx = (unsigned)((w + T - 1) / T), ty = (unsigned)((h + T - 1) / T);
+    if (wdec) {
+        const unsigned long long per_sample = (unsigned long long)(((long long)wdec->g.NTy * wdec->g.NTx * 16 * wdec->C4 + 255) / 256);
+        const unsigned long long nC = per_sample * (unsigned)B, nP = (unsigned long long)tx * ty * (unsigned)B;
+        if (nC + nP >= 0x7fffffffull) return hipErrorInvalidValue;
+        if (T == 4) wdec_output_predict_up_kernel<4><<<dim3((unsigned)(nC + nP)), dim3(256), 0, stream>>>(*wdec, (unsigned)nC, (unsigned)per_sample, A, W, tx, ty);
+        else wdec_output_predict_up_kernel<8><<<dim3((unsigned)(nC + nP)), dim3(256), 0, stream>>>(*wdec, (unsigned)nC, (unsigned)per_sample, A, W, tx, ty);
+        return hipGetLastError();
+    }
     if (combine && combine->ksplit > 1) {
         const long long total = (long long)combine->Mmax * (combine->N >> 2) * combine->nphase;
         const unsigned long long nC = (unsigned long long)((total + 255) / 256), nP = (unsigned long long)tx * ty * (unsigned)B;

@@ -156,6 +156,28 @@ void pack_winograd(const float *W, const double *scale, int cin, int cout, int n
                          wpk + (size_t)(i * 4 + j) * phase_floats);
 }
 
+// Winograd F(2x2,2x2) operands of a 4x4 stride-2 transposed convolution (winograd_ops.hip): per axis the 2-tap filter of output parity p is
+// g = (W[3 - p], W[1 - p]) (taps on inputs d0, d1 resp. d1, d2 of a tile) and its transform u = (g0, g0 + g1, g1) = G g, G = [1 0; 1 1; 0 1]
+void pack_wdec(const float *W, const double *scale, int cin, int cs_in, int cout, float *wpk)
+{
+    static const double G[3][2] = {{1.0, 0.0}, {1.0, 1.0}, {0.0, 1.0}};
+    const KLayout L = klayout_run(1, 1, cs_in);
+    const int npad = 4 * cout;
+    const size_t pos_floats = (size_t)L.ktiles() * npad * 32;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            pack_generic(L, cs_in, cin, 1, npad, npad,
+                         [&](int, int, int ci, int n) {
+                             const int ph = n / cout, co = n - ph * cout, py = ph >> 1, px = ph & 1;
+                             double u = 0.0;                               // (G g G^T)[i][j] in double, BatchNorm scale folded in
+                             for (int a = 0; a < 2; ++a)
+                                 for (int b = 0; b < 2; ++b)
+                                     u += G[i][a] * G[j][b] * (double)W[(((size_t)(3 - py - 2 * a) * 4 + (3 - px - 2 * b)) * cout + co) * cin + ci];
+                             return (float)(u * scale[co]);
+                         },
+                         wpk + (size_t)(i * 3 + j) * pos_floats);
+}
+
 void pack_predict2_table(const float *W, int cin, int cs_in, int npad, float *wpk)
 {
     const KLayout L = klayout_run(1, 1, cs_in);

@@ -246,6 +246,77 @@ hipError_t launch_wino_weights(const float *W, int cin, int cout, int transpose,
 hipError_t launch_wino_output(const float *M, int B, int Ho, int Wo, int C, const float *bias, int act, float *out, int Cs_out, int c_off,
                               hipStream_t stream);
 
+// Winograd F(2x2,2x2) form of a 4x4 stride-2 SAME transposed convolution (winograd_ops.hip documents the algebra): tile grid and, per
+// position row / column, how many tiles are not identically zero
+struct WdecGeom {
+    int NTy, NTx;           // tiles per axis: Ho/4 + 1, Wo/4 + 1
+    int nty[3], ntx[3];     // tiles position row i / column j needs (the rest is zero)
+};
+inline WdecGeom wdec_geom(int Hi, int Wi, int Ho, int Wo)
+{
+    WdecGeom g;
+    g.NTy = Ho / 4 + 1; g.NTx = Wo / 4 + 1;
+    g.nty[0] = g.NTy < Hi / 2 + 1 ? g.NTy : Hi / 2 + 1; g.nty[1] = g.nty[2] = g.NTy < (Hi + 1) / 2 ? g.NTy : (Hi + 1) / 2;
+    g.ntx[0] = g.NTx < Wi / 2 + 1 ? g.NTx : Wi / 2 + 1; g.ntx[1] = g.ntx[2] = g.NTx < (Wi + 1) / 2 ? g.NTx : (Wi + 1) / 2;
+    return g;
+}
+struct WdecOutArgs { const float *M; int C4; const float *bias; int act; float *out; int Ho, Wo, Cs_out, c_off; WdecGeom g; };
+#ifdef __HIPCC__
+// One work item of the inverse transform (wdec_output_kernel; also the first workgroups of wdec_output_predict_up_kernel): item idx of
+// sample n = (tile, phase, four output channels): nine M values -> the phase's 2 x 2 outputs, + bias, activation, stores
+__device__ __forceinline__ void wdec_output_item(const WdecOutArgs &A, const long long idx, const int n)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const WdecGeom &g = A.g;
+    const int C4 = A.C4;
+    if (idx >= (long long)g.NTy * g.NTx * 4 * C4) return;
+    const int c = (int)(idx % C4);
+    const int ph = (int)((idx / C4) & 3);
+    const int tile = (int)(idx / (4 * C4));
+    const int ty = tile / g.NTx, tx = tile - ty * g.NTx;
+    const int py = ph >> 1, px = ph & 1;
+    const int N = 16 * C4;                           // 4 phases x Cout floats per GEMM row
+    const long long plane = (long long)g.NTy * g.NTx * N;
+    const float *mb = A.M + (long long)n * 9 * plane + (long long)tile * N + ph * (4 * C4) + c * 4;
+    f32x4 m[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ty < g.nty[i] && tx < g.ntx[j]) v = *reinterpret_cast<const f32x4 *>(mb + (i * 3 + j) * plane);
+            m[i][j] = v;
+        }
+    f32x4 s[2][3];                                  // rows: (m0 + m1, m1 - m2)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        s[0][j] = m[0][j] + m[1][j];
+        s[1][j] = m[1][j] - m[2][j];
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(A.bias + c * 4);
+    const float slope = A.act == 1 ? 0.1f : 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oy = 4 * ty + 2 * a - py;          // even phase: 4t, 4t+2; odd phase: 4t-1, 4t+1
+        if ((unsigned)oy >= (unsigned)A.Ho) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ox = 4 * tx + 2 * b - px;
+            if ((unsigned)ox >= (unsigned)A.Wo) continue;
+            f32x4 y = (b == 0 ? s[a][0] + s[a][1] : s[a][1] - s[a][2]) + bv;
+            if (A.act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], slope * y[e]);
+            }
+            *reinterpret_cast<f32x4 *>(A.out + (((long long)n * A.Ho + oy) * A.Wo + ox) * A.Cs_out + A.c_off + c * 4) = y;
+        }
+    }
+}
+#endif
+hipError_t launch_wdec_input(const float *x, int B, int Hi, int Wi, int Cs, float *V, const WdecGeom &g, hipStream_t stream);
+hipError_t launch_wdec_output(const float *M, int B, int Ho, int Wo, int cout, const float *bias, int act, float *out, int Cs_out, int c_off,
+                              const WdecGeom &g, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------
 // Small VALU kernels of the flow pyramid and the warp.
 // ---------------------------------------------------------------------------------
@@ -257,7 +328,8 @@ hipError_t launch_wino_output(const float *M, int B, int Ho, int Wo, int C, cons
 struct UpflowW { float w[64]; float b[2]; };   // w[ky][kx][co][ci]
 hipError_t launch_predict_up(const float *src, int ks, long long slab_stride, int B, int h, int w, const float *bias2,
                              const float *prev, int ph, int pw, float *out, const UpflowW &W, float *concat, int oh, int ow,
-                             int Cs, int c_off, hipStream_t stream, const ConvParams *combine = nullptr);
+                             int Cs, int c_off, hipStream_t stream, const ConvParams *combine = nullptr, const WdecOutArgs *wdec = nullptr);
+// wdec != null: the same launch also runs the inverse Winograd transform of the level's transposed convolution (wdec_output_item)
 // combine != null (with ksplit > 1): the same launch also sums that launch's split-K slabs into its output (the level's transposed
 // convolution, launched with combine = false): combine_predict_up_kernel
 
@@ -438,6 +510,10 @@ void pack_deconv5(const float *W, const double *scale, int cin, int cs_in, int c
 
 // 3x3 conv W[3][3][Cin][Cout] -> 16 Winograd-domain 1x1 operands (position xi = 4 i + j), phase xi starts at xi * ktiles * npad * 32
 void pack_winograd(const float *W, const double *scale, int cin, int cout, int npad, float *wpk);
+
+// 4x4 stride-2 transposed conv W[4][4][Cout][Cin] -> 9 Winograd F(2x2,2x2)-domain 1x1 operands (position 3 i + j), each [cs_in -> 4 cout]
+// with column = phase * cout + co (phase = 2 py + px); position p starts at p * ktiles * (4 cout) * 32
+void pack_wdec(const float *W, const double *scale, int cin, int cs_in, int cout, float *wpk);
 
 // predict head W[3][3][Cin][2] -> tap-table weights: 1x1 conv (run mode over cs_in) with 18 (pad npad)
 // output columns, col = tap*2 + o

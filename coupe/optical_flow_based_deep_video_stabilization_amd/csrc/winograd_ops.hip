@@ -207,6 +207,86 @@ __global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 2x2) for the 4x4 stride-2 SAME transposed convolutions of the decoder (model.py:850-851, 859-860, 868-869, 877-878:
+// y[oy,ox,co] = sum x[iy,ix,ci] W[ky,kx,co,ci] over oy = 2 iy + ky - 1).  Per axis, output parity p is a 2-tap stride-1 correlation of the
+// input:  y[2i] = x[i-1] W[3] + x[i] W[1],  y[2i+1] = x[i] W[2] + x[i+1] W[0].  Tile t takes the three inputs d = (x[2t-1], x[2t], x[2t+1])
+// and yields FOUR outputs: the even pair y[4t], y[4t+2] (taps g = (W[3], W[1])) and the odd pair y[4t-1], y[4t+1] (g = (W[2], W[0])) --
+// both pairs read the SAME d, so one transformed tile V feeds all four output phases:
+//     v = (d0 - d1, d1, d1 - d2),  u = (g0, g0 + g1, g1),  m_i = v_i u_i,  pair = (m0 + m1, m1 - m2)       3 multiplies for 2 outputs
+// In 2-D: 9 positions, each a GEMM [tiles x Cin] x [Cin x 4 Cout] (the four phases side by side in N): 36 multiply-adds per 4x4 output
+// block instead of 64.  The transforms have coefficients 0, +-1 only.  Tile grid per axis: NT = Ho/4 + 1 (the odd pair of tile 0 starts at
+// output -1, so an even Ho needs one more tile than Hin/2: its d is (x[Hin-1], 0, 0) and only v0 is non-zero); position row i needs the
+// tiles t < nt[i] with nt[0] = min(NT, Hin/2 + 1), nt[1] = nt[2] = min(NT, (Hin+1)/2) -- the others are identically zero and are
+// neither written here nor multiplied (the GEMM's phase grids are nt_y[i] x nt_x[j], the inverse transform reads them as zeros).
+//   wdec_input_kernel :  x [B,Hi,Wi,Cs] (all Cs floats of a pixel: the concat's pad channels are zeros and meet zero weights)
+//                        -> V [B][9][NTy][NTx][Cs]
+//   wdec_output_kernel:  M [B][9][NTy][NTx][4*Cout] (column = phase * Cout + co, phase = 2 py + px) -> out [B,Ho,Wo,Cs_out] channels
+//                        c_off..+Cout, + bias, leaky relu
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wdec_input_kernel(const float *__restrict__ x, int Hi, int Wi, int C4, float *__restrict__ V, const WdecGeom g)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)g.NTy * g.NTx * C4) return;
+    const int n = blockIdx.y;
+    const int c = (int)(idx % C4);
+    const int tile = (int)(idx / C4);
+    const int ty = tile / g.NTx, tx = tile - ty * g.NTx;
+    const int Cs = C4 * 4;
+    const float *xb = x + (long long)n * Hi * Wi * Cs + c * 4;
+    f32x4 d[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int y = 2 * ty - 1 + i;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int xx = 2 * tx - 1 + j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)y < (unsigned)Hi && (unsigned)xx < (unsigned)Wi) v = *reinterpret_cast<const f32x4 *>(xb + ((long long)y * Wi + xx) * Cs);
+            d[i][j] = v;
+        }
+    }
+    f32x4 t[3][3];                                  // rows: (d0 - d1, d1, d1 - d2)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t[0][j] = d[0][j] - d[1][j];
+        t[1][j] = d[1][j];
+        t[2][j] = d[1][j] - d[2][j];
+    }
+    const long long plane = (long long)g.NTy * g.NTx * Cs;
+    float *vb = V + (long long)n * 9 * plane + (long long)tile * Cs + c * 4;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (ty >= g.nty[i]) continue;
+        if (tx < g.ntx[0]) *reinterpret_cast<f32x4 *>(vb + (i * 3 + 0) * plane) = t[i][0] - t[i][1];
+        if (tx < g.ntx[1]) *reinterpret_cast<f32x4 *>(vb + (i * 3 + 1) * plane) = t[i][1];
+        if (tx < g.ntx[2]) *reinterpret_cast<f32x4 *>(vb + (i * 3 + 2) * plane) = t[i][1] - t[i][2];
+    }
+}
+
+__global__ __launch_bounds__(256) void wdec_output_kernel(const WdecOutArgs A)
+{
+    wdec_output_item(A, (long long)blockIdx.x * 256 + threadIdx.x, (int)blockIdx.y);
+}
+
+hipError_t launch_wdec_input(const float *x, int B, int Hi, int Wi, int Cs, float *V, const WdecGeom &g, hipStream_t stream)
+{
+    if ((Cs & 3) || B < 1) return hipErrorInvalidValue;
+    const long long per = (long long)g.NTy * g.NTx * (Cs / 4);
+    wdec_input_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(x, Hi, Wi, Cs / 4, V, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_wdec_output(const float *M, int B, int Ho, int Wo, int cout, const float *bias, int act, float *out, int Cs_out, int c_off,
+                              const WdecGeom &g, hipStream_t stream)
+{
+    if ((cout & 3) || (Cs_out & 3) || (c_off & 3) || B < 1) return hipErrorInvalidValue;
+    const WdecOutArgs A{M, cout / 4, bias, act, out, Ho, Wo, Cs_out, c_off, g};
+    const long long per = (long long)g.NTy * g.NTx * cout;
+    wdec_output_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(A);
+    return hipGetLastError();
+}
+
 // dM: [16][B*tiles][C] (position-major over the whole batch)
 hipError_t launch_wino_outgrad(const float *dy, int B, int H, int W, int Cs, int c_off, int C, float *dM, hipStream_t stream)
 {

@@ -429,6 +429,8 @@ VSTAB_API int vstab_warp_perspective_u8(const uint8_t *src, int B, int sh, int s
 #define VSTAB_PLAN_NO_SKINNY 1u
 #define VSTAB_PLAN_NO_DUAL 2u      /* a refinement level as four launches (tap table, predict_up, transposed conv, combine) instead of two */
 #define VSTAB_PLAN_NO_TAIL 4u      /* vstab_stabilise_originalsize: predict_flow2's gather and the glue + warp as two launches (bit-identical) */
+#define VSTAB_PLAN_NO_WDEC 8u      /* transposed convolutions as four direct sub-pixel phases, never in Winograd F(2x2,2x2) form (round 6) */
+#define VSTAB_PLAN_FORCE_WDEC 16u  /* deconv4 / deconv3 in Winograd F(2x2,2x2) form whatever their size (tests: small shapes) */
 VSTAB_API int vstab_set_plan_flags(vstab_ctx *ctx, unsigned flags);
 
 /* ---- measurement support.  With profiling enabled every conv-like launch of
@@ -497,6 +499,13 @@ VSTAB_API int vstab_host_layer_plan_pinned(int plan_batch, unsigned flags, int B
  * to `wpk` (capacity `cap` floats) and returns the number of floats, or a negative error. */
 VSTAB_API long long vstab_host_pack_layer(int Cin, int layer, const float *W, const double *scale,
                                           float *wpk, long long cap);
+
+/* The transposed convolution of refinement level l (0..3 = deconv5..deconv2) in Winograd F(2x2,2x2) form (csrc/winograd_ops.hip):
+ * the 9-position GEMM's plan in vstab_host_layer_plan's format (26 ints + 7 per position; `reserved` = 1 when the default plan of this
+ * problem chooses the form) followed by the tile geometry {NTy, NTx, nty[3], ntx[3]}; and its packed operands as vstab_load_weights
+ * builds them (W = the reference-layout filter [4][4][Cout][Cin]; 9 positions x [KT][4 Cout][32]). */
+VSTAB_API int vstab_host_wdec_plan(int B, int H, int W, int Cin, int l, int32_t *out, int cap);
+VSTAB_API long long vstab_host_pack_wdec(int l, const float *W, const double *scale, float *wpk, long long cap);
 
 #ifdef __cplusplus
 }

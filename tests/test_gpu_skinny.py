@@ -119,15 +119,16 @@ def test_two_launch_refinement_levels_equal_the_four_launch_sequence_bit_for_bit
     # a level's transposed convolution + tap-table GEMM in one launch (conv_dual_kernel) and its split-K combine + predict_up in one
     # launch (combine_predict_up_kernel) are the same workgroup programs as the four separate launches: identical bits, every level,
     # every internal tensor of the decoder.  (Flag 1 keeps the few-row layers on the tiled kernel in both runs: the four-launch
-    # sequence may otherwise put a transposed convolution on the weight-stream kernel, whose sums associate differently.)
+    # sequence may otherwise put a transposed convolution on the weight-stream kernel, whose sums associate differently; flag 8 keeps the
+    # transposed convolutions in their direct form in both runs: the Winograd form of round 6 exists in the two-problem launch only.)
     g = torch.Generator().manual_seed(B * 1000 + H)
     feats = torch.rand(B, H, W, 27, generator=g).cuda()
     names = ("concat5", "concat4", "concat3", "concat2")
-    ctx.set_plan_flags(1)
+    ctx.set_plan_flags(1 | 8)
     a = vs.flownetS_pyramid(feats, B)
     a = {k: a[k].clone() for k in KEYS}
     ia = {k: v.clone() for k, v in ctx.internals(B, H, W, 27).items() if k in names}
-    ctx.set_plan_flags(1 | 2)
+    ctx.set_plan_flags(1 | 2 | 8)
     b = vs.flownetS_pyramid(feats, B)
     ib = {k: v for k, v in ctx.internals(B, H, W, 27).items() if k in names}
     for k in names:

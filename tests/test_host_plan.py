@@ -203,3 +203,98 @@ def test_pinned_plan_is_the_plan_of_its_batch():
     assert _lib.lib().vstab_host_layer_plan_pinned(4, 0, 5, 384, 512, 27, 3, out, 200) < 0      # beyond the pinned batch
     # flag 1: the round-3 schedule (few-row layers on the tiled kernel with a combine launch)
     assert any(t[0] == 6 for t in layer_tiles(1, 256, 256)) and not any(t[0] == 6 for t in layer_tiles(1, 256, 256, flags=1))
+
+
+# ---- Winograd F(2x2,2x2) form of the transposed convolutions (round 6; csrc/winograd_ops.hip documents the algebra).  The host side --
+# tile geometry, the 9-position GEMM's plan, the packed operands -- is run through the numpy GEMM emulation between numpy statements
+# of the two transforms (the device kernels' arithmetic, statement for statement) and compared with the oracle's transposed convolution.
+def wdec_plan(B, H, W, l):
+    buf = (C.c_int32 * 128)()
+    n = _lib.lib().vstab_host_wdec_plan(B, H, W, 27, l, buf, 128)
+    assert n == 26 + 63 + 8
+    p = dict(zip(FIELDS, buf[:26]))
+    p["ph"] = [dict(zip(PH_FIELDS, buf[26 + 7 * k:33 + 7 * k])) for k in range(9)]
+    g = list(buf[89:97])
+    return p, dict(NTy=g[0], NTx=g[1], nty=g[2:5], ntx=g[5:8])
+
+
+def wdec_input_np(x, g):
+    """x [B,Hi,Wi,Cs] -> V [B, 9*NTy, NTx, Cs]; tiles a position does not need stay NaN (the GEMM must not read them)."""
+    B, Hi, Wi, Cs = x.shape
+    xp = np.zeros((B, 2 * g["NTy"] + 2, 2 * g["NTx"] + 2, Cs))
+    xp[:, 1:1 + Hi, 1:1 + Wi] = x                                   # xp[r] = x[r - 1]: tile t reads rows 2t-1 .. 2t+1 = xp[2t .. 2t+2]
+    V = np.full((B, 9 * g["NTy"], g["NTx"], Cs), np.nan)
+    d = [[xp[:, i:i + 2 * g["NTy"]:2, j:j + 2 * g["NTx"]:2] for j in range(3)] for i in range(3)]
+    t = [[d[0][j] - d[1][j] for j in range(3)], [d[1][j] for j in range(3)], [d[1][j] - d[2][j] for j in range(3)]]
+    for i in range(3):
+        v = [t[i][0] - t[i][1], t[i][1], t[i][1] - t[i][2]]
+        for j in range(3):
+            pos = i * 3 + j
+            V[:, pos * g["NTy"]:pos * g["NTy"] + g["nty"][i], :g["ntx"][j]] = v[j][:, :g["nty"][i], :g["ntx"][j]]
+    return V
+
+
+def wdec_output_np(M, g, cout, Ho, Wo):
+    """M [B, 9*NTy, NTx, 4*cout] (NaN where the GEMM wrote nothing) -> y [B,Ho,Wo,cout]"""
+    B = M.shape[0]
+    m = [[None] * 3 for _ in range(3)]
+    for i in range(3):
+        for j in range(3):
+            pos = i * 3 + j
+            blk = np.zeros((B, g["NTy"], g["NTx"], 4 * cout))
+            blk[:, :g["nty"][i], :g["ntx"][j]] = M[:, pos * g["NTy"]:pos * g["NTy"] + g["nty"][i], :g["ntx"][j]]
+            m[i][j] = blk
+    y = np.full((B, Ho, Wo, cout), np.nan)
+    s = [[m[0][j] + m[1][j] for j in range(3)], [m[1][j] - m[2][j] for j in range(3)]]
+    for a in range(2):
+        for b in range(2):
+            blk = s[a][0] + s[a][1] if b == 0 else s[a][1] - s[a][2]
+            for py in range(2):
+                for px in range(2):
+                    for ty in range(g["NTy"]):
+                        oy = 4 * ty + 2 * a - py
+                        if not 0 <= oy < Ho:
+                            continue
+                        ox = 4 * np.arange(g["NTx"]) + 2 * b - px
+                        ok = (ox >= 0) & (ox < Wo)
+                        ph = 2 * py + px
+                        y[:, oy, ox[ok]] = blk[:, ty, ok, ph * cout:(ph + 1) * cout]
+    return y
+
+
+@pytest.mark.parametrize("l", [1, 2, 3])
+@pytest.mark.parametrize("HW", [(64, 64), (88, 104), (96, 128)])     # (88, 104): odd output grids on some levels
+def test_winograd_deconv_geometry_packing_and_transforms(l, HW):
+    H, W = HW
+    B = 2
+    d = layer_plan(B, H, W, 27, 10 + l)                               # the direct form: sizes and channel strides
+    p, g = wdec_plan(B, H, W, l)
+    cin = (1024, 1026, 770, 386)[l]
+    cout = (512, 256, 128, 64)[l]
+    assert p["N"] == 4 * cout and p["nphase"] == 9 and p["Cs_in"] == d["Cs_in"] and p["ksplit"] == 1
+    assert g["NTy"] == d["Ho"] // 4 + 1 and g["NTx"] == d["Wo"] // 4 + 1
+    rng = np.random.default_rng(20 + l)
+    inp = rng.standard_normal((B, d["Hi"], d["Wi"], d["Cs_in"]))
+    inp[..., cin:] = 0.0                                              # the concat's pad channels are zeros (and meet zero weights)
+    Wt = (rng.standard_normal((4, 4, cout, cin)) * 0.1).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout)
+    cap = 9 * (p["SEGP"] // 32) * 4 * cout * 32
+    wpk = np.zeros(cap, np.float32)
+    n = _lib.lib().vstab_host_pack_wdec(l, Wt.ctypes.data_as(_lib.c_float_p), scale.ctypes.data_as(C.POINTER(C.c_double)),
+                                        wpk.ctypes.data_as(_lib.c_float_p), cap)
+    assert n == cap
+    V = wdec_input_np(inp, g)
+    assert p["Hi"] == V.shape[1] and p["Wi"] == V.shape[2]
+    Vz = np.where(np.isnan(V), 1e30, V)                               # a tile the GEMM should skip would blow the result up
+    M = emulate(Vz, p, wpk)
+    got = wdec_output_np(M, g, cout, d["Ho"], d["Wo"])
+    ref = vo.deconv4x4s2(torch.from_numpy(inp[..., :cin].copy()), torch.from_numpy(Wt.astype(np.float64)), None,
+                         (d["Ho"], d["Wo"])).numpy() * scale
+    assert not np.isnan(got).any()                                    # every output pixel is produced
+    assert np.abs(got - ref).max() < 2e-6 * max(1, np.abs(ref).max())       # operands are fp32(G g G^T * scale)
+    # multiply-adds per output channel and input channel: one per GEMM row and phase column against four taps per output pixel, direct
+    issued = sum(ph["M"] for ph in p["ph"]) * 4
+    direct = B * d["Ho"] * d["Wo"] * 4
+    assert issued / direct >= 9 / 16                                  # 9 multiplies per 4x4 outputs x 4 ... / 64, plus the ragged grid
+    if min(d["Hi"], d["Wi"]) >= 12:
+        assert issued / direct < 0.75, issued / direct
