@@ -11,7 +11,8 @@ largest difference between the default plan and the other plans (two kernel fami
 Shapes: BASELINE configs[0] (1x256x256), the reference's native 1x384x512 (main:491), configs[1] (8x512x512: sample 0 of a batch
 of eight copies), one 720p sample (configs[2]'s shape).  Weight sets: He-normal + identity BatchNorm (what bench.py times),
 random BatchNorm statistics with flow_gain 1 and 2 (what the parity tests use; flows of tens to ~200 px).
-Plan flags: 0 default, 1 = few-row layers on the tiled kernel, 2 = refinement levels as four launches, 3 = both (round-3 schedule).
+Plan flags: 0 default, 1 = few-row layers on the tiled kernel, 2 = refinement levels as four launches, 3 = both (round-3 schedule),
+8 = transposed convolutions never in Winograd F(2x2,2x2) form (round 6: the default plan uses the form for deconv3 of the cfg1 cells).
 """
 import argparse
 import json
@@ -62,7 +63,7 @@ def main():
             cpu32 = {k: float((ref32[k][0].double() - ref[k][0]).abs().max()) for k in vo.FLOW_KEYS}
             feats = torch.from_numpy(one).cuda().expand(B, -1, -1, -1).contiguous()
             base = None
-            for flags in (0, 1, 2, 3):
+            for flags in (0, 1, 2, 3, 8):
                 runtime.reset()
                 vs.assign_weights(w)
                 ctx = runtime.get_context()
@@ -92,13 +93,14 @@ def main():
                 f"{m['predict_flow3']:.1f} / {m['predict_flow2']:.1f} | **{e[worst] / TOL:.2f}** ({worst[-1]}) | "
                 f"{cell['err_in_eps_of_flow']['predict_flow2']:.1f} | {cell['cpu_fp32_err']['predict_flow2']:.2e} | {vd:.2e} |")
 
-    lines = ["# Parity headroom of the flow outputs (round 5 schedule)", "",
+    lines = ["# Parity headroom of the flow outputs (round 6 schedule)", "",
              "Generated by `scripts/flow_err_margin.py` on the GPU box; every figure is sample 0 of the batch against the **fp64** CPU restatement",
              "(`oracle/vstab_oracle.py`; parity unpinned: TensorFlow 1.10 cannot run here).  Tolerance 1e-3 max-abs (BASELINE.json north_star).",
              "`frac` = worst level's error / 1e-3 (the level in brackets).  `pf2 err / (eps·max|pf2|)` = predict_flow2's error in units of one fp32",
              "epsilon of the largest flow.  `CPU fp32` = predict_flow2 error of the torch-CPU **fp32** restatement against the same fp64 result: the noise floor",
              "any fp32 evaluation of this graph sits on (TensorFlow's CPU kernels included), for this weight set and input.  `vs default` = largest difference of any level to the default plan's result (two kernel families / launch",
-             "schedules for the same layers: plan flags 1 = few-row layers on the tiled kernel, 2 = refinement levels as four launches, 3 = both).", "",
+             "schedules for the same layers: plan flags 1 = few-row layers on the tiled kernel, 2 = refinement levels as four launches, 3 = both,",
+             "8 = transposed convolutions in their direct form only -- the default plan runs deconv3 of the cfg1 cells in Winograd F(2x2,2x2) form).", "",
              "| weights | shape | flags | pf6 | pf5 | pf4 | pf3 | pf2 | max\\|pf3\\| / max\\|pf2\\| | frac of 1e-3 | pf2 err / (eps·max\\|pf2\\|) | CPU fp32 pf2 err | vs default |",
              "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     lines += [fmt(c) for c in cells]
