@@ -17,8 +17,23 @@ namespace vstab {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The transformed planes of a LARGE stage leave as non-temporal stores (NT = true): V is 4x (9/4 x) the stage's input and, from about the
+// Infinity Cache's 256 MB down to half of it, writing it through the caches only evicts what the GEMM that follows would still find there
+// (round 6, one box: conv3_1's transform at B=8 512x512, V = 134 MB, 33.9 -> 26.4 us and its GEMM 133.2 -> 130.7 us; the SMALLER V of
+// deconv3, 64 MB, is better left cached: its GEMM 155.5 -> 171.9 us with non-temporal stores) -- launch_wino_input / launch_wdec_input decide
+#ifndef VSTAB_NT_MIN_BYTES
+#define VSTAB_NT_MIN_BYTES (100ll << 20)          // (A/B builds: scripts/build_variant_lib.sh -DVSTAB_NT_MIN_BYTES=...)
+#endif
+template <bool NT>
+__device__ __forceinline__ void vstore(float *p, const f32x4 v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
+    else *reinterpret_cast<f32x4 *>(p) = v;
+}
+
 // (sample_stride, pos_stride) in floats: (16*tiles*C, tiles*C) = [B][16][tiles][C] for the forward GEMM's phases,
 // (tiles*C, B*tiles*C) = [16][B*tiles][C] when the reduction runs over all tiles of the batch (filter gradient)
+template <bool NT>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int H, int W, int Cs, int c_off, int C4,
                                                          float *__restrict__ V, int TH, int TW, long long sample_stride, long long pos_stride)
 {
@@ -54,10 +69,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
     const long long xs = pos_stride;                                         // stride between the 16 positions
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 0) * xs) = t[i][0] - t[i][2];
-        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 1) * xs) = t[i][1] + t[i][2];
-        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 2) * xs) = t[i][2] - t[i][1];
-        *reinterpret_cast<f32x4 *>(vb + (i * 4 + 3) * xs) = t[i][1] - t[i][3];
+        vstore<NT>(vb + (i * 4 + 0) * xs, t[i][0] - t[i][2]);
+        vstore<NT>(vb + (i * 4 + 1) * xs, t[i][1] + t[i][2]);
+        vstore<NT>(vb + (i * 4 + 2) * xs, t[i][2] - t[i][1]);
+        vstore<NT>(vb + (i * 4 + 3) * xs, t[i][1] - t[i][3]);
     }
 }
 
@@ -224,6 +239,7 @@ __global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float *__re
 //   wdec_output_kernel:  M [B][9][NTy][NTx][4*Cout] (column = phase * Cout + co, phase = 2 py + px) -> out [B,Ho,Wo,Cs_out] channels
 //                        c_off..+Cout, + bias, leaky relu
 // ---------------------------------------------------------------------------------------------------------------------------------
+template <bool NT>
 __global__ __launch_bounds__(256) void wdec_input_kernel(const float *__restrict__ x, int Hi, int Wi, int C4, float *__restrict__ V, const WdecGeom g)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -258,9 +274,9 @@ __global__ __launch_bounds__(256) void wdec_input_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         if (ty >= g.nty[i]) continue;
-        if (tx < g.ntx[0]) *reinterpret_cast<f32x4 *>(vb + (i * 3 + 0) * plane) = t[i][0] - t[i][1];
-        if (tx < g.ntx[1]) *reinterpret_cast<f32x4 *>(vb + (i * 3 + 1) * plane) = t[i][1];
-        if (tx < g.ntx[2]) *reinterpret_cast<f32x4 *>(vb + (i * 3 + 2) * plane) = t[i][1] - t[i][2];
+        if (tx < g.ntx[0]) vstore<NT>(vb + (i * 3 + 0) * plane, t[i][0] - t[i][1]);
+        if (tx < g.ntx[1]) vstore<NT>(vb + (i * 3 + 1) * plane, t[i][1]);
+        if (tx < g.ntx[2]) vstore<NT>(vb + (i * 3 + 2) * plane, t[i][1] - t[i][2]);
     }
 }
 
@@ -273,7 +289,9 @@ hipError_t launch_wdec_input(const float *x, int B, int Hi, int Wi, int Cs, floa
 {
     if ((Cs & 3) || B < 1) return hipErrorInvalidValue;
     const long long per = (long long)g.NTy * g.NTx * (Cs / 4);
-    wdec_input_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(x, Hi, Wi, Cs / 4, V, g);
+    const dim3 grid((unsigned)((per + 255) / 256), (unsigned)B);
+    if ((long long)B * 9 * g.NTy * g.NTx * Cs * 4 >= VSTAB_NT_MIN_BYTES) wdec_input_kernel<true><<<grid, dim3(256), 0, stream>>>(x, Hi, Wi, Cs / 4, V, g);
+    else wdec_input_kernel<false><<<grid, dim3(256), 0, stream>>>(x, Hi, Wi, Cs / 4, V, g);
     return hipGetLastError();
 }
 
@@ -317,8 +335,11 @@ hipError_t launch_wino_input(const float *x, int B, int H, int W, int Cs, int c_
     if ((C & 3) || (Cs & 3) || (c_off & 3)) return hipErrorInvalidValue;
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
     const long long per = (long long)TH * TW * (C / 4), tc = (long long)TH * TW * C;
-    wino_input_kernel<<<dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, stream>>>(x, H, W, Cs, c_off, C / 4, V, TH, TW,
-                                                                                              pos_major ? tc : 16 * tc, pos_major ? B * tc : tc);
+    const dim3 grid((unsigned)((per + 255) / 256), (unsigned)B);
+    if ((long long)B * 16 * tc * 4 >= VSTAB_NT_MIN_BYTES)
+        wino_input_kernel<true><<<grid, dim3(256), 0, stream>>>(x, H, W, Cs, c_off, C / 4, V, TH, TW, pos_major ? tc : 16 * tc, pos_major ? B * tc : tc);
+    else
+        wino_input_kernel<false><<<grid, dim3(256), 0, stream>>>(x, H, W, Cs, c_off, C / 4, V, TH, TW, pos_major ? tc : 16 * tc, pos_major ? B * tc : tc);
     return hipGetLastError();
 }
 
